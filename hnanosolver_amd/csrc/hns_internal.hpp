@@ -1,0 +1,73 @@
+// hns_internal.hpp -- shared declarations of libhns.so (not part of the public ABI; see include/hns.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "hns.h"
+
+namespace hns {
+
+// ---- error plumbing -------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+inline int fail(int code, const char* msg) {
+	set_error("%s", msg);
+	return code;
+}
+
+// ---- host topology ----------------------------------------------------------------------------------------------
+// Replaces the NanoGrid<ValueOnIndex> tree walk (reference Stencils.hpp:51-71 -> NanoVDB.h:5549) with flat tables:
+//   origins[l]      leaf origin (8-aligned), l = position of the leaf in the caller's coordinate array
+//   nbr27[l][27]    leaf index of the 27 surrounding leaves ((dx+1)*9+(dy+1)*3+(dz+1)), -1 = absent
+//   hash            open-addressing map origin -> leaf for taps further than one leaf away
+struct Topology {
+	std::vector<int32_t> origins;  // n_leaves * 4 (x, y, z, pad) -- int4 on the device
+	std::vector<int32_t> nbr27;    // n_leaves * 27
+	std::vector<int32_t> hash;     // table_size entries, -1 = empty
+	uint32_t hash_mask = 0;
+	int64_t n_leaves = 0;
+
+	// Returns HNS_OK or HNS_ERR_TOPOLOGY (message set).
+	int build(const int32_t* leaf_origins_xyz, int64_t n_leaves);
+	int64_t find_leaf(int32_t ox, int32_t oy, int32_t oz) const;
+	uint64_t offset(int32_t i, int32_t j, int32_t k) const;  // 1-based, 0 = outside
+};
+
+uint32_t hash_origin(int32_t x, int32_t y, int32_t z);
+
+// Device view handed to every kernel by value.
+struct GridDev {
+	const int4* origins;
+	const int* nbr27;
+	const int* hash;
+	const int* sched;  // block -> leaf order (XCD-chunked), n_active entries
+	uint32_t hash_mask;
+	int n_leaves;
+	int n_active;
+};
+
+}  // namespace hns
+
+struct hns_grid {
+	hns::Topology topo;
+	float voxel_size = 1.0f;
+	uint64_t n_active = 0;
+	bool on_device = false;
+	int device = -1;
+	// device copies
+	void* d_origins = nullptr;
+	void* d_nbr27 = nullptr;
+	void* d_hash = nullptr;
+	void* d_sched = nullptr;
+	hns::GridDev dev() const;
+};
+
+// implemented in hns_api.hip
+int hns_grid_upload(hns_grid* g);
+void hns_grid_free_device(hns_grid* g);
+int hns_grid_upload_schedule(hns_grid* g);

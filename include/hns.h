@@ -1,0 +1,192 @@
+/*
+ * hns.h -- C ABI of libhns.so: the MI355X-native (HIP, gfx950) implementation of HNanoSolver's per-substep hot path.
+ *
+ * This is the drop-in boundary. Each entry point replaces one of the reference's `extern "C"` C++-typed functions
+ * (paths relative to the reference checkout), keeping argument meaning, synchronous in-place semantics and refusal
+ * conditions, but with plain pointers/sizes and int return codes instead of C++ types and exceptions:
+ *
+ *   hns_grid_create                 <- CreateIndexGrid          src/Cuda/HNanoSolver.cu:375-390   (decl. src/SOP/HNanoSolver/SOP_HNanoSolver.hpp:82)
+ *   hns_compute_sim                 <- Compute_Sim              src/Cuda/HNanoSolver.cu:9-372,393-396 (decl. SOP_HNanoSolver.hpp:84-85)
+ *   hns_advect_index_grid           <- AdvectIndexGrid          src/Cuda/Advection.cu:13-112,169-171  (decl. src/SOP/VDBAdvect/SOP_VDBAdvect.hpp:66)
+ *   hns_advect_index_grid_velocity  <- AdvectIndexGridVelocity  src/Cuda/Advection.cu:114-166,173-175 (decl. src/SOP/VDBAdvectVelocity/SOP_VDBAdvectVelocity.hpp:60)
+ *   hns_project_non_divergent       <- ProjectNonDivergent      src/Cuda/PressureProjection.cu:9-78,132-135 (decl. src/SOP/VDBProjectNonDivergent/SOP_VDBProjectNonDivergent.hpp:69)
+ *   hns_divergence                  <- Divergence               src/Cuda/PressureProjection.cu:81-129       (decl. SOP_VDBProjectNonDivergent.hpp:70)
+ *
+ * The type crossing the boundary in the reference is HNS::GridIndexedData (src/Utils/GridData.hpp:16-166): a
+ * coordinate array plus named float / Vec3f blocks in insertion order. Here it is `hns_field[]` (same order) and the
+ * `hns_grid` handle built from the coordinate array. All host arrays are caller-owned and overwritten in place.
+ *
+ * Data layout (identical to the reference's): flat leaf-dense arrays, element = leaf*512 + (x<<6 | y<<3 | z) where
+ * leaf l is the l-th block of 512 coordinates handed to hns_grid_create (src/Utils/GridBuilder.hpp:156-166);
+ * Vec3f fields are AoS float[3] on the host. All arithmetic is float32.
+ *
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream). Every host-pointer entry point is
+ * synchronous: it returns after the stream has drained, like the reference's cudaStreamSynchronize at the end of
+ * each driver (HNanoSolver.cu:371, PressureProjection.cu:72, Advection.cu:99-103,158).
+ *
+ * There is no CPU fallback: without a usable HIP device every compute entry point fails with HNS_ERR_NO_DEVICE.
+ */
+#ifndef HNS_H
+#define HNS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HNS_VERSION 100
+
+/* Return codes. Negative = failure; hns_last_error() holds the message (thread-local). */
+#define HNS_OK 0
+#define HNS_ERR_INVALID_ARGUMENT (-1) /* the reference throws std::invalid_argument (HNanoSolver.cu:12-23) */
+#define HNS_ERR_RUNTIME (-2)          /* the reference throws std::runtime_error  (HNanoSolver.cu:44,62,196; Advection.cu:20,28) */
+#define HNS_ERR_HIP (-3)              /* a HIP runtime call failed (the reference's CUDA_CHECK, Utils.cuh:10-18) */
+#define HNS_ERR_NO_DEVICE (-4)        /* no HIP device / host-only grid */
+#define HNS_ERR_TOPOLOGY (-5)         /* coordinates are not leaf-dense 8^3 blocks, or a leaf appears twice */
+
+const char* hns_last_error(void);
+int hns_version(void);
+int hns_device_count(void); /* 0 when no HIP device is visible; never initialises a device context */
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Index grid (topology)                                                                                         */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+typedef struct hns_grid hns_grid;
+
+#define HNS_GRID_DEFAULT 0u
+#define HNS_GRID_HOST_ONLY 1u     /* build the host tables only (no device upload); compute calls then fail */
+#define HNS_GRID_SKIP_VALIDATE 2u /* trust that coords are leaf-dense; only every 512th coordinate is read */
+
+/* Replaces CreateIndexGrid. coords_xyz = n_voxels x 3 int32 (openvdb::Coord[n], GridData.hpp:95), leaf-dense: each
+ * consecutive block of 512 is one 8^3 leaf in x<<6|y<<3|z order. The flat index of coords[i] is i by construction
+ * (the reference relies on offset(coords[i]) == i+1, Kernel.cu:505 vs :511). */
+hns_grid* hns_grid_create(const int32_t* coords_xyz, uint64_t n_voxels, float voxel_size, unsigned flags, int* err);
+/* Same topology from the 8-aligned leaf origins alone (n_leaves x 3). */
+hns_grid* hns_grid_create_from_leaves(const int32_t* leaf_origins_xyz, uint64_t n_leaves, float voxel_size, unsigned flags, int* err);
+void hns_grid_destroy(hns_grid*);
+
+uint64_t hns_grid_leaf_count(const hns_grid*);
+uint64_t hns_grid_voxel_count(const hns_grid*);
+float hns_grid_voxel_size(const hns_grid*);
+/* Kernels update leaves [0, n_active) only; leaves [n_active, leaf_count) are ghosts that are read but never written
+ * (multi-GPU halo leaves). Default n_active = leaf_count. */
+int hns_grid_set_active_leaves(hns_grid*, uint64_t n_active);
+uint64_t hns_grid_active_leaves(const hns_grid*);
+/* Host-side queries (work on HOST_ONLY grids): IndexOffsetSampler<0>::offset (Stencils.hpp:59-61): 1-based, 0 = outside. */
+int hns_grid_offsets(const hns_grid*, const int32_t* ijk, uint64_t n, uint64_t* out);
+/* 27-neighbour leaf table, n_leaves x 27 int32, entry (dx+1)*9+(dy+1)*3+(dz+1), -1 = absent. */
+int hns_grid_neighbor_table(const hns_grid*, int32_t* out);
+/* Writes the n_voxels x 3 coordinate array the grid represents (what the reference keeps as d_coords). */
+int hns_grid_coords(const hns_grid*, int32_t* out_xyz);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Drop-in operators (host pointers in, results in place, synchronous)                                           */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+typedef struct {
+	const char* name; /* block name, e.g. "density", "vel", "collision_sdf" */
+	int ncomp;        /* 1 = float block, 3 = Vec3f block (AoS) */
+	float* host;      /* n_voxels * ncomp floats, caller-owned */
+} hns_field;
+
+typedef struct { /* CombustionParams, src/Cuda/Kernels.cuh:6-13 */
+	float expansionRate, temperatureRelease, buoyancyStrength, ambientTemp, vorticityScale, factorScale;
+} hns_combustion_params;
+
+/* Compute_Sim: [collision] -> advect_vector -> vorticity -> divergence -> combustion -> buoyancy -> `iterations` x
+ * (red, black) SOR sweeps -> gradient subtraction -> [collision] -> advect_scalars over every float block except
+ * "collision_sdf". Requires exactly one ncomp==3 field, >=1 float field, and float fields named fuel, waste,
+ * temperature, flame (HNanoSolver.cu:42-63,193-201). omega = 2/(1+sinf(3.14159f*voxel_size)) (:257). */
+int hns_compute_sim(hns_grid*, hns_field* fields, int n_fields, int iterations, float dt, float voxel_size,
+                    const hns_combustion_params* params, int has_collision, void* stream);
+/* AdvectIndexGrid: every float field through the single-field BFECC kernel (advect_scalar), no collision. */
+int hns_advect_index_grid(hns_grid*, hns_field* fields, int n_fields, float dt, float voxel_size, void* stream);
+/* AdvectIndexGridVelocity: BFECC self-advection of the one Vec3f field. */
+int hns_advect_index_grid_velocity(hns_grid*, hns_field* fields, int n_fields, float dt, float voxel_size, void* stream);
+/* ProjectNonDivergent: divergence -> iterations x (red, black) -> u -= grad p. omega uses double sin (PressureProjection.cu:53). */
+int hns_project_non_divergent(hns_grid*, hns_field* fields, int n_fields, uint64_t iterations, float voxel_size, void* stream);
+/* Divergence: writes the float field named "divergence" (PressureProjection.cu:91). */
+int hns_divergence(hns_grid*, hns_field* fields, int n_fields, float voxel_size, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Device-resident simulation state (upload once, many substeps; what bench.py and the multi-GPU driver use)      */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+typedef struct hns_sim hns_sim;
+
+/* Allocates velocity + the named float fields + scratch on the current device. Field order = insertion order. */
+hns_sim* hns_sim_create(hns_grid*, const char* const* float_names, int n_float, int* err);
+void hns_sim_destroy(hns_sim*);
+int hns_sim_upload(hns_sim*, const hns_field* fields, int n_fields, void* stream);   /* matches fields by name; ncomp 3 = velocity */
+int hns_sim_download(hns_sim*, hns_field* fields, int n_fields, void* stream);       /* synchronous */
+/* One Compute_Sim substep entirely on the device (no H2D/D2H, no allocation, asynchronous on `stream`). */
+int hns_sim_substep(hns_sim*, int iterations, float dt, float voxel_size, const hns_combustion_params*, int has_collision, void* stream);
+/* The metric's core substep: advect_vector -> divergence -> iterations x RB-SOR -> gradient subtraction ->
+ * advect_scalars over every float field (SURVEY.md 8d "core substep"); asynchronous on `stream`. */
+int hns_sim_core_substep(hns_sim*, int iterations, float dt, float voxel_size, void* stream);
+/* Only the pressure hot loop on the sim's divergence/pressure buffers (pressure zeroed first); asynchronous. */
+int hns_sim_pressure_solve(hns_sim*, int iterations, float voxel_size, void* stream);
+/* Raw device pointers of the sim's buffers (ux,uy,uz planar velocity, float fields, divergence, pressure). */
+float* hns_sim_velocity_ptr(hns_sim*, int component);
+float* hns_sim_field_ptr(hns_sim*, const char* name);
+float* hns_sim_divergence_ptr(hns_sim*);
+float* hns_sim_pressure_ptr(hns_sim*);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Kernel-level entry points on caller-owned DEVICE memory (asynchronous on `stream`).                           */
+/* Velocity is planar on the device: three float arrays (ux, uy, uz), each leaf-dense like a float field.        */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+int hns_dev_aos_to_soa(const float* aos3, float* x, float* y, float* z, uint64_t n, void* stream);
+int hns_dev_soa_to_aos(const float* x, const float* y, const float* z, float* aos3, uint64_t n, void* stream);
+
+/* advect_vector (Kernel.cu:354-453) */
+int hns_dev_advect_vector(hns_grid*, const float* ux, const float* uy, const float* uz, float* ox, float* oy, float* oz, const float* sdf,
+                          int has_collision, float dt, float inv_dx, void* stream);
+/* advect_scalar (Kernel.cu:269-352) */
+int hns_dev_advect_scalar(hns_grid*, const float* ux, const float* uy, const float* uz, const float* in, float* out, const float* sdf,
+                          int has_collision, float dt, float inv_dx, void* stream);
+/* advect_scalars (Kernel.cu:118-266); in/out are HOST arrays of n device pointers */
+int hns_dev_advect_scalars(hns_grid*, const float* ux, const float* uy, const float* uz, const float* const* in, float* const* out, int n,
+                           const float* sdf, int has_collision, float dt, float inv_dx, void* stream);
+/* divergence / divergence_opt (Kernel.cu:455-519) */
+int hns_dev_divergence(hns_grid*, const float* ux, const float* uy, const float* uz, float* div, float inv_dx, void* stream);
+/* One colour of redBlackGaussSeidelUpdate(_opt) in place (Kernel.cu:521-623): the two-launch form. */
+int hns_dev_rbgs_color(hns_grid*, const float* div, float* p, float dx, float omega, int color, void* stream);
+/* `iterations` full (red, black) iterations with one fused launch per iteration, ping-ponging p_a -> p_b -> p_a ...
+ * Bit-identical to 2*iterations calls of hns_dev_rbgs_color. Result is in p_a when iterations is even, else p_b
+ * (*result_in_b tells). p_a and p_b must not alias. */
+int hns_dev_rbgs_iterate(hns_grid*, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int* result_in_b,
+                         void* stream);
+/* subtractPressureGradient(_opt) (Kernel.cu:694-829); out may alias u (each voxel reads only its own u) */
+int hns_dev_subtract_pressure_gradient(hns_grid*, const float* ux, const float* uy, const float* uz, const float* p, float* ox, float* oy,
+                                       float* oz, const float* sdf, int has_collision, float inv_dx, void* stream);
+/* combustion_oxygen (Kernel.cu:923-966) */
+int hns_dev_combustion_oxygen(const float* fuel, const float* waste, const float* temperature, float* divergence, const float* flame,
+                              float* out_fuel, float* out_waste, float* out_temperature, float* out_flame, float temp_gain, float expansion,
+                              uint64_t n, void* stream);
+/* temperature_buoyancy (Kernel.cu:831-847): only the y component changes */
+int hns_dev_temperature_buoyancy(const float* uy, const float* temperature, float* out_uy, float dt, float ambient, float strength, uint64_t n,
+                                 void* stream);
+/* vorticityConfinement (Kernel.cu:970-1024), out-of-place (the reference's in-place launch races when factor_scale >= 1) */
+int hns_dev_vorticity_confinement(hns_grid*, const float* ux, const float* uy, const float* uz, float* ox, float* oy, float* oz, float dt,
+                                  float inv_dx, float confinement_scale, float factor_scale, void* stream);
+/* enforceCollisionBoundaries (Kernel.cu:77-116), in place */
+int hns_dev_enforce_collision_boundaries(hns_grid*, float* ux, float* uy, float* uz, const float* sdf, float voxel_size, void* stream);
+
+/* Halo support for leaf-partitioned multi-GPU runs: copy whole leaves (512 floats each) between a field and a packed
+ * buffer. leaf_ids is a DEVICE array of n leaf indices. */
+int hns_dev_pack_leaves(const float* field, const int32_t* leaf_ids, uint64_t n, float* packed, void* stream);
+int hns_dev_unpack_leaves(const float* packed, const int32_t* leaf_ids, uint64_t n, float* field, void* stream);
+
+/* Timing helper: runs `iterations` fused RB-SOR iterations `reps` times on `stream`, bracketing each launch group with
+ * hipEvents on that stream, and returns the mean milliseconds per fused-iteration launch. */
+int hns_dev_time_rbgs(hns_grid*, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int reps, float* ms_per_launch,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HNS_H */

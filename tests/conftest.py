@@ -1,0 +1,34 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build_oracle():
+    """The oracle is test infrastructure: make sure liboracle.so (and, when the reference checkout is present,
+    oracle/_ref/libhns_ref.so) exist before any test imports them."""
+    odir = os.path.join(ROOT, "oracle")
+    if not os.path.exists(os.path.join(odir, "liboracle.so")) or (
+        os.path.exists("/root/reference/src/Utils/Stencils.hpp") and not os.path.exists(os.path.join(odir, "_ref", "libhns_ref.so"))
+    ):
+        subprocess.run(["make", "-C", odir], check=True, capture_output=True)
+    yield
+
+
+def has_gpu() -> bool:
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
