@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- solver substeps/s of the HNanoSolver hot path on MI355X, with the pressure stencil's HBM roofline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 256|128|64|plume] [--iterations 50]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one core substep on device-resident fields: advect_vector -> divergence -> 50 red-black
+SOR iterations -> pressure-gradient subtraction -> advect_scalars (S=1), i.e. 688 algorithmic bytes per voxel. Inputs
+are the closed-form synthetic fields of hnanosolver_amd.fields, already resident in HBM when the timed region starts.
+
+N = 1: the workload is BASELINE.json's roofline configuration, the 256^3 dense-active grid (16,777,216 voxels).
+N > 1: weak scaling -- every rank owns one such x-slab of a (256*N) x 256 x 256 domain; ranks exchange the halo
+leaves of u / p / phi over RCCL each time the reference would have a global kernel boundary that the stencil crosses
+(hnanosolver_amd/dist.py). `value` = slab-substeps/s summed over ranks = N x (global substeps/s).
+
+Rank 0 prints ONE JSON line. `roofline`: dominant kernel k_rbgs_fused, algorithmic 12 B/voxel per launch (read p, read
+div, write p once each), launch time from hipEvents recorded on the launch stream around the pressure loop of every
+timed step. `cpu_baseline`: the oracle (C restatement of the reference kernels, OpenMP over leaves) on the host cores,
+rank 0 at N=1 only, on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+BYTES_PER_VOXEL_ITER = 12  # RB-SOR per iteration reads p, reads div, writes p once each
+BYTES_PER_VOXEL_SUBSTEP = 688  # advect_vector 24 + divergence 16 + 50*12 + gradient 28 + advect_scalars(S=1) 20
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="256", help="256 (default, roofline config) | 128 | 64 | plume")
+    ap.add_argument("--iterations", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(origins, R, iterations, budget_s=25.0):
+    """Time the oracle (test infrastructure, here only as the reported CPU baseline) on a bounded sample: the SAME
+    workload with `it_s` pressure iterations instead of `iterations`, extrapolated linearly in the iteration count
+    (every iteration does identical work)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hnanosolver_amd import fields
+    from oracle_lib import OracleGrid, oracle
+
+    L = oracle()
+    cores = int(L.orc_get_threads())
+    G = OracleGrid(origins)
+    f = fields.synthetic_fields(origins, R)
+    vs = 1.0 / R
+    inv_dx, dt = float(R), 1.0 / 24.0
+    omega = float(L.orc_omega_compute(vs))
+    t0 = time.perf_counter()
+    adv = G.advect_vector(f["vel"], dt, inv_dx)
+    div = G.divergence(adv, inv_dx)
+    t_pre = time.perf_counter() - t0
+    p = np.zeros(G.N, dtype=np.float32)
+    it_s, t_it = 0, 0.0
+    while it_s < iterations and (it_s < 2 or t_it + t_pre * 2 < budget_s * 0.6):
+        t1 = time.perf_counter()
+        G.rbgs(div, p, vs, 0, omega)
+        G.rbgs(div, p, vs, 1, omega)
+        t_it += time.perf_counter() - t1
+        it_s += 1
+    t2 = time.perf_counter()
+    u = G.subtract_pressure_gradient(adv, p, inv_dx)
+    G.advect_scalars(u, [f["density"]], dt, inv_dx)
+    t_post = time.perf_counter() - t2
+    per_substep = t_pre + t_post + (t_it / it_s) * iterations
+    return {
+        "value": 1.0 / per_substep,
+        "unit": "substeps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"oracle core substep on the same {G.N}-voxel grid: advect_vector+divergence+gradient+advect_scalars(S=1) timed once "
+                  f"({t_pre + t_post:.2f} s), {it_s} of {iterations} RB-SOR iterations timed ({t_it:.2f} s) and scaled linearly",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from hnanosolver_amd import api, device as D, fields
+
+    origins, R = fields.config_leaves(args.config)
+    vs, dt = 1.0 / R, 1.0 / 24.0
+    n_vox_rank = len(origins) * 512
+
+    if world == 1:
+        f = fields.synthetic_fields(origins, R)
+        grid = api.create_grid_from_leaves(origins, vs)
+        sim = D.Sim(grid, ["density"])
+        sim.upload({"vel": f["vel"], "density": f["density"]})
+        stream = D.current_stream()
+
+        def step():
+            sim.core_substep(args.iterations, dt, vs, stream)
+
+        def timing_on():
+            sim.timing(args.steps)
+
+        def pressure_time():
+            return sim.pressure_time()
+    else:
+        from hnanosolver_amd import dist as HD
+
+        runner = HD.SlabBench(origins, R, rank, world, args.iterations, dt)
+        step, timing_on, pressure_time = runner.step, runner.timing_on, runner.pressure_time
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timing_on()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    p_ms, launches = pressure_time()
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * args.steps / elapsed  # slab-substeps/s over all ranks
+        ms_launch = p_ms / max(1, launches)
+        achieved = BYTES_PER_VOXEL_ITER * n_vox_rank / (ms_launch * 1e-3) / 1e9 if launches else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                j = json.load(open(pmc))
+                if j.get("config") == args.config and j.get("kernel") == "k_rbgs_fused":
+                    traffic = j.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "solver substeps/sec (advect + 50 red-black SOR iterations + project) at N active voxels",
+            "value": value,
+            "unit": "substeps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.config}^3 dense-active grid" if args.config.isdigit() else args.config,
+                "active_voxels_per_gpu": n_vox_rank,
+                "leaves_per_gpu": len(origins),
+                "pressure_iterations": args.iterations,
+                "substep": "advect_vector + divergence + RB-SOR + gradient subtraction + advect_scalars(S=1)",
+                "algorithmic_bytes_per_voxel_substep": BYTES_PER_VOXEL_SUBSTEP - 600 + 12 * args.iterations,
+                "parallelism": "single GPU" if world == 1 else f"x-slab leaf partition over {world} GPUs, RCCL halo exchange",
+            },
+            "roofline": {
+                "kernel": "k_rbgs_fused (one launch = one red+black SOR iteration)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": BYTES_PER_VOXEL_ITER * n_vox_rank,
+                "ms_per_launch": ms_launch,
+                "launches_timed": launches,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(origins, R, args.iterations)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,6 +123,11 @@ struct hns_sim {
 	float* p_b = nullptr;
 	float* p_result = nullptr;  // whichever of p_a/p_b holds the last solve
 	float* stage = nullptr;     // 3n floats, AoS staging for H2D/D2H
+	// optional hipEvent bracketing of the pressure hot loop (hns_sim_timing), on the stream the kernels run on
+	bool timing = false;
+	std::vector<hipEvent_t> ev;  // start/stop pairs
+	size_t ev_used = 0;
+	long long timed_launches = 0;
 	int find(const char* name) const {
 		for (size_t i = 0; i < names.size(); ++i)
 			if (names[i] == name) return (int)i;
@@ -149,6 +154,7 @@ extern "C" void hns_sim_destroy(hns_sim* s) {
 	hipFree(s->p_a);
 	hipFree(s->p_b);
 	hipFree(s->stage);
+	for (hipEvent_t e : s->ev) hipEventDestroy(e);
 	delete s;
 }
 
@@ -273,7 +279,14 @@ static int validate_step(float voxel_size, float dt, int64_t iterations, bool ne
 static int sim_pressure(hns_sim* s, int iterations, float voxel_size, float omega, void* stream) {
 	HNS_HIP(hipMemsetAsync(s->p_a, 0, sizeof(float) * (size_t)s->n, (hipStream_t)stream));  // never warm-started (HNanoSolver.cu:113)
 	int in_b = 0;
+	const bool timed = s->timing && s->ev_used + 2 <= s->ev.size();
+	if (timed) HNS_HIP(hipEventRecord(s->ev[s->ev_used], (hipStream_t)stream));
 	HNS_TRY(hns_dev_rbgs_iterate(s->grid, s->div, s->p_a, s->p_b, voxel_size, omega, iterations, &in_b, stream));
+	if (timed) {
+		HNS_HIP(hipEventRecord(s->ev[s->ev_used + 1], (hipStream_t)stream));
+		s->ev_used += 2;
+		s->timed_launches += iterations;
+	}
 	s->p_result = in_b ? s->p_b : s->p_a;
 	return HNS_OK;
 }
@@ -285,6 +298,35 @@ extern "C" int hns_sim_pressure_solve(hns_sim* s, int iterations, float voxel_si
 	if (!s) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_sim_pressure_solve: null sim");
 	HNS_TRY(validate_step(voxel_size, 0.0f, iterations, true));
 	return sim_pressure(s, iterations, voxel_size, omega_compute(voxel_size), stream);
+}
+
+// Bracket every following pressure loop (up to max_solves of them) with a hipEvent pair on its launch stream.
+extern "C" int hns_sim_timing(hns_sim* s, int max_solves) {
+	if (!s || max_solves < 0) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_sim_timing: bad arguments");
+	while (s->ev.size() < (size_t)max_solves * 2) {
+		hipEvent_t e;
+		HNS_HIP(hipEventCreate(&e));
+		s->ev.push_back(e);
+	}
+	s->timing = max_solves > 0;
+	s->ev_used = 0;
+	s->timed_launches = 0;
+	return HNS_OK;
+}
+
+// Sum of the bracketed pressure-loop times since hns_sim_timing() and the number of fused-iteration launches inside.
+extern "C" int hns_sim_pressure_time(hns_sim* s, float* total_ms, long long* launches) {
+	if (!s || !total_ms || !launches) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_sim_pressure_time: null argument");
+	double tot = 0.0;
+	for (size_t i = 0; i + 1 < s->ev_used; i += 2) {
+		HNS_HIP(hipEventSynchronize(s->ev[i + 1]));
+		float ms = 0.0f;
+		HNS_HIP(hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]));
+		tot += ms;
+	}
+	*total_ms = (float)tot;
+	*launches = s->timed_launches;
+	return HNS_OK;
 }
 
 static int sim_advect_scalars(hns_sim* s, const float* sdf, bool coll, float dt, float inv_dx, void* stream) {

@@ -174,7 +174,7 @@ __device__ __forceinline__ f3 sdf_normal(const GridDev& g, const int* s_nbr, con
 	const float back = ld0(sdf, tap_index(g, s_nbr, org, i, j, k - 1));
 	const float s = 0.5f * eps;
 	f3 gr = {s * (right - left), s * (top - bottom), s * (front - back)};
-	const float len = __fsqrt_rn(gr.x * gr.x + gr.y * gr.y + gr.z * gr.z);
+	const float len = sqrtf(gr.x * gr.x + gr.y * gr.y + gr.z * gr.z);
 	if (len > 1e-6f) {
 		const float inv = 1.0f / len;
 		gr.x = inv * gr.x;
@@ -762,7 +762,7 @@ __device__ __forceinline__ f3 curl_at(const GridDev& g, const int* s_nbr, const 
 __device__ __forceinline__ float curl_mag(const GridDev& g, const int* s_nbr, const int4 org, const float* __restrict__ ux,
                                           const float* __restrict__ uy, const float* __restrict__ uz, int i, int j, int k, float factor) {
 	const f3 w = curl_at(g, s_nbr, org, ux, uy, uz, i, j, k, factor);
-	return __fsqrt_rn(w.x * w.x + w.y * w.y + w.z * w.z);
+	return sqrtf(w.x * w.x + w.y * w.y + w.z * w.z);
 }
 
 __global__ __launch_bounds__(512) void k_vorticity(const GridDev g, const float* __restrict__ ux, const float* __restrict__ uy,
@@ -781,8 +781,8 @@ __global__ __launch_bounds__(512) void k_vorticity(const GridDev g, const float*
 	const float grad_x = (m_pX - m_mX) * 0.5f * inv_dx;
 	const float grad_y = (m_pY - m_mY) * 0.5f * inv_dx;
 	const float grad_z = (m_pZ - m_mZ) * 0.5f * inv_dx;
-	const float gradLen = __fsqrt_rn(grad_x * grad_x + grad_y * grad_y + grad_z * grad_z) + 1e-5f;
-	const float Nx = __fdiv_rn(grad_x, gradLen), Ny = __fdiv_rn(grad_y, gradLen), Nz = __fdiv_rn(grad_z, gradLen);
+	const float gradLen = sqrtf(grad_x * grad_x + grad_y * grad_y + grad_z * grad_z) + 1e-5f;
+	const float Nx = grad_x / gradLen, Ny = grad_y / gradLen, Nz = grad_z / gradLen;
 	ox[idx] = ux[idx] + dt * (scale * (Ny * w.z - Nz * w.y));
 	oy[idx] = uy[idx] + dt * (scale * (Nz * w.x - Nx * w.z));
 	oz[idx] = uz[idx] + dt * (scale * (Nx * w.y - Ny * w.x));

@@ -179,6 +179,15 @@ class Sim:
     def pressure_solve(self, iterations: int, voxel_size: float, stream: int = 0) -> None:
         _raise(lib.hns_sim_pressure_solve(self._ptr, iterations, voxel_size, stream))
 
+    def timing(self, max_solves: int) -> None:
+        _raise(lib.hns_sim_timing(self._ptr, max_solves))
+
+    def pressure_time(self):
+        """(total ms of the event-bracketed pressure loops, number of fused-iteration launches inside them)"""
+        ms, n = C.c_float(0.0), C.c_longlong(0)
+        _raise(lib.hns_sim_pressure_time(self._ptr, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
     def close(self) -> None:
         if self._ptr:
             lib.hns_sim_destroy(self._ptr)

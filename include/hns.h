@@ -128,6 +128,11 @@ int hns_sim_substep(hns_sim*, int iterations, float dt, float voxel_size, const 
 int hns_sim_core_substep(hns_sim*, int iterations, float dt, float voxel_size, void* stream);
 /* Only the pressure hot loop on the sim's divergence/pressure buffers (pressure zeroed first); asynchronous. */
 int hns_sim_pressure_solve(hns_sim*, int iterations, float voxel_size, void* stream);
+/* hipEvent timing of the pressure hot loop on its launch stream: after hns_sim_timing(sim, max_solves) every pressure
+ * loop (up to max_solves) is bracketed by an event pair; hns_sim_pressure_time() returns the summed milliseconds and the
+ * number of fused-iteration launches they contained. hns_sim_timing(sim, 0) switches it off. */
+int hns_sim_timing(hns_sim*, int max_solves);
+int hns_sim_pressure_time(hns_sim*, float* total_ms, long long* launches);
 /* Raw device pointers of the sim's buffers (ux,uy,uz planar velocity, float fields, divergence, pressure). */
 float* hns_sim_velocity_ptr(hns_sim*, int component);
 float* hns_sim_field_ptr(hns_sim*, const char* name);
