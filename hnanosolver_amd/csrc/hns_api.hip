@@ -36,6 +36,7 @@ GridDev hns_grid::dev() const {
 	d.nbr27 = (const int*)d_nbr27;
 	d.hash = (const int*)d_hash;
 	d.sched = (const int*)d_sched;
+	d.blk = (const int*)d_blk;
 	d.hash_mask = topo.hash_mask;
 	d.n_leaves = (int)topo.n_leaves;
 	d.n_active = (int)n_active;
@@ -57,18 +58,37 @@ int hns_grid_upload_schedule(hns_grid* g) {
 		hipFree(g->d_sched);
 		g->d_sched = nullptr;
 	}
+	if (g->d_blk) {
+		hipFree(g->d_blk);
+		g->d_blk = nullptr;
+	}
 	const int64_t n = (int64_t)g->n_active;
+	if (n == 0) return HNS_OK;
 	const char* mode = getenv("HNS_SCHEDULE");
-	if (n == 0 || (mode && strcmp(mode, "linear") == 0)) return HNS_OK;
+	const bool linear = mode && strcmp(mode, "linear") == 0;
 	const int nx = 8;
 	const int64_t chunk = (n + nx - 1) / nx;
 	std::vector<int32_t> sched;
 	sched.reserve((size_t)n);
-	for (int64_t i = 0; i < chunk; ++i)
-		for (int x = 0; x < nx; ++x) {
-			const int64_t l = x * chunk + i;
-			if (l < n) sched.push_back((int32_t)l);
-		}
+	if (linear) {
+		for (int64_t l = 0; l < n; ++l) sched.push_back((int32_t)l);
+	} else {
+		for (int64_t i = 0; i < chunk; ++i)
+			for (int x = 0; x < nx; ++x) {
+				const int64_t l = x * chunk + i;
+				if (l < n) sched.push_back((int32_t)l);
+			}
+	}
+	// launch-ordered records {leaf, nbr27}: the one-wave-per-leaf SOR kernel reads its whole topology with one fetch
+	std::vector<int32_t> blk((size_t)n * 28);
+	for (int64_t b = 0; b < n; ++b) {
+		const int32_t l = sched[(size_t)b];
+		blk[(size_t)b * 28] = l;
+		memcpy(&blk[(size_t)b * 28 + 1], &g->topo.nbr27[(size_t)l * 27], 27 * sizeof(int32_t));
+	}
+	HNS_HIP(hipMalloc(&g->d_blk, sizeof(int32_t) * blk.size()));
+	HNS_HIP(hipMemcpy(g->d_blk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
+	if (linear) return HNS_OK;
 	HNS_HIP(hipMalloc(&g->d_sched, sizeof(int32_t) * (size_t)n));
 	HNS_HIP(hipMemcpy(g->d_sched, sched.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
 	return HNS_OK;
@@ -101,7 +121,8 @@ void hns_grid_free_device(hns_grid* g) {
 	if (g->d_nbr27) hipFree(g->d_nbr27);
 	if (g->d_hash) hipFree(g->d_hash);
 	if (g->d_sched) hipFree(g->d_sched);
-	g->d_origins = g->d_nbr27 = g->d_hash = g->d_sched = nullptr;
+	if (g->d_blk) hipFree(g->d_blk);
+	g->d_origins = g->d_nbr27 = g->d_hash = g->d_sched = g->d_blk = nullptr;
 	g->on_device = false;
 }
 

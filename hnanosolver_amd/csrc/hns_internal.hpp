@@ -46,6 +46,7 @@ struct GridDev {
 	const int* nbr27;
 	const int* hash;
 	const int* sched;  // block -> leaf order (XCD-chunked), n_active entries
+	const int* blk;    // per block, in launch order: {leaf, nbr27[27]} (28 ints)
 	uint32_t hash_mask;
 	int n_leaves;
 	int n_active;
@@ -64,6 +65,7 @@ struct hns_grid {
 	void* d_nbr27 = nullptr;
 	void* d_hash = nullptr;
 	void* d_sched = nullptr;
+	void* d_blk = nullptr;
 	hns::GridDev dev() const;
 };
 

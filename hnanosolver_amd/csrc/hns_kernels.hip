@@ -15,6 +15,9 @@
 //     p in LDS, recomputes the red updates of the face-adjacent halo voxels itself (bit-identical to what the
 //     neighbouring workgroup computes), then does black, ping-ponging p_in -> p_out. 12 B/voxel/iteration of HBM
 //     traffic instead of the >=16 B of two in-place launches.
+#include <cstdlib>
+#include <cstring>
+
 #include "hns_internal.hpp"
 
 namespace hns {
@@ -636,6 +639,194 @@ __global__ __launch_bounds__(256) void k_rbgs_fused(const GridDev g, const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// red-black SOR, fused form, ONE WAVE PER LEAF (the production kernel)
+// ---------------------------------------------------------------------------------------------------------------
+//
+// Same algorithm and the same per-voxel arithmetic as k_rbgs_fused above, reorganised for the CDNA4 wave: the 64 lanes
+// of one wave own the 64 z-rows of a leaf (lane = x*8+y, the memory order, so the 2 KB payload is read and written as
+// two 16-byte accesses per lane, fully coalesced) and keep their row in registers. No workgroup barrier exists: the
+// wave's private LDS tile only carries rows between lanes. Work per lane:
+//   * own row: p[-2..9] (z halo from the +-z neighbour leaves) and div[0..7] in registers; lateral neighbours are the
+//     rows of lanes x+-1 / y+-1 (or of the face-neighbour leaves), read from LDS as 2 x ds_read_b128 each;
+//   * one z-halo red voxel: (x,y,-1) if x+y is odd, else (x,y,8);
+//   * lanes 0..31 additionally recompute the red voxels of one face-adjacent halo row each (4 faces x 8 rows); the
+//     depth-2 row behind it sits in a side area of the tile so that all four lateral reads have the same shape.
+// Every candidate is evaluated for all 8 z of a row and accepted by colour, which keeps the code free of
+// lane-dependent register indexing; rejected candidates never reach memory, so the result is bit-identical to
+// the two-launch form.
+//
+// LDS tile: rows (x',y') in [-1,8]^2 -> R = (x'+1)*10 + (y'+1), plus rows 100..131 for the depth-2 rows.
+// Row R occupies floats [4+12R-1, 4+12R+8]: z = -1 .. 8 (z=0 is 16-byte aligned; 48-byte row stride).
+
+#define W_OFF(R, z) (4 + (R) * 12 + (z))
+#define W_ROW(xp, yp) (((xp) + 1) * 10 + ((yp) + 1))
+#define W_FLOATS (4 + 132 * 12)
+
+struct Row8 {
+	float v[8];
+};
+
+__device__ __forceinline__ Row8 lds_row(const float* T, int R) {
+	const float4 a = *reinterpret_cast<const float4*>(T + W_OFF(R, 0));
+	const float4 b = *reinterpret_cast<const float4*>(T + W_OFF(R, 4));
+	Row8 r = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+	return r;
+}
+
+__device__ __forceinline__ void lds_put_row(float* T, int R, const float (&v)[8]) {
+	*reinterpret_cast<float4*>(T + W_OFF(R, 0)) = make_float4(v[0], v[1], v[2], v[3]);
+	*reinterpret_cast<float4*>(T + W_OFF(R, 4)) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+__device__ __forceinline__ Row8 glb_row(const float* __restrict__ f, int leaf, int row) {
+	Row8 r;
+	if (leaf < 0) {
+#pragma unroll
+		for (int z = 0; z < 8; ++z) r.v[z] = 0.0f;
+		return r;
+	}
+	const float4* q = reinterpret_cast<const float4*>(f + (size_t)leaf * 512 + row * 8);
+	const float4 a = q[0], b = q[1];
+	r.v[0] = a.x, r.v[1] = a.y, r.v[2] = a.z, r.v[3] = a.w, r.v[4] = b.x, r.v[5] = b.y, r.v[6] = b.z, r.v[7] = b.w;
+	return r;
+}
+
+// SOR candidates of a whole z-row: c[z+1] = centre row z = -1..8 (10 values), lateral rows xp/xm/yp/ym, d = div row
+__device__ __forceinline__ void row_candidates(const Row8& xp, const Row8& xm, const Row8& yp, const Row8& ym, const float (&c)[10],
+                                               const float (&d)[8], float dx2, float omega, float (&cand)[8]) {
+#pragma unroll
+	for (int z = 0; z < 8; ++z) cand[z] = sor_update(xp.v[z], xm.v[z], yp.v[z], ym.v[z], c[z + 2], c[z], d[z], c[z + 1], dx2, omega);
+}
+
+__global__ __launch_bounds__(64) void k_rbgs_wave(const GridDev g, const float* __restrict__ div, const float* __restrict__ p_in,
+                                                  float* __restrict__ p_out, const float dx2, const float omega) {
+	__shared__ __attribute__((aligned(16))) float T[W_FLOATS];
+	const int l = threadIdx.x;
+	// per-block record {leaf, nbr27[27]} in launch order: one dependent scalar fetch instead of sched -> nbr27
+	const int* __restrict__ rec = g.blk + (size_t)blockIdx.x * 28;
+	const int leaf = __builtin_amdgcn_readfirstlane(rec[0]);
+	const int n_xm = __builtin_amdgcn_readfirstlane(rec[1 + 4]), n_xp = __builtin_amdgcn_readfirstlane(rec[1 + 22]);
+	const int n_ym = __builtin_amdgcn_readfirstlane(rec[1 + 10]), n_yp = __builtin_amdgcn_readfirstlane(rec[1 + 16]);
+	const int n_zm = __builtin_amdgcn_readfirstlane(rec[1 + 12]), n_zp = __builtin_amdgcn_readfirstlane(rec[1 + 14]);
+
+	const int x = l >> 3, y = l & 7;
+	const int par = (x + y) & 1;  // 0: even z are red; 1: odd z are red
+
+	// ---- issue every global load up front ----
+	const Row8 P = glb_row(p_in, leaf, l);
+	const Row8 D = glb_row(div, leaf, l);
+	float2 zlo = make_float2(0.0f, 0.0f), zhi = make_float2(0.0f, 0.0f);  // p(x,y,-2..-1), p(x,y,8..9)
+	if (n_zm >= 0) zlo = *reinterpret_cast<const float2*>(p_in + (size_t)n_zm * 512 + l * 8 + 6);
+	if (n_zp >= 0) zhi = *reinterpret_cast<const float2*>(p_in + (size_t)n_zp * 512 + l * 8);
+	const int n_zh = par ? n_zm : n_zp;  // leaf of this lane's z-halo red voxel: (x,y,-1) if par else (x,y,8)
+	float d_zh = 0.0f;
+	if (n_zh >= 0) d_zh = div[(size_t)n_zh * 512 + l * 8 + (par ? 7 : 0)];
+
+	// halo rows (lanes 0..31): face f, row i. A = adjacent row (recomputed), B = the row behind it
+	const int f = (l >> 3) & 3, i = l & 7;
+	const int n_f = f == 0 ? n_xm : (f == 1 ? n_xp : (f == 2 ? n_ym : n_yp));
+	const int srcA = f == 0 ? 56 + i : (f == 1 ? i : (f == 2 ? i * 8 + 7 : i * 8));
+	const int srcB = f == 0 ? 48 + i : (f == 1 ? 8 + i : (f == 2 ? i * 8 + 6 : i * 8 + 1));
+	const int ax = f == 0 ? -1 : (f == 1 ? 8 : i), ay = f == 2 ? -1 : (f == 3 ? 8 : i);
+	const bool halo_lane = l < 32;
+	const int n_h = halo_lane ? n_f : -1;
+	const Row8 HA = glb_row(p_in, n_h, srcA);
+	const Row8 HB = glb_row(p_in, n_h, srcB);
+	const Row8 HD = glb_row(div, n_h, srcA);
+
+	// edge rows along z: tile rows (-1,-1), (-1,8), (8,-1), (8,8) (lanes 32..35)
+	const int ea = (l >> 1) & 1, eb = l & 1;
+	const bool erow_lane = (l >> 2) == 8;
+	const int n_er = erow_lane ? rec[1 + (ea ? 2 : 0) * 9 + (eb ? 2 : 0) * 3 + 1] : -1;
+	const Row8 ER = glb_row(p_in, n_er, (ea ? 0 : 7) * 8 + (eb ? 0 : 7));
+
+	// edge singles: lines 0..3 = (x,z) edges along y, lines 4..7 = (y,z) edges along x; one voxel per lane
+	const int ln = l >> 3, sa = (ln >> 1) & 1, sb = ln & 1;
+	const int ta = sa ? 8 : -1, tb = sb ? 8 : -1;  // tile coordinates of the line
+	const int ca = sa ? 0 : 7, cb = sb ? 0 : 7;    // coordinates inside the neighbour leaf
+	const int e_slot = ln < 4 ? (sa ? 2 : 0) * 9 + 3 + (sb ? 2 : 0) : 9 + (sa ? 2 : 0) * 3 + (sb ? 2 : 0);
+	const int e_src = ln < 4 ? ca * 64 + i * 8 + cb : i * 64 + ca * 8 + cb;
+	const int e_row = ln < 4 ? W_ROW(ta, i) : W_ROW(i, ta);
+	const int n_e = rec[1 + e_slot];
+	float e_val = 0.0f;
+	if (n_e >= 0) e_val = p_in[(size_t)n_e * 512 + e_src];
+
+	// ---- stage rows in LDS ----
+	const int R_own = W_ROW(x, y);
+	lds_put_row(T, R_own, P.v);
+	T[W_OFF(R_own, -1)] = zlo.y;
+	T[W_OFF(R_own, 8)] = zhi.x;
+	const int R_A = W_ROW(ax, ay), R_B = 100 + l;
+	if (halo_lane) {
+		lds_put_row(T, R_A, HA.v);
+		lds_put_row(T, R_B, HB.v);
+	}
+	if (erow_lane) lds_put_row(T, W_ROW(ea ? 8 : -1, eb ? 8 : -1), ER.v);
+	T[W_OFF(e_row, tb)] = e_val;
+	__syncthreads();  // single-wave workgroup: orders the LDS traffic, no cross-wave rendezvous
+
+	// ---- phase R ----
+	// (a) halo rows
+	float hnew[8];
+	if (halo_lane) {
+		const Row8 hxm = lds_row(T, f == 0 ? R_B : W_ROW(ax - 1, ay));
+		const Row8 hxp = lds_row(T, f == 1 ? R_B : W_ROW(ax + 1, ay));
+		const Row8 hym = lds_row(T, f == 2 ? R_B : W_ROW(ax, ay - 1));
+		const Row8 hyp = lds_row(T, f == 3 ? R_B : W_ROW(ax, ay + 1));
+		const float hc[10] = {T[W_OFF(R_A, -1)], HA.v[0], HA.v[1], HA.v[2], HA.v[3], HA.v[4], HA.v[5], HA.v[6], HA.v[7], T[W_OFF(R_A, 8)]};
+		float cand[8];
+		row_candidates(hxp, hxm, hyp, hym, hc, HD.v, dx2, omega, cand);
+		const int hpar = (ax + ay) & 1;
+#pragma unroll
+		for (int z = 0; z < 8; ++z) hnew[z] = (((hpar + z) & 1) == 0 && n_h >= 0) ? cand[z] : HA.v[z];
+	}
+	// (b) own row + z-halo voxel
+	const int R_xm = W_ROW(x - 1, y), R_xp = W_ROW(x + 1, y), R_ym = W_ROW(x, y - 1), R_yp = W_ROW(x, y + 1);
+	float c[10] = {zlo.y, P.v[0], P.v[1], P.v[2], P.v[3], P.v[4], P.v[5], P.v[6], P.v[7], zhi.x};  // z = -1..8
+	{
+		const Row8 xm = lds_row(T, R_xm), xp = lds_row(T, R_xp), ym = lds_row(T, R_ym), yp = lds_row(T, R_yp);
+		float cand[8];
+		row_candidates(xp, xm, yp, ym, c, D.v, dx2, omega, cand);
+		// z-halo red voxel at zh = par ? -1 : 8
+		const int zh = par ? -1 : 8;
+		const float zc = sor_update(T[W_OFF(R_xp, zh)], T[W_OFF(R_xm, zh)], T[W_OFF(R_yp, zh)], T[W_OFF(R_ym, zh)], par ? P.v[0] : zhi.y,
+		                            par ? zlo.x : P.v[7], d_zh, par ? zlo.y : zhi.x, dx2, omega);
+#pragma unroll
+		for (int z = 0; z < 8; ++z) c[z + 1] = (((par + z) & 1) == 0) ? cand[z] : c[z + 1];
+		if (n_zh >= 0) {
+			if (par) c[0] = zc;
+			else c[9] = zc;
+		}
+	}
+	__syncthreads();  // all phase-R reads done before the tile is overwritten with the new reds
+	{
+		const float own[8] = {c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]};
+		lds_put_row(T, R_own, own);
+		if (halo_lane) lds_put_row(T, R_A, hnew);
+	}
+	__syncthreads();
+
+	// ---- phase B ----
+	{
+		const Row8 xm = lds_row(T, R_xm), xp = lds_row(T, R_xp), ym = lds_row(T, R_ym), yp = lds_row(T, R_yp);
+		float cand[8];
+		row_candidates(xp, xm, yp, ym, c, D.v, dx2, omega, cand);
+		float4 o0, o1;
+		o0.x = par ? cand[0] : c[1];
+		o0.y = par ? c[2] : cand[1];
+		o0.z = par ? cand[2] : c[3];
+		o0.w = par ? c[4] : cand[3];
+		o1.x = par ? cand[4] : c[5];
+		o1.y = par ? c[6] : cand[5];
+		o1.z = par ? cand[6] : c[7];
+		o1.w = par ? c[8] : cand[7];
+		float4* q = reinterpret_cast<float4*>(p_out + (size_t)leaf * 512 + l * 8);
+		q[0] = o0;
+		q[1] = o1;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // subtractPressureGradient (reference Kernel.cu:765-829 / :694-762)
 // ---------------------------------------------------------------------------------------------------------------
 
@@ -963,8 +1154,12 @@ int hns_dev_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, 
 	const GridDev gd = g->dev();
 	float* src = p_a;
 	float* dst = p_b;
+	static const bool use_lds_kernel = getenv("HNS_RBGS") && strcmp(getenv("HNS_RBGS"), "block") == 0;  // A/B switch: 256-thread LDS-tile form
 	for (int it = 0; it < iterations; ++it) {
-		hipLaunchKernelGGL(k_rbgs_fused, dim3((unsigned)g->n_active), dim3(256), 0, (hipStream_t)stream, gd, div, (const float*)src, dst, dx2, omega);
+		if (use_lds_kernel)
+			hipLaunchKernelGGL(k_rbgs_fused, dim3((unsigned)g->n_active), dim3(256), 0, (hipStream_t)stream, gd, div, (const float*)src, dst, dx2, omega);
+		else
+			hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, div, (const float*)src, dst, dx2, omega);
 		float* tmp = src;
 		src = dst;
 		dst = tmp;
