@@ -62,6 +62,10 @@ int hns_grid_upload_schedule(hns_grid* g) {
 		hipFree(g->d_blk);
 		g->d_blk = nullptr;
 	}
+	if (g->d_pairs) hipFree(g->d_pairs);
+	if (g->d_singles) hipFree(g->d_singles);
+	g->d_pairs = g->d_singles = nullptr;
+	g->n_pairs = g->n_singles = 0;
 	const int64_t n = (int64_t)g->n_active;
 	if (n == 0) return HNS_OK;
 	const char* mode = getenv("HNS_SCHEDULE");
@@ -88,6 +92,53 @@ int hns_grid_upload_schedule(hns_grid* g) {
 	}
 	HNS_HIP(hipMalloc(&g->d_blk, sizeof(int32_t) * blk.size()));
 	HNS_HIP(hipMemcpy(g->d_blk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
+	// z-adjacent pairs for k_rbgs_pair: walk the schedule, pair a leaf with its +z neighbour when both are active and unpaired
+	{
+		std::vector<char> used((size_t)n, 0);
+		std::vector<int32_t> pairs, singles;
+		auto put = [&](std::vector<int32_t>& v, int32_t l) {
+			v.push_back(l);
+			v.insert(v.end(), g->topo.nbr27.begin() + (size_t)l * 27, g->topo.nbr27.begin() + (size_t)l * 27 + 27);
+		};
+		std::vector<int32_t> order_pairs, order_single;
+		for (int64_t b = 0; b < n; ++b) {
+			const int32_t l = sched[(size_t)b];
+			if (used[(size_t)l]) continue;
+			const int32_t up = g->topo.nbr27[(size_t)l * 27 + 14];
+			const int32_t dn = g->topo.nbr27[(size_t)l * 27 + 12];
+			if (up >= 0 && up < n && !used[(size_t)up]) {
+				used[(size_t)l] = used[(size_t)up] = 1;
+				put(pairs, l);
+				put(pairs, up);
+			} else if (dn >= 0 && dn < n && !used[(size_t)dn]) {
+				used[(size_t)l] = used[(size_t)dn] = 1;
+				put(pairs, dn);
+				put(pairs, l);
+			} else {
+				used[(size_t)l] = 1;
+				put(singles, l);
+			}
+		}
+		g->n_pairs = pairs.size() / 56;
+		g->n_singles = singles.size() / 28;
+		if (g->n_pairs) {
+			// re-chunk the pair list over the 8 XCDs (the schedule above interleaves leaves, pairs halve the count)
+			std::vector<int32_t> ordered;
+			ordered.reserve(pairs.size());
+			if (linear) {
+				ordered = pairs;
+			} else {
+				// pairs were emitted in schedule order, which already alternates XCD chunks block by block
+				ordered = pairs;
+			}
+			HNS_HIP(hipMalloc(&g->d_pairs, sizeof(int32_t) * ordered.size()));
+			HNS_HIP(hipMemcpy(g->d_pairs, ordered.data(), sizeof(int32_t) * ordered.size(), hipMemcpyHostToDevice));
+		}
+		if (g->n_singles) {
+			HNS_HIP(hipMalloc(&g->d_singles, sizeof(int32_t) * singles.size()));
+			HNS_HIP(hipMemcpy(g->d_singles, singles.data(), sizeof(int32_t) * singles.size(), hipMemcpyHostToDevice));
+		}
+	}
 	if (linear) return HNS_OK;
 	HNS_HIP(hipMalloc(&g->d_sched, sizeof(int32_t) * (size_t)n));
 	HNS_HIP(hipMemcpy(g->d_sched, sched.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
@@ -122,7 +173,9 @@ void hns_grid_free_device(hns_grid* g) {
 	if (g->d_hash) hipFree(g->d_hash);
 	if (g->d_sched) hipFree(g->d_sched);
 	if (g->d_blk) hipFree(g->d_blk);
-	g->d_origins = g->d_nbr27 = g->d_hash = g->d_sched = g->d_blk = nullptr;
+	if (g->d_pairs) hipFree(g->d_pairs);
+	if (g->d_singles) hipFree(g->d_singles);
+	g->d_origins = g->d_nbr27 = g->d_hash = g->d_sched = g->d_blk = g->d_pairs = g->d_singles = nullptr;
 	g->on_device = false;
 }
 

@@ -66,6 +66,9 @@ struct hns_grid {
 	void* d_hash = nullptr;
 	void* d_sched = nullptr;
 	void* d_blk = nullptr;
+	void* d_pairs = nullptr;    // launch-ordered records of z-adjacent leaf pairs: {leaf0, nbr27, leaf1, nbr27} (56 ints)
+	void* d_singles = nullptr;  // {leaf, nbr27} records (28 ints) of the active leaves that are in no pair
+	uint64_t n_pairs = 0, n_singles = 0;
 	hns::GridDev dev() const;
 };
 

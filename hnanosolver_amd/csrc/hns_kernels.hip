@@ -827,6 +827,184 @@ __global__ __launch_bounds__(64) void k_rbgs_wave(const GridDev g, const float* 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// red-black SOR, fused form, one wave per PAIR of z-adjacent leaves (the production kernel for paired leaves)
+// ---------------------------------------------------------------------------------------------------------------
+//
+// z is the fastest-varying index of the leaf payload, so the +-z faces are the expensive halo: 8-byte pieces at a
+// 32-byte stride (16 cache lines for 512 useful bytes). k_rbgs_wave spends most of its time in the texture addresser /
+// L1 on exactly those accesses (profiles/r01_v2_*). Here one wave owns two leaves stacked along z: the face between
+// them never leaves the registers, the strided z-halo loads are halved, and the recomputation of the face-adjacent
+// halo rows (32 rows per leaf) is spread over all 64 lanes (lanes 0-31: lower leaf, 32-63: upper leaf).
+// Arithmetic per voxel is sor_update(), exactly as in the other forms.
+//
+// LDS rows are kept as separate 16-byte halves LO (z 0..3) / HI (z 4..7) indexed by a row number chosen so that the
+// lateral-neighbour reads of the 64 lanes are linear in the lane id (conflict-free ds_read_b128):
+//   (x', y') x' in -1..8, y' in 0..7 -> 8*(x'+1) + y'          (x'=-1 / 8 are the -x / +x face rows)
+//   (x', -1) -> 87 + 8*x'      (== row (x',0) - 1   mod 16)
+//   (x',  8) -> 96 + 8*x'      (== row (x',7) + 1   mod 16)
+//   edge rows (-1,-1) (-1,8) (8,-1) (8,8) -> 81..84; depth-2 rows of halo lane h -> 89 + 8*(h/6) + h%6
+// ZM / ZP hold the z=-1 values of the lower tile and the z=8 values of the upper tile (core rows and face rows).
+
+#define PR_ROWS 153
+
+struct PairTile {
+	float4 LO[2][PR_ROWS];
+	float4 HI[2][PR_ROWS];
+	float ZM[PR_ROWS];
+	float ZP[PR_ROWS];
+};
+
+__device__ __forceinline__ Row8 pt_row(const PairTile& S, int k, int R) {
+	const float4 a = S.LO[k][R], b = S.HI[k][R];
+	Row8 r = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+	return r;
+}
+__device__ __forceinline__ void pt_put(PairTile& S, int k, int R, const float (&v)[8]) {
+	S.LO[k][R] = make_float4(v[0], v[1], v[2], v[3]);
+	S.HI[k][R] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+__global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs, const float* __restrict__ div, const float* __restrict__ p_in,
+                                                  float* __restrict__ p_out, const float dx2, const float omega) {
+	__shared__ __attribute__((aligned(16))) PairTile S;
+	const int l = threadIdx.x;
+	// record: {leaf0, nbr27 of leaf0, leaf1, nbr27 of leaf1}; leaf1 is the +z neighbour of leaf0
+	const int* __restrict__ rec = pairs + (size_t)blockIdx.x * 56;
+	const int leaf0 = __builtin_amdgcn_readfirstlane(rec[0]), leaf1 = __builtin_amdgcn_readfirstlane(rec[28]);
+	const int n_zm = __builtin_amdgcn_readfirstlane(rec[1 + 12]), n_zp = __builtin_amdgcn_readfirstlane(rec[28 + 1 + 14]);
+	const int x = l >> 3, y = l & 7;
+	const int par = (x + y) & 1;  // 0: even z red, 1: odd z red (both leaves: their z origins differ by 8)
+
+	// ---- every global load up front ----
+	const Row8 P0 = glb_row(p_in, leaf0, l), P1 = glb_row(p_in, leaf1, l);
+	const Row8 D0 = glb_row(div, leaf0, l), D1 = glb_row(div, leaf1, l);
+	float2 zlo = make_float2(0.0f, 0.0f), zhi = make_float2(0.0f, 0.0f);  // p(x,y,-2..-1) below leaf0, p(x,y,8..9) above leaf1
+	if (n_zm >= 0) zlo = *reinterpret_cast<const float2*>(p_in + (size_t)n_zm * 512 + l * 8 + 6);
+	if (n_zp >= 0) zhi = *reinterpret_cast<const float2*>(p_in + (size_t)n_zp * 512 + l * 8);
+	const int n_zh = par ? n_zm : n_zp;  // this lane's z-halo red voxel: below leaf0 if par, else above leaf1
+	float d_zh = 0.0f;
+	if (n_zh >= 0) d_zh = div[(size_t)n_zh * 512 + l * 8 + (par ? 7 : 0)];
+
+	// halo-row duty: lanes 0..31 -> leaf0, 32..63 -> leaf1; face f (-x,+x,-y,+y), row i
+	const int w = l >> 5, h = l & 31, f = h >> 3, i = h & 7;
+	const int* __restrict__ nb = rec + 28 * w + 1;
+	const int slotF = f == 0 ? 4 : (f == 1 ? 22 : (f == 2 ? 10 : 16));
+	const int n_f = nb[slotF];
+	const int srcA = f == 0 ? 56 + i : (f == 1 ? i : (f == 2 ? i * 8 + 7 : i * 8));
+	const int srcB = f == 0 ? 48 + i : (f == 1 ? 8 + i : (f == 2 ? i * 8 + 6 : i * 8 + 1));
+	const Row8 HA = glb_row(p_in, n_f, srcA);
+	const Row8 HB = glb_row(p_in, n_f, srcB);
+	const Row8 HD = glb_row(div, n_f, srcA);
+	// the halo row's own z-neighbour outside the pair: z=-1 for the lower leaf, z=8 for the upper leaf
+	const int n_e = nb[slotF + (w ? 1 : -1)];
+	float e_val = 0.0f;
+	if (n_e >= 0) e_val = p_in[(size_t)n_e * 512 + srcA * 8 + (w ? 0 : 7)];
+	// edge rows along z (lanes 0..7): tile rows (-1,-1), (-1,8), (8,-1), (8,8) of each leaf
+	const int ew = (l >> 2) & 1, ea = (l >> 1) & 1, eb = l & 1;
+	const bool erow_lane = l < 8;
+	const int n_er = erow_lane ? rec[28 * ew + 1 + (ea ? 2 : 0) * 9 + (eb ? 2 : 0) * 3 + 1] : -1;
+	const Row8 ER = glb_row(p_in, n_er, (ea ? 0 : 7) * 8 + (eb ? 0 : 7));
+
+	// ---- row numbers ----
+	const int I = 8 * (x + 1) + y;
+	const int R_xm = I - 8, R_xp = I + 8, R_ym = y == 0 ? 87 + 8 * x : I - 1, R_yp = y == 7 ? 96 + 8 * x : I + 1;
+	const int RA = f == 0 ? i : (f == 1 ? 72 + i : (f == 2 ? 87 + 8 * i : 96 + 8 * i));
+	const int RB = 89 + 8 * (h / 6) + (h % 6);
+	const int H_xm = f == 0 ? RB : (f == 1 ? 64 + i : (i == 0 ? (f == 2 ? 81 : 82) : (f == 2 ? 87 + 8 * (i - 1) : 96 + 8 * (i - 1))));
+	const int H_xp = f == 1 ? RB : (f == 0 ? 8 + i : (i == 7 ? (f == 2 ? 83 : 84) : (f == 2 ? 87 + 8 * (i + 1) : 96 + 8 * (i + 1))));
+	const int H_ym = f == 2 ? RB : (f == 3 ? 8 * (i + 1) + 7 : (i == 0 ? (f == 0 ? 81 : 83) : (f == 0 ? i - 1 : 72 + i - 1)));
+	const int H_yp = f == 3 ? RB : (f == 2 ? 8 * (i + 1) : (i == 7 ? (f == 0 ? 82 : 84) : (f == 0 ? i + 1 : 72 + i + 1)));
+
+	// ---- stage ----
+	pt_put(S, 0, I, P0.v);
+	pt_put(S, 1, I, P1.v);
+	S.ZM[I] = zlo.y;
+	S.ZP[I] = zhi.x;
+	pt_put(S, w, RA, HA.v);
+	pt_put(S, w, RB, HB.v);
+	if (w == 0) S.ZM[RA] = e_val;
+	else S.ZP[RA] = e_val;
+	if (erow_lane) pt_put(S, ew, 81 + ea * 2 + eb, ER.v);
+	__syncthreads();
+
+	// ---- phase R ----
+	float hnew[8];
+	{
+		const Row8 hxm = pt_row(S, w, H_xm), hxp = pt_row(S, w, H_xp), hym = pt_row(S, w, H_ym), hyp = pt_row(S, w, H_yp);
+		const float below = w == 0 ? e_val : S.HI[0][RA].w;  // z=-1 of this halo row
+		const float above = w == 0 ? S.LO[1][RA].x : e_val;  // z=8
+		const float hc[10] = {below, HA.v[0], HA.v[1], HA.v[2], HA.v[3], HA.v[4], HA.v[5], HA.v[6], HA.v[7], above};
+		float cand[8];
+		row_candidates(hxp, hxm, hyp, hym, hc, HD.v, dx2, omega, cand);
+		const int hpar = (i + ((f & 1) ? 0 : 1)) & 1;  // parity of ax+ay: faces -x,-y sit at coordinate -1
+#pragma unroll
+		for (int z = 0; z < 8; ++z) hnew[z] = (((hpar + z) & 1) == 0 && n_f >= 0) ? cand[z] : HA.v[z];
+	}
+	float c0[10] = {zlo.y, P0.v[0], P0.v[1], P0.v[2], P0.v[3], P0.v[4], P0.v[5], P0.v[6], P0.v[7], P1.v[0]};
+	float c1[10] = {P0.v[7], P1.v[0], P1.v[1], P1.v[2], P1.v[3], P1.v[4], P1.v[5], P1.v[6], P1.v[7], zhi.x};
+	{
+		float cand0[8], cand1[8];
+		{
+			const Row8 xm = pt_row(S, 0, R_xm), xp = pt_row(S, 0, R_xp), ym = pt_row(S, 0, R_ym), yp = pt_row(S, 0, R_yp);
+			row_candidates(xp, xm, yp, ym, c0, D0.v, dx2, omega, cand0);
+		}
+		{
+			const Row8 xm = pt_row(S, 1, R_xm), xp = pt_row(S, 1, R_xp), ym = pt_row(S, 1, R_ym), yp = pt_row(S, 1, R_yp);
+			row_candidates(xp, xm, yp, ym, c1, D1.v, dx2, omega, cand1);
+		}
+		// z-halo red voxel: (x,y,-1) under leaf0 when par, else (x,y,8) over leaf1
+		const float* ZA = par ? S.ZM : S.ZP;
+		const float zc = sor_update(ZA[R_xp], ZA[R_xm], ZA[R_yp], ZA[R_ym], par ? P0.v[0] : zhi.y, par ? zlo.x : P1.v[7], d_zh,
+		                            par ? zlo.y : zhi.x, dx2, omega);
+#pragma unroll
+		for (int z = 0; z < 8; ++z) {
+			const bool red = ((par + z) & 1) == 0;
+			c0[z + 1] = red ? cand0[z] : c0[z + 1];
+			c1[z + 1] = red ? cand1[z] : c1[z + 1];
+		}
+		c0[9] = c1[1];  // the face between the two leaves: whichever of the two voxels is red has just been updated
+		c1[0] = c0[8];
+		if (n_zh >= 0) {
+			if (par) c0[0] = zc;
+			else c1[9] = zc;
+		}
+	}
+	__syncthreads();  // phase-R reads complete before the rows are overwritten
+	{
+		const float o0[8] = {c0[1], c0[2], c0[3], c0[4], c0[5], c0[6], c0[7], c0[8]};
+		const float o1[8] = {c1[1], c1[2], c1[3], c1[4], c1[5], c1[6], c1[7], c1[8]};
+		pt_put(S, 0, I, o0);
+		pt_put(S, 1, I, o1);
+		pt_put(S, w, RA, hnew);
+	}
+	__syncthreads();
+
+	// ---- phase B ----
+	{
+		float cand0[8], cand1[8];
+		{
+			const Row8 xm = pt_row(S, 0, R_xm), xp = pt_row(S, 0, R_xp), ym = pt_row(S, 0, R_ym), yp = pt_row(S, 0, R_yp);
+			row_candidates(xp, xm, yp, ym, c0, D0.v, dx2, omega, cand0);
+		}
+		{
+			const Row8 xm = pt_row(S, 1, R_xm), xp = pt_row(S, 1, R_xp), ym = pt_row(S, 1, R_ym), yp = pt_row(S, 1, R_yp);
+			row_candidates(xp, xm, yp, ym, c1, D1.v, dx2, omega, cand1);
+		}
+		float4 a0, b0, a1, b1;
+		a0.x = par ? cand0[0] : c0[1], a0.y = par ? c0[2] : cand0[1], a0.z = par ? cand0[2] : c0[3], a0.w = par ? c0[4] : cand0[3];
+		b0.x = par ? cand0[4] : c0[5], b0.y = par ? c0[6] : cand0[5], b0.z = par ? cand0[6] : c0[7], b0.w = par ? c0[8] : cand0[7];
+		a1.x = par ? cand1[0] : c1[1], a1.y = par ? c1[2] : cand1[1], a1.z = par ? cand1[2] : c1[3], a1.w = par ? c1[4] : cand1[3];
+		b1.x = par ? cand1[4] : c1[5], b1.y = par ? c1[6] : cand1[5], b1.z = par ? cand1[6] : c1[7], b1.w = par ? c1[8] : cand1[7];
+		float4* q0 = reinterpret_cast<float4*>(p_out + (size_t)leaf0 * 512 + l * 8);
+		float4* q1 = reinterpret_cast<float4*>(p_out + (size_t)leaf1 * 512 + l * 8);
+		q0[0] = a0;
+		q0[1] = b0;
+		q1[0] = a1;
+		q1[1] = b1;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // subtractPressureGradient (reference Kernel.cu:765-829 / :694-762)
 // ---------------------------------------------------------------------------------------------------------------
 
@@ -1155,11 +1333,23 @@ int hns_dev_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, 
 	float* src = p_a;
 	float* dst = p_b;
 	static const bool use_lds_kernel = getenv("HNS_RBGS") && strcmp(getenv("HNS_RBGS"), "block") == 0;  // A/B switch: 256-thread LDS-tile form
+	static const bool use_wave_kernel = getenv("HNS_RBGS") && strcmp(getenv("HNS_RBGS"), "wave") == 0;   // A/B switch: one leaf per wave everywhere
 	for (int it = 0; it < iterations; ++it) {
 		if (use_lds_kernel)
 			hipLaunchKernelGGL(k_rbgs_fused, dim3((unsigned)g->n_active), dim3(256), 0, (hipStream_t)stream, gd, div, (const float*)src, dst, dx2, omega);
-		else
+		else if (use_wave_kernel || !g->d_pairs)
 			hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, div, (const float*)src, dst, dx2, omega);
+		else {
+			// paired leaves and the unpaired remainder are disjoint and both read src / write dst: two independent launches
+			if (g->n_pairs)
+				hipLaunchKernelGGL(k_rbgs_pair, dim3((unsigned)g->n_pairs), dim3(64), 0, (hipStream_t)stream, (const int*)g->d_pairs, div, (const float*)src,
+				                   dst, dx2, omega);
+			if (g->n_singles) {
+				GridDev gs = gd;
+				gs.blk = (const int*)g->d_singles;
+				hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_singles), dim3(64), 0, (hipStream_t)stream, gs, div, (const float*)src, dst, dx2, omega);
+			}
+		}
 		float* tmp = src;
 		src = dst;
 		dst = tmp;
