@@ -847,6 +847,14 @@ __global__ __launch_bounds__(64) void k_rbgs_wave(const GridDev g, const float* 
 
 #define PR_ROWS 153
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// a z-row as four (even z, odd z) pairs: the SOR arithmetic below is written on pairs so that it compiles to packed
+// v_pk_add_f32 / v_pk_mul_f32 (two voxels per VALU instruction); -ffp-contract=off keeps every operation separate
+struct RowP {
+	v2f q[4];
+};
+
 struct PairTile {
 	float4 LO[2][PR_ROWS];
 	float4 HI[2][PR_ROWS];
@@ -854,14 +862,51 @@ struct PairTile {
 	float ZP[PR_ROWS];
 };
 
-__device__ __forceinline__ Row8 pt_row(const PairTile& S, int k, int R) {
+__device__ __forceinline__ RowP pt_row(const PairTile& S, int k, int R) {
 	const float4 a = S.LO[k][R], b = S.HI[k][R];
-	Row8 r = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+	RowP r;
+	r.q[0] = v2f{a.x, a.y}, r.q[1] = v2f{a.z, a.w}, r.q[2] = v2f{b.x, b.y}, r.q[3] = v2f{b.z, b.w};
 	return r;
 }
-__device__ __forceinline__ void pt_put(PairTile& S, int k, int R, const float (&v)[8]) {
-	S.LO[k][R] = make_float4(v[0], v[1], v[2], v[3]);
-	S.HI[k][R] = make_float4(v[4], v[5], v[6], v[7]);
+__device__ __forceinline__ void pt_put(PairTile& S, int k, int R, const RowP& r) {
+	S.LO[k][R] = make_float4(r.q[0].x, r.q[0].y, r.q[1].x, r.q[1].y);
+	S.HI[k][R] = make_float4(r.q[2].x, r.q[2].y, r.q[3].x, r.q[3].y);
+}
+
+// Row `row` of leaf `leaf` (-1 = absent -> zeros). Branch-free: an absent leaf reads leaf 0 and discards the data.
+__device__ __forceinline__ RowP glb_rowp(const float* __restrict__ f, int leaf, int row) {
+	const float4* q = reinterpret_cast<const float4*>(f + (size_t)(leaf < 0 ? 0 : leaf) * 512 + row * 8);
+	const float4 a = q[0], b = q[1];
+	const bool ok = leaf >= 0;
+	RowP r;
+	r.q[0] = v2f{ok ? a.x : 0.0f, ok ? a.y : 0.0f};
+	r.q[1] = v2f{ok ? a.z : 0.0f, ok ? a.w : 0.0f};
+	r.q[2] = v2f{ok ? b.x : 0.0f, ok ? b.y : 0.0f};
+	r.q[3] = v2f{ok ? b.z : 0.0f, ok ? b.w : 0.0f};
+	return r;
+}
+
+// sor_update() on two voxels at once; same operation order per element (Kernel.cu:621-622)
+__device__ __forceinline__ v2f sor2(v2f pxp, v2f pxm, v2f pyp, v2f pym, v2f pzp, v2f pzm, v2f d, v2f pold, float dx2, float omega) {
+	constexpr float inv6 = 0.166666667f;
+	const v2f pGS = ((pxp + pxm + pyp + pym + pzp + pzm) - d * dx2) * inv6;
+	return pold + omega * (pGS - pold);
+}
+
+// One colour of a whole z-row: candidates for all 8 voxels, then keep the even-z ones (take_even) or the odd-z ones.
+// c = the row itself, below / above = its z=-1 / z=8 neighbours. `valid` false leaves the row untouched.
+__device__ __forceinline__ RowP row_sweep(const RowP& xp, const RowP& xm, const RowP& yp, const RowP& ym, const RowP& c, float below, float above,
+                                          const RowP& d, float dx2, float omega, bool take_even, bool valid) {
+	RowP out;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const v2f zp = v2f{c.q[j].y, j < 3 ? c.q[j < 3 ? j + 1 : 3].x : above};
+		const v2f zm = v2f{j > 0 ? c.q[j > 0 ? j - 1 : 0].y : below, c.q[j].x};
+		const v2f cand = sor2(xp.q[j], xm.q[j], yp.q[j], ym.q[j], zp, zm, d.q[j], c.q[j], dx2, omega);
+		out.q[j].x = (valid && take_even) ? cand.x : c.q[j].x;
+		out.q[j].y = (valid && !take_even) ? cand.y : c.q[j].y;
+	}
+	return out;
 }
 
 __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs, const float* __restrict__ div, const float* __restrict__ p_in,
@@ -873,17 +918,18 @@ __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs,
 	const int leaf0 = __builtin_amdgcn_readfirstlane(rec[0]), leaf1 = __builtin_amdgcn_readfirstlane(rec[28]);
 	const int n_zm = __builtin_amdgcn_readfirstlane(rec[1 + 12]), n_zp = __builtin_amdgcn_readfirstlane(rec[28 + 1 + 14]);
 	const int x = l >> 3, y = l & 7;
-	const int par = (x + y) & 1;  // 0: even z red, 1: odd z red (both leaves: their z origins differ by 8)
+	const bool par = (x + y) & 1;  // false: even z red, true: odd z red (both leaves: their z origins differ by 8)
 
 	// ---- every global load up front ----
-	const Row8 P0 = glb_row(p_in, leaf0, l), P1 = glb_row(p_in, leaf1, l);
-	const Row8 D0 = glb_row(div, leaf0, l), D1 = glb_row(div, leaf1, l);
-	float2 zlo = make_float2(0.0f, 0.0f), zhi = make_float2(0.0f, 0.0f);  // p(x,y,-2..-1) below leaf0, p(x,y,8..9) above leaf1
-	if (n_zm >= 0) zlo = *reinterpret_cast<const float2*>(p_in + (size_t)n_zm * 512 + l * 8 + 6);
-	if (n_zp >= 0) zhi = *reinterpret_cast<const float2*>(p_in + (size_t)n_zp * 512 + l * 8);
+	const RowP P0 = glb_rowp(p_in, leaf0, l), P1 = glb_rowp(p_in, leaf1, l);
+	const RowP D0 = glb_rowp(div, leaf0, l), D1 = glb_rowp(div, leaf1, l);
+	// p(x,y,-2..-1) below leaf0 and p(x,y,8..9) above leaf1; n_zm / n_zp are wave-uniform
+	float2 zlo = *reinterpret_cast<const float2*>(p_in + (size_t)(n_zm < 0 ? 0 : n_zm) * 512 + l * 8 + 6);
+	float2 zhi = *reinterpret_cast<const float2*>(p_in + (size_t)(n_zp < 0 ? 0 : n_zp) * 512 + l * 8);
+	if (n_zm < 0) zlo = make_float2(0.0f, 0.0f);
+	if (n_zp < 0) zhi = make_float2(0.0f, 0.0f);
 	const int n_zh = par ? n_zm : n_zp;  // this lane's z-halo red voxel: below leaf0 if par, else above leaf1
-	float d_zh = 0.0f;
-	if (n_zh >= 0) d_zh = div[(size_t)n_zh * 512 + l * 8 + (par ? 7 : 0)];
+	float d_zh = div[(size_t)(n_zh < 0 ? 0 : n_zh) * 512 + l * 8 + (par ? 7 : 0)];
 
 	// halo-row duty: lanes 0..31 -> leaf0, 32..63 -> leaf1; face f (-x,+x,-y,+y), row i
 	const int w = l >> 5, h = l & 31, f = h >> 3, i = h & 7;
@@ -892,18 +938,18 @@ __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs,
 	const int n_f = nb[slotF];
 	const int srcA = f == 0 ? 56 + i : (f == 1 ? i : (f == 2 ? i * 8 + 7 : i * 8));
 	const int srcB = f == 0 ? 48 + i : (f == 1 ? 8 + i : (f == 2 ? i * 8 + 6 : i * 8 + 1));
-	const Row8 HA = glb_row(p_in, n_f, srcA);
-	const Row8 HB = glb_row(p_in, n_f, srcB);
-	const Row8 HD = glb_row(div, n_f, srcA);
+	const RowP HA = glb_rowp(p_in, n_f, srcA);
+	const RowP HB = glb_rowp(p_in, n_f, srcB);
+	const RowP HD = glb_rowp(div, n_f, srcA);
 	// the halo row's own z-neighbour outside the pair: z=-1 for the lower leaf, z=8 for the upper leaf
 	const int n_e = nb[slotF + (w ? 1 : -1)];
-	float e_val = 0.0f;
-	if (n_e >= 0) e_val = p_in[(size_t)n_e * 512 + srcA * 8 + (w ? 0 : 7)];
+	float e_val = p_in[(size_t)(n_e < 0 ? 0 : n_e) * 512 + srcA * 8 + (w ? 0 : 7)];
+	e_val = n_e < 0 ? 0.0f : e_val;
 	// edge rows along z (lanes 0..7): tile rows (-1,-1), (-1,8), (8,-1), (8,8) of each leaf
 	const int ew = (l >> 2) & 1, ea = (l >> 1) & 1, eb = l & 1;
-	const bool erow_lane = l < 8;
-	const int n_er = erow_lane ? rec[28 * ew + 1 + (ea ? 2 : 0) * 9 + (eb ? 2 : 0) * 3 + 1] : -1;
-	const Row8 ER = glb_row(p_in, n_er, (ea ? 0 : 7) * 8 + (eb ? 0 : 7));
+	const int n_er = rec[28 * ew + 1 + (ea ? 2 : 0) * 9 + (eb ? 2 : 0) * 3 + 1];
+	RowP ER;
+	if (l < 8) ER = glb_rowp(p_in, n_er, (ea ? 0 : 7) * 8 + (eb ? 0 : 7));
 
 	// ---- row numbers ----
 	const int I = 8 * (x + 1) + y;
@@ -916,91 +962,64 @@ __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs,
 	const int H_yp = f == 3 ? RB : (f == 2 ? 8 * (i + 1) : (i == 7 ? (f == 0 ? 82 : 84) : (f == 0 ? i + 1 : 72 + i + 1)));
 
 	// ---- stage ----
-	pt_put(S, 0, I, P0.v);
-	pt_put(S, 1, I, P1.v);
+	pt_put(S, 0, I, P0);
+	pt_put(S, 1, I, P1);
 	S.ZM[I] = zlo.y;
 	S.ZP[I] = zhi.x;
-	pt_put(S, w, RA, HA.v);
-	pt_put(S, w, RB, HB.v);
-	if (w == 0) S.ZM[RA] = e_val;
-	else S.ZP[RA] = e_val;
-	if (erow_lane) pt_put(S, ew, 81 + ea * 2 + eb, ER.v);
+	pt_put(S, w, RA, HA);
+	pt_put(S, w, RB, HB);
+	(w ? S.ZP : S.ZM)[RA] = e_val;
+	if (l < 8) pt_put(S, ew, 81 + ea * 2 + eb, ER);
 	__syncthreads();
 
 	// ---- phase R ----
-	float hnew[8];
+	RowP hnew, c0, c1;
+	float zc;
 	{
-		const Row8 hxm = pt_row(S, w, H_xm), hxp = pt_row(S, w, H_xp), hym = pt_row(S, w, H_ym), hyp = pt_row(S, w, H_yp);
-		const float below = w == 0 ? e_val : S.HI[0][RA].w;  // z=-1 of this halo row
-		const float above = w == 0 ? S.LO[1][RA].x : e_val;  // z=8
-		const float hc[10] = {below, HA.v[0], HA.v[1], HA.v[2], HA.v[3], HA.v[4], HA.v[5], HA.v[6], HA.v[7], above};
-		float cand[8];
-		row_candidates(hxp, hxm, hyp, hym, hc, HD.v, dx2, omega, cand);
-		const int hpar = (i + ((f & 1) ? 0 : 1)) & 1;  // parity of ax+ay: faces -x,-y sit at coordinate -1
-#pragma unroll
-		for (int z = 0; z < 8; ++z) hnew[z] = (((hpar + z) & 1) == 0 && n_f >= 0) ? cand[z] : HA.v[z];
+		const RowP hxm = pt_row(S, w, H_xm), hxp = pt_row(S, w, H_xp), hym = pt_row(S, w, H_ym), hyp = pt_row(S, w, H_yp);
+		const float other_lo = S.HI[0][RA].w, other_hi = S.LO[1][RA].x;
+		const float below = w ? other_lo : e_val;  // z=-1 of this halo row
+		const float above = w ? e_val : other_hi;  // z=8
+		const bool hpar = (i + ((f & 1) ? 0 : 1)) & 1;  // parity of ax+ay: faces -x,-y sit at coordinate -1
+		hnew = row_sweep(hxp, hxm, hyp, hym, HA, below, above, HD, dx2, omega, !hpar, n_f >= 0);
 	}
-	float c0[10] = {zlo.y, P0.v[0], P0.v[1], P0.v[2], P0.v[3], P0.v[4], P0.v[5], P0.v[6], P0.v[7], P1.v[0]};
-	float c1[10] = {P0.v[7], P1.v[0], P1.v[1], P1.v[2], P1.v[3], P1.v[4], P1.v[5], P1.v[6], P1.v[7], zhi.x};
 	{
-		float cand0[8], cand1[8];
-		{
-			const Row8 xm = pt_row(S, 0, R_xm), xp = pt_row(S, 0, R_xp), ym = pt_row(S, 0, R_ym), yp = pt_row(S, 0, R_yp);
-			row_candidates(xp, xm, yp, ym, c0, D0.v, dx2, omega, cand0);
-		}
-		{
-			const Row8 xm = pt_row(S, 1, R_xm), xp = pt_row(S, 1, R_xp), ym = pt_row(S, 1, R_ym), yp = pt_row(S, 1, R_yp);
-			row_candidates(xp, xm, yp, ym, c1, D1.v, dx2, omega, cand1);
-		}
+		const RowP xm = pt_row(S, 0, R_xm), xp = pt_row(S, 0, R_xp), ym = pt_row(S, 0, R_ym), yp = pt_row(S, 0, R_yp);
+		c0 = row_sweep(xp, xm, yp, ym, P0, zlo.y, P1.q[0].x, D0, dx2, omega, !par, true);
+	}
+	{
+		const RowP xm = pt_row(S, 1, R_xm), xp = pt_row(S, 1, R_xp), ym = pt_row(S, 1, R_ym), yp = pt_row(S, 1, R_yp);
+		c1 = row_sweep(xp, xm, yp, ym, P1, P0.q[3].y, zhi.x, D1, dx2, omega, !par, true);
+	}
+	{
 		// z-halo red voxel: (x,y,-1) under leaf0 when par, else (x,y,8) over leaf1
 		const float* ZA = par ? S.ZM : S.ZP;
-		const float zc = sor_update(ZA[R_xp], ZA[R_xm], ZA[R_yp], ZA[R_ym], par ? P0.v[0] : zhi.y, par ? zlo.x : P1.v[7], d_zh,
-		                            par ? zlo.y : zhi.x, dx2, omega);
-#pragma unroll
-		for (int z = 0; z < 8; ++z) {
-			const bool red = ((par + z) & 1) == 0;
-			c0[z + 1] = red ? cand0[z] : c0[z + 1];
-			c1[z + 1] = red ? cand1[z] : c1[z + 1];
-		}
-		c0[9] = c1[1];  // the face between the two leaves: whichever of the two voxels is red has just been updated
-		c1[0] = c0[8];
-		if (n_zh >= 0) {
-			if (par) c0[0] = zc;
-			else c1[9] = zc;
-		}
+		zc = sor_update(ZA[R_xp], ZA[R_xm], ZA[R_yp], ZA[R_ym], par ? P0.q[0].x : zhi.y, par ? zlo.x : P1.q[3].y, d_zh, par ? zlo.y : zhi.x, dx2,
+		                omega);
 	}
+	// values just outside each row after the red sweep
+	const float below0 = (par && n_zh >= 0) ? zc : zlo.y;
+	const float above1 = (!par && n_zh >= 0) ? zc : zhi.x;
 	__syncthreads();  // phase-R reads complete before the rows are overwritten
-	{
-		const float o0[8] = {c0[1], c0[2], c0[3], c0[4], c0[5], c0[6], c0[7], c0[8]};
-		const float o1[8] = {c1[1], c1[2], c1[3], c1[4], c1[5], c1[6], c1[7], c1[8]};
-		pt_put(S, 0, I, o0);
-		pt_put(S, 1, I, o1);
-		pt_put(S, w, RA, hnew);
-	}
+	pt_put(S, 0, I, c0);
+	pt_put(S, 1, I, c1);
+	pt_put(S, w, RA, hnew);
 	__syncthreads();
 
 	// ---- phase B ----
 	{
-		float cand0[8], cand1[8];
-		{
-			const Row8 xm = pt_row(S, 0, R_xm), xp = pt_row(S, 0, R_xp), ym = pt_row(S, 0, R_ym), yp = pt_row(S, 0, R_yp);
-			row_candidates(xp, xm, yp, ym, c0, D0.v, dx2, omega, cand0);
-		}
-		{
-			const Row8 xm = pt_row(S, 1, R_xm), xp = pt_row(S, 1, R_xp), ym = pt_row(S, 1, R_ym), yp = pt_row(S, 1, R_yp);
-			row_candidates(xp, xm, yp, ym, c1, D1.v, dx2, omega, cand1);
-		}
-		float4 a0, b0, a1, b1;
-		a0.x = par ? cand0[0] : c0[1], a0.y = par ? c0[2] : cand0[1], a0.z = par ? cand0[2] : c0[3], a0.w = par ? c0[4] : cand0[3];
-		b0.x = par ? cand0[4] : c0[5], b0.y = par ? c0[6] : cand0[5], b0.z = par ? cand0[6] : c0[7], b0.w = par ? c0[8] : cand0[7];
-		a1.x = par ? cand1[0] : c1[1], a1.y = par ? c1[2] : cand1[1], a1.z = par ? cand1[2] : c1[3], a1.w = par ? c1[4] : cand1[3];
-		b1.x = par ? cand1[4] : c1[5], b1.y = par ? c1[6] : cand1[5], b1.z = par ? cand1[6] : c1[7], b1.w = par ? c1[8] : cand1[7];
-		float4* q0 = reinterpret_cast<float4*>(p_out + (size_t)leaf0 * 512 + l * 8);
-		float4* q1 = reinterpret_cast<float4*>(p_out + (size_t)leaf1 * 512 + l * 8);
-		q0[0] = a0;
-		q0[1] = b0;
-		q1[0] = a1;
-		q1[1] = b1;
+		const RowP xm = pt_row(S, 0, R_xm), xp = pt_row(S, 0, R_xp), ym = pt_row(S, 0, R_ym), yp = pt_row(S, 0, R_yp);
+		const RowP o = row_sweep(xp, xm, yp, ym, c0, below0, c1.q[0].x, D0, dx2, omega, par, true);
+		float4* q = reinterpret_cast<float4*>(p_out + (size_t)leaf0 * 512 + l * 8);
+		q[0] = make_float4(o.q[0].x, o.q[0].y, o.q[1].x, o.q[1].y);
+		q[1] = make_float4(o.q[2].x, o.q[2].y, o.q[3].x, o.q[3].y);
+	}
+	{
+		const RowP xm = pt_row(S, 1, R_xm), xp = pt_row(S, 1, R_xp), ym = pt_row(S, 1, R_ym), yp = pt_row(S, 1, R_yp);
+		const RowP o = row_sweep(xp, xm, yp, ym, c1, c0.q[3].y, above1, D1, dx2, omega, par, true);
+		float4* q = reinterpret_cast<float4*>(p_out + (size_t)leaf1 * 512 + l * 8);
+		q[0] = make_float4(o.q[0].x, o.q[0].y, o.q[1].x, o.q[1].y);
+		q[1] = make_float4(o.q[2].x, o.q[2].y, o.q[3].x, o.q[3].y);
 	}
 }
 
