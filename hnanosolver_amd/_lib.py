@@ -53,6 +53,7 @@ SIGNATURES = {
     "hns_grid_voxel_size": (_f, [_vp]),
     "hns_grid_set_active_leaves": (_i, [_vp, _u64]),
     "hns_grid_active_leaves": (_u64, [_vp]),
+    "hns_grid_set_outside_element": (_i, [_vp, _u64]),
     "hns_grid_offsets": (_i, [_vp, _vp, _u64, _vp]),
     "hns_grid_neighbor_table": (_i, [_vp, _vp]),
     "hns_grid_coords": (_i, [_vp, _vp]),

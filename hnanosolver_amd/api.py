@@ -172,6 +172,9 @@ class IndexGridHandle:
     def set_active_leaves(self, n: int) -> None:
         _raise(lib.hns_grid_set_active_leaves(self._ptr, int(n)))
 
+    def set_outside_element(self, element_index: int) -> None:
+        _raise(lib.hns_grid_set_outside_element(self._ptr, int(element_index)))
+
     def __del__(self):
         try:
             self.reset()

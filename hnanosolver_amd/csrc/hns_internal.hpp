@@ -50,6 +50,7 @@ struct GridDev {
 	uint32_t hash_mask;
 	int n_leaves;
 	int n_active;
+	int oob;  // element read by advect_scalars for out-of-domain taps (0 on an unpartitioned grid)
 };
 
 }  // namespace hns
@@ -58,6 +59,7 @@ struct hns_grid {
 	hns::Topology topo;
 	float voxel_size = 1.0f;
 	uint64_t n_active = 0;
+	uint64_t outside_element = 0;
 	bool on_device = false;
 	int device = -1;
 	// device copies

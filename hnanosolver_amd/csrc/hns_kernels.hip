@@ -362,7 +362,7 @@ __device__ __forceinline__ void setup_interp(const GridDev& g, const int* s_nbr,
 	ix[6] = t[3];
 	ix[7] = t[7];
 #pragma unroll
-	for (int q = 0; q < 8; ++q) ix[q] = ix[q] < 0 ? 0 : ix[q];
+	for (int q = 0; q < 8; ++q) ix[q] = ix[q] < 0 ? g.oob : ix[q];
 }
 
 template <bool COLL>
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(512) void k_advect_scalars(const GridDev g, const f
 	for (int d = 0; d < 6; ++d) {  // -x,+x,-y,+y,-z,+z (Kernel.cu:219)
 		const int s = (d & 1) ? 1 : -1;
 		const int t = tap_index(g, s_nbr, L.org, ci + (d < 2 ? s : 0), cj + ((d >> 1) == 1 ? s : 0), ck + (d >= 4 ? s : 0));
-		nb[d] = t < 0 ? 0 : t;
+		nb[d] = t < 0 ? g.oob : t;
 	}
 	for (int s = 0; s < P.n; ++s) {
 		const float* __restrict__ in = P.in[s];
@@ -909,6 +909,36 @@ __device__ __forceinline__ RowP row_sweep(const RowP& xp, const RowP& xm, const 
 	return out;
 }
 
+// Per-lane constants of k_rbgs_pair (halo-row duty of lane l), generated at compile time so that the kernel reads them
+// with two 16-byte loads instead of ~100 instructions of lane-dependent index arithmetic.
+struct PairLane {
+	int slotF, srcA, srcB, RA, RB, H_xm, H_xp, H_ym, H_yp, slotE, hpar, pad;
+};
+struct PairLaneTab {
+	PairLane t[64];
+};
+constexpr PairLaneTab make_pair_lane_tab() {
+	PairLaneTab T{};
+	for (int l = 0; l < 64; ++l) {
+		const int w = l >> 5, h = l & 31, f = h >> 3, i = h & 7;
+		PairLane& e = T.t[l];
+		e.slotF = f == 0 ? 4 : (f == 1 ? 22 : (f == 2 ? 10 : 16));
+		e.srcA = f == 0 ? 56 + i : (f == 1 ? i : (f == 2 ? i * 8 + 7 : i * 8));
+		e.srcB = f == 0 ? 48 + i : (f == 1 ? 8 + i : (f == 2 ? i * 8 + 6 : i * 8 + 1));
+		e.RA = f == 0 ? i : (f == 1 ? 72 + i : (f == 2 ? 87 + 8 * i : 96 + 8 * i));
+		e.RB = 89 + 8 * (h / 6) + (h % 6);
+		e.H_xm = f == 0 ? e.RB : (f == 1 ? 64 + i : (i == 0 ? (f == 2 ? 81 : 82) : (f == 2 ? 87 + 8 * (i - 1) : 96 + 8 * (i - 1))));
+		e.H_xp = f == 1 ? e.RB : (f == 0 ? 8 + i : (i == 7 ? (f == 2 ? 83 : 84) : (f == 2 ? 87 + 8 * (i + 1) : 96 + 8 * (i + 1))));
+		e.H_ym = f == 2 ? e.RB : (f == 3 ? 8 * (i + 1) + 7 : (i == 0 ? (f == 0 ? 81 : 83) : (f == 0 ? i - 1 : 72 + i - 1)));
+		e.H_yp = f == 3 ? e.RB : (f == 2 ? 8 * (i + 1) : (i == 7 ? (f == 0 ? 82 : 84) : (f == 0 ? i + 1 : 72 + i + 1)));
+		e.slotE = e.slotF + (w ? 1 : -1);              // the face neighbour one leaf further along -z (lower leaf) / +z (upper leaf)
+		e.hpar = (i + ((f & 1) ? 0 : 1)) & 1;          // parity of the halo row's x+y: faces -x,-y sit at coordinate -1
+		e.pad = 0;
+	}
+	return T;
+}
+__device__ const PairLaneTab g_pair_lane_tab = make_pair_lane_tab();
+
 __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs, const float* __restrict__ div, const float* __restrict__ p_in,
                                                   float* __restrict__ p_out, const float dx2, const float omega) {
 	__shared__ __attribute__((aligned(16))) PairTile S;
@@ -931,18 +961,19 @@ __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs,
 	const int n_zh = par ? n_zm : n_zp;  // this lane's z-halo red voxel: below leaf0 if par, else above leaf1
 	float d_zh = div[(size_t)(n_zh < 0 ? 0 : n_zh) * 512 + l * 8 + (par ? 7 : 0)];
 
-	// halo-row duty: lanes 0..31 -> leaf0, 32..63 -> leaf1; face f (-x,+x,-y,+y), row i
-	const int w = l >> 5, h = l & 31, f = h >> 3, i = h & 7;
+	// halo-row duty: lanes 0..31 -> leaf0, 32..63 -> leaf1; 4 faces x 8 rows each (constants from g_pair_lane_tab)
+	const int w = l >> 5;
+	const int4* __restrict__ lt = reinterpret_cast<const int4*>(&g_pair_lane_tab.t[l]);
+	const int4 t0 = lt[0], t1 = lt[1], t2 = lt[2];
+	const int slotF = t0.x, srcA = t0.y, srcB = t0.z, RA = t0.w, RB = t1.x, H_xm = t1.y, H_xp = t1.z, H_ym = t1.w, H_yp = t2.x, slotE = t2.y;
+	const bool hpar = t2.z;
 	const int* __restrict__ nb = rec + 28 * w + 1;
-	const int slotF = f == 0 ? 4 : (f == 1 ? 22 : (f == 2 ? 10 : 16));
 	const int n_f = nb[slotF];
-	const int srcA = f == 0 ? 56 + i : (f == 1 ? i : (f == 2 ? i * 8 + 7 : i * 8));
-	const int srcB = f == 0 ? 48 + i : (f == 1 ? 8 + i : (f == 2 ? i * 8 + 6 : i * 8 + 1));
 	const RowP HA = glb_rowp(p_in, n_f, srcA);
 	const RowP HB = glb_rowp(p_in, n_f, srcB);
 	const RowP HD = glb_rowp(div, n_f, srcA);
 	// the halo row's own z-neighbour outside the pair: z=-1 for the lower leaf, z=8 for the upper leaf
-	const int n_e = nb[slotF + (w ? 1 : -1)];
+	const int n_e = nb[slotE];
 	float e_val = p_in[(size_t)(n_e < 0 ? 0 : n_e) * 512 + srcA * 8 + (w ? 0 : 7)];
 	e_val = n_e < 0 ? 0.0f : e_val;
 	// edge rows along z (lanes 0..7): tile rows (-1,-1), (-1,8), (8,-1), (8,8) of each leaf
@@ -951,15 +982,9 @@ __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs,
 	RowP ER;
 	if (l < 8) ER = glb_rowp(p_in, n_er, (ea ? 0 : 7) * 8 + (eb ? 0 : 7));
 
-	// ---- row numbers ----
+	// ---- row numbers of the lane's own rows ----
 	const int I = 8 * (x + 1) + y;
 	const int R_xm = I - 8, R_xp = I + 8, R_ym = y == 0 ? 87 + 8 * x : I - 1, R_yp = y == 7 ? 96 + 8 * x : I + 1;
-	const int RA = f == 0 ? i : (f == 1 ? 72 + i : (f == 2 ? 87 + 8 * i : 96 + 8 * i));
-	const int RB = 89 + 8 * (h / 6) + (h % 6);
-	const int H_xm = f == 0 ? RB : (f == 1 ? 64 + i : (i == 0 ? (f == 2 ? 81 : 82) : (f == 2 ? 87 + 8 * (i - 1) : 96 + 8 * (i - 1))));
-	const int H_xp = f == 1 ? RB : (f == 0 ? 8 + i : (i == 7 ? (f == 2 ? 83 : 84) : (f == 2 ? 87 + 8 * (i + 1) : 96 + 8 * (i + 1))));
-	const int H_ym = f == 2 ? RB : (f == 3 ? 8 * (i + 1) + 7 : (i == 0 ? (f == 0 ? 81 : 83) : (f == 0 ? i - 1 : 72 + i - 1)));
-	const int H_yp = f == 3 ? RB : (f == 2 ? 8 * (i + 1) : (i == 7 ? (f == 0 ? 82 : 84) : (f == 0 ? i + 1 : 72 + i + 1)));
 
 	// ---- stage ----
 	pt_put(S, 0, I, P0);
@@ -980,7 +1005,6 @@ __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs,
 		const float other_lo = S.HI[0][RA].w, other_hi = S.LO[1][RA].x;
 		const float below = w ? other_lo : e_val;  // z=-1 of this halo row
 		const float above = w ? e_val : other_hi;  // z=8
-		const bool hpar = (i + ((f & 1) ? 0 : 1)) & 1;  // parity of ax+ay: faces -x,-y sit at coordinate -1
 		hnew = row_sweep(hxp, hxm, hyp, hym, HA, below, above, HD, dx2, omega, !hpar, n_f >= 0);
 	}
 	{

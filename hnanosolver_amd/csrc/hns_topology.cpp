@@ -184,6 +184,14 @@ int hns_grid_set_active_leaves(hns_grid* g, uint64_t n_active) {
 	return g->on_device ? hns_grid_upload_schedule(g) : HNS_OK;
 }
 
+int hns_grid_set_outside_element(hns_grid* g, uint64_t element_index) {
+	if (!g) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_set_outside_element: null grid");
+	if (element_index >= (uint64_t)g->topo.n_leaves * 512u && element_index != 0)
+		return fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_set_outside_element: index beyond the grid");
+	g->outside_element = element_index;
+	return HNS_OK;
+}
+
 int hns_grid_offsets(const hns_grid* g, const int32_t* ijk, uint64_t n, uint64_t* out) {
 	if (!g || (!ijk && n) || (!out && n)) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_offsets: null argument");
 	for (uint64_t t = 0; t < n; ++t) out[t] = g->topo.offset(ijk[3 * t], ijk[3 * t + 1], ijk[3 * t + 2]);

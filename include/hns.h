@@ -74,6 +74,10 @@ float hns_grid_voxel_size(const hns_grid*);
  * (multi-GPU halo leaves). Default n_active = leaf_count. */
 int hns_grid_set_active_leaves(hns_grid*, uint64_t n_active);
 uint64_t hns_grid_active_leaves(const hns_grid*);
+/* advect_scalars reads ELEMENT 0 of each array for taps outside the domain (reference Kernel.cu:133,192,225). On a
+ * leaf-partitioned rank "element 0" of the global arrays lives at another local index (the ghost copy of global leaf 0):
+ * this sets the flat element index those taps read. Default 0 = the reference's behaviour on an unpartitioned grid. */
+int hns_grid_set_outside_element(hns_grid*, uint64_t element_index);
 /* Host-side queries (work on HOST_ONLY grids): IndexOffsetSampler<0>::offset (Stencils.hpp:59-61): 1-based, 0 = outside. */
 int hns_grid_offsets(const hns_grid*, const int32_t* ijk, uint64_t n, uint64_t* out);
 /* 27-neighbour leaf table, n_leaves x 27 int32, entry (dx+1)*9+(dy+1)*3+(dz+1), -1 = absent. */

@@ -23,6 +23,7 @@ struct orc_grid {
 	int32_t* origins; /* n_leaves x 3 */
 	uint32_t mask;    /* table size - 1 */
 	int32_t* table;   /* open addressing, -1 = empty, else leaf index */
+	uint64_t oob;     /* element read for out-of-domain taps by advect_scalars (0 in the reference) */
 };
 
 static int g_vec3_fma = 1;
@@ -98,6 +99,8 @@ orc_grid* orc_grid_create(const int32_t* leaf_origins_xyz, int64_t n_leaves) {
 	}
 	return g;
 }
+
+void orc_grid_set_outside_element(orc_grid* g, uint64_t element_index) { g->oob = element_index; }
 
 void orc_grid_destroy(orc_grid* g) {
 	if (!g) return;
@@ -420,7 +423,7 @@ static inline interp_t setup_interp(acc_t* a, vec3 pos) {
 	const int32_t c[8][3] = {{i0, j0, k0}, {i1, j0, k0}, {i0, j1, k0}, {i1, j1, k0}, {i0, j0, k1}, {i1, j0, k1}, {i0, j1, k1}, {i1, j1, k1}};
 	for (int t = 0; t < 8; ++t) {
 		const uint64_t off = acc_offset(a, c[t][0], c[t][1], c[t][2]);
-		d.indices[t] = off == 0 ? 0 : off - 1;
+		d.indices[t] = off == 0 ? a->g->oob : off - 1;
 	}
 	return d;
 }
@@ -431,7 +434,7 @@ void orc_advect_scalars(const orc_grid* g, const float* vel, const float* const*
 	static const int offs[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}}; /* Kernel.cu:219 */
 	FOR_EACH_VOXEL(g)
 	uint64_t origIndex = acc_offset(&acc, ci, cj, ck);
-	origIndex = origIndex == 0 ? 0 : origIndex - 1;
+	origIndex = origIndex == 0 ? g->oob : origIndex - 1;
 	const vec3 posCell = v3((float)ci, (float)cj, (float)ck);
 	const vec3 velCenter = v3_load(vel, origIndex);
 	vec3 backPos = v3_sub(posCell, v3_scale(velCenter, scaled_dt));
@@ -452,7 +455,7 @@ void orc_advect_scalars(const orc_grid* g, const float* vel, const float* const*
 	uint64_t nbrIdx[6];
 	for (int n = 0; n < 6; ++n) {
 		const uint64_t off = acc_offset(&acc, ci + offs[n][0], cj + offs[n][1], ck + offs[n][2]);
-		nbrIdx[n] = off == 0 ? 0 : off - 1;
+		nbrIdx[n] = off == 0 ? g->oob : off - 1;
 	}
 	for (int s = 0; s < n_scalars; ++s) {
 		const float* inData = in[s];

@@ -47,6 +47,9 @@ typedef struct {
 /* ---- topology (IndexOffsetSampler<0>, Stencils.hpp:51-71) ---- */
 orc_grid* orc_grid_create(const int32_t* leaf_origins_xyz, int64_t n_leaves); /* leaf l = l-th origin; NULL on duplicate/misaligned */
 void orc_grid_destroy(orc_grid*);
+/* element read by orc_advect_scalars for out-of-domain taps; 0 (default) is the reference's behaviour (Kernel.cu:133,192,225).
+ * Only the partitioned multi-rank tests move it (to the local copy of global element 0). */
+void orc_grid_set_outside_element(orc_grid*, uint64_t element_index);
 int64_t orc_grid_leaf_count(const orc_grid*);
 int64_t orc_grid_voxel_count(const orc_grid*);
 uint64_t orc_offset(const orc_grid*, int32_t i, int32_t j, int32_t k); /* 1-based value index, 0 = outside */

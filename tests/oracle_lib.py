@@ -32,6 +32,7 @@ def oracle():
     sig = {
         "orc_grid_create": (_vp, [_vp, _i64]),
         "orc_grid_destroy": (None, [_vp]),
+        "orc_grid_set_outside_element": (None, [_vp, C.c_uint64]),
         "orc_grid_leaf_count": (_i64, [_vp]),
         "orc_grid_voxel_count": (_i64, [_vp]),
         "orc_offset": (C.c_uint64, [_vp, C.c_int32, C.c_int32, C.c_int32]),
@@ -124,6 +125,9 @@ class OracleGrid:
                 self.g = None
         except Exception:
             pass
+
+    def set_outside_element(self, idx):
+        self.L.orc_grid_set_outside_element(self.g, int(idx))
 
     def coords(self):
         out = np.zeros((self.N, 3), dtype=np.int32)

@@ -1,0 +1,158 @@
+"""CPU-side checks of the drop-in boundary: libhns.so loads, exports exactly what include/hns.h declares, the host-side
+topology agrees with the oracle, and nothing computes without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from hnanosolver_amd import _lib, api, fields
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "hns.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hns_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = header_functions()
+    assert len(names) >= 45
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.library_path()], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (hns_[a-z0-9_]+)", out))
+    assert set(names) <= exported, f"declared but not exported: {sorted(set(names) - exported)}"
+    assert exported <= set(names), f"exported but not declared in include/hns.h: {sorted(exported - set(names))}"
+    assert set(_lib.SIGNATURES) == set(names), "python binding and header disagree"
+    lib = _lib.load_library()
+    assert lib.hns_version() == 100
+
+
+def test_no_cuda_or_reference_symbols_in_library():
+    out = subprocess.run(["nm", "-D", _lib.library_path()], capture_output=True, text=True, check=True).stdout
+    assert "cuda" not in out.lower() and "nanovdb" not in out.lower() and "orc_" not in out
+
+
+def test_host_topology_matches_oracle():
+    from oracle_lib import OracleGrid
+
+    rng = np.random.default_rng(4)
+    lat = np.stack(np.meshgrid(*[np.arange(-3, 3)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    o = (lat[rng.random(len(lat)) < 0.4] * 8).astype(np.int32)
+    o = np.concatenate([o, [[-4104, 0, 0], [2 ** 31 - 8, 0, 0], [-(2 ** 31), 8, 8]]]).astype(np.int32)
+    o = np.ascontiguousarray(o[rng.permutation(len(o))])  # any order is accepted: the caller's order defines the layout
+    h = api.create_grid_from_leaves(o, 0.5, _lib.HNS_GRID_HOST_ONLY)
+    G = OracleGrid(o)
+    assert h.leaf_count() == len(o) and h.voxel_count() == len(o) * 512
+    c = G.coords()
+    assert np.array_equal(h.coords(), c)
+    ijk = np.concatenate([c[rng.integers(0, len(c), 5000)] + rng.integers(-9, 10, (5000, 3)), rng.integers(-6000, 6000, (2000, 3))]).astype(np.int32)
+    assert np.array_equal(h.offsets(ijk), G.offsets(ijk))
+    # the invariant the reference relies on: offset(coords[i]) == i + 1 (Kernel.cu:505 vs :511)
+    assert np.array_equal(h.offsets(c[:4096]), np.arange(1, 4097, dtype=np.uint64))
+    nb = h.neighbor_table()
+    for l in rng.integers(0, len(o), 40):
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dz in (-1, 0, 1):
+                    q = o[l].astype(np.int64) + 8 * np.array([dx, dy, dz])
+                    want = -1
+                    if np.all(q >= -(2 ** 31)) and np.all(q < 2 ** 31):
+                        off = int(G.offsets([q.astype(np.int32)])[0])
+                        want = (off - 1) // 512 if off else -1
+                    assert nb[l, (dx + 1) * 9 + (dy + 1) * 3 + dz + 1] == want
+    assert nb[:, 13].tolist() == list(range(len(o)))
+
+
+def test_create_index_grid_validates_leaf_density():
+    d = api.GridIndexedData()
+    d.allocateCoords(3)
+    d.pCoords()[:] = [[1, 2, 3], [1, 2, 4], [8, 2, 3]]  # the NanoVDB unit-test triple is NOT a leaf-dense domain
+    with pytest.raises(RuntimeError, match="leaf-dense"):
+        api.CreateIndexGrid(d, api.IndexGridHandle(), 1.0, _lib.HNS_GRID_HOST_ONLY)
+    o = fields.dense_leaves(16)
+    c = fields.leaves_to_coords(o)
+    bad = c.copy()
+    bad[700] += 1
+    d.allocateCoords(len(c))
+    d.pCoords()[:] = bad
+    with pytest.raises(RuntimeError, match="breaks the leaf-dense"):
+        api.CreateIndexGrid(d, api.IndexGridHandle(), 1.0, _lib.HNS_GRID_HOST_ONLY)
+    dup = np.concatenate([c, c[:512]])
+    d.allocateCoords(len(dup))
+    d.pCoords()[:] = dup
+    with pytest.raises(RuntimeError, match="appears twice"):
+        api.CreateIndexGrid(d, api.IndexGridHandle(), 1.0, _lib.HNS_GRID_HOST_ONLY)
+    d.allocateCoords(len(c))
+    d.pCoords()[:] = c
+    h = api.IndexGridHandle()
+    api.CreateIndexGrid(d, h, 1.0 / 16, _lib.HNS_GRID_HOST_ONLY)
+    assert h.leaf_count() == 8 and np.array_equal(h.coords(), c)
+
+
+def test_grid_indexed_data_mirrors_reference_container():
+    """reference Tests/IndexGrid.cpp:473-539 (GridIndexedData alloc/add/clear)"""
+    d = api.GridIndexedData()
+    assert d.size() == 0 and d.numValueBlocks() == 0
+    d.allocateCoords(1024)
+    assert d.size() == 1024 and d.pCoords().shape == (1024, 3)
+    assert d.addValueBlock("density", d.FLOAT) and d.addValueBlock("vel", d.VEC3F) and d.addValueBlock("temperature", d.FLOAT)
+    assert not d.addValueBlock("density", d.FLOAT)  # duplicate name refused (GridData.hpp:62-65)
+    assert d.numValueBlocks() == 3
+    assert d.getBlocksOfType(d.FLOAT) == ["density", "temperature"] and d.getBlocksOfType(d.VEC3F) == ["vel"]
+    assert d.pValues("density").shape == (1024,) and d.pValues("vel").shape == (1024, 3)
+    assert d.pValues("nope") is None and d.pValues("density", d.VEC3F) is None  # type mismatch -> nullptr
+    d.pValues("density")[3] = 7.0
+    assert d.pValues("density")[3] == 7.0
+    d.clearValues()
+    assert d.numValueBlocks() == 0 and d.size() == 1024
+    d.clear()
+    assert d.size() == 0 and d.pCoords() is None
+
+
+def test_compute_fails_loudly_without_a_device():
+    lib = _lib.load_library()
+    if lib.hns_device_count() > 0:
+        pytest.skip("a HIP device is present; this test is for the CPU-only container")
+    o = fields.dense_leaves(16)
+    with pytest.raises(_lib.HNSError) as e:
+        api.create_grid_from_leaves(o, 1.0)
+    assert e.value.code == _lib.HNS_ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
+    h = api.create_grid_from_leaves(o, 1.0 / 16, _lib.HNS_GRID_HOST_ONLY)
+    f = fields.synthetic_fields(o, 16)
+    d = api.GridIndexedData()
+    d.allocateCoords(len(f["density"]))
+    d.pCoords()[:] = fields.leaves_to_coords(o)
+    for n in ("density", "temperature", "fuel", "waste", "flame"):
+        d.addValueBlock(n, d.FLOAT)
+        d.pValues(n)[:] = f[n]
+    d.addValueBlock("vel", d.VEC3F)
+    d.pValues("vel")[:] = f["vel"]
+    before = d.pValues("vel").copy()
+    for call in (
+        lambda: api.Compute_Sim(d, h, 5, 0.04, 1.0 / 16, api.CombustionParams(), False),
+        lambda: api.ProjectNonDivergent(d, 5, 1.0 / 16, handle=h),
+        lambda: api.AdvectIndexGrid(d, 0.04, 1.0 / 16, handle=h),
+        lambda: api.AdvectIndexGridVelocity(d, 0.04, 1.0 / 16, handle=h),
+    ):
+        with pytest.raises(_lib.HNSError) as e:
+            call()
+        assert e.value.code == _lib.HNS_ERR_NO_DEVICE
+    assert np.array_equal(d.pValues("vel"), before)
+    # argument validation still comes first, as in the reference (HNanoSolver.cu:12-23)
+    with pytest.raises(ValueError, match="voxelSize must be positive"):
+        api.Compute_Sim(d, h, 5, 0.04, -1.0, api.CombustionParams(), False)
+
+
+def test_synthetic_configurations():
+    assert len(fields.dense_leaves(64)) == 512 and len(fields.dense_leaves(128)) == 4096
+    n = len(fields.plume_leaves(32, 2.5, 0.22))
+    assert abs(n - 4096) <= 0.05 * 4096  # BASELINE.json: ~4k leaves / ~2M voxels
+    o = fields.dense_leaves(32)
+    assert np.array_equal(o, o[fields.nanovdb_order(o)])
+    f = fields.synthetic_fields(o[:8], 32)
+    cfl = np.abs(f["vel"]).max() * 32 / 24
+    assert f["vel"].shape == (4096, 3) and cfl < 6.0
