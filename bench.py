@@ -44,7 +44,42 @@ def parse():
     ap.add_argument("--config", default="256", help="256 (default, roofline config) | 128 | 64 | plume")
     ap.add_argument("--iterations", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cook", action="store_true", help="time the cook-equivalent hns_compute_sim call (upload + grid build + substep + download) instead")
     return ap.parse_args()
+
+
+def cook_equivalent(args):
+    """What one reference SOP cook costs (HNanoSolver.cu:87-133,361-371 + :375-384): CreateIndexGrid + Compute_Sim with all
+    fields crossing PCIe both ways. Reported on its own line; never the headline value."""
+    from hnanosolver_amd import api, fields
+
+    origins, R = fields.config_leaves(args.config)
+    f = fields.synthetic_fields(origins, R)
+    d = api.GridIndexedData()
+    coords = fields.leaves_to_coords(origins)
+    d.allocateCoords(len(coords))
+    d.pCoords()[:] = coords
+    for n in ("density", "temperature", "fuel", "waste", "flame"):
+        d.addValueBlock(n, d.FLOAT)
+        d.pValues(n)[:] = f[n]
+    d.addValueBlock("vel", d.VEC3F)
+    d.pValues("vel")[:] = f["vel"]
+    p = api.CombustionParams(vorticityScale=0.0)
+    times = {"create_index_grid_ms": [], "compute_sim_ms": []}
+    for _ in range(args.warmup + args.steps):
+        h = api.IndexGridHandle()
+        t0 = time.perf_counter()
+        api.CreateIndexGrid(d, h, 1.0 / R)
+        t1 = time.perf_counter()
+        api.Compute_Sim(d, h, args.iterations, 1.0 / 24.0, 1.0 / R, p, False)
+        t2 = time.perf_counter()
+        times["create_index_grid_ms"].append(1e3 * (t1 - t0))
+        times["compute_sim_ms"].append(1e3 * (t2 - t1))
+    k = args.warmup
+    out = {"metric": "cook-equivalent Compute_Sim (host arrays in, host arrays out; PCIe inclusive)", "config": args.config,
+           "active_voxels": len(coords), "create_index_grid_ms": float(np.median(times["create_index_grid_ms"][k:])),
+           "compute_sim_ms": float(np.median(times["compute_sim_ms"][k:])), "bytes_over_pcie_per_cook": int(len(coords) * (12 + 5 * 4) * 2)}
+    print(json.dumps(out))
 
 
 def cpu_baseline(origins, R, iterations, budget_s=25.0):
@@ -108,6 +143,9 @@ def main():
 
     from hnanosolver_amd import api, device as D, fields
 
+    if args.cook:
+        cook_equivalent(args)
+        return
     origins, R = fields.config_leaves(args.config)
     vs, dt = 1.0 / R, 1.0 / 24.0
     n_vox_rank = len(origins) * 512

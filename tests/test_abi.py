@@ -156,3 +156,49 @@ def test_synthetic_configurations():
     f = fields.synthetic_fields(o[:8], 32)
     cfl = np.abs(f["vel"]).max() * 32 / 24
     assert f["vel"].shape == (4096, 3) and cfl < 6.0
+
+
+def _build_host_mirror(tmp_path):
+    exe = os.path.join(str(tmp_path), "host_mirror")
+    libdir = os.path.dirname(_lib.library_path())
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "hnanosolver_amd", "host"),
+           os.path.join(ROOT, "tests", "cpp", "host_mirror.cpp"), "-o", exe, "-L", libdir, "-lhns", f"-Wl,-rpath,{libdir}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_cpp_host_mirror_builds_and_behaves(tmp_path):
+    """hnanosolver_amd/host/HNanoSolver.hpp (the C++ twin of api.py) compiles with plain g++ against the C ABI and maps
+    return codes to the reference's exception types."""
+    exe = _build_host_mirror(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_host_mirror_matches_python_path_on_gpu(tmp_path):
+    exe = _build_host_mirror(tmp_path)
+    o = fields.dense_leaves(32)
+    f = fields.synthetic_fields(o, 32)
+    c = fields.leaves_to_coords(o)
+    inp, outp = os.path.join(str(tmp_path), "in.bin"), os.path.join(str(tmp_path), "out.bin")
+    with open(inp, "wb") as fh:
+        fh.write(np.int64(len(c)).tobytes())
+        fh.write(c.tobytes())
+        fh.write(f["vel"].tobytes())
+        fh.write(f["density"].tobytes())
+    r = subprocess.run([exe, "gpu", inp, outp], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(outp, dtype=np.float32)
+    vel, den = raw[: 3 * len(c)].reshape(-1, 3), raw[3 * len(c):]
+    d = api.GridIndexedData()
+    d.allocateCoords(len(c))
+    d.pCoords()[:] = c
+    d.addValueBlock("density", d.FLOAT)
+    d.addValueBlock("vel", d.VEC3F)
+    d.pValues("density")[:] = f["density"]
+    d.pValues("vel")[:] = f["vel"]
+    api.ProjectNonDivergent(d, 20, 1.0 / 32)
+    api.AdvectIndexGrid(d, 1.0 / 24, 1.0 / 32)
+    assert np.array_equal(vel, d.pValues("vel")) and np.array_equal(den, d.pValues("density"))

@@ -112,3 +112,18 @@ def test_world_size_one_solver_equals_sim():
     torch.cuda.synchronize()
     assert np.array_equal(np.stack([c.cpu().numpy() for c in sol.u], 1), arrays["vel"])
     assert np.array_equal(sol.phi[0].cpu().numpy(), arrays["density"])
+
+
+def test_slab_bench_driver_single_rank():
+    """bench.py's multi-GPU driver, exercised with world = 1 (its halo exchange is then a no-op)."""
+    import torch
+
+    b = HD.SlabBench(fields.dense_leaves(32), 32, 0, 1, 5, 1.0 / 24.0)
+    b.step()
+    b.timing_on()
+    b.step()
+    b.step()
+    ms, launches = b.pressure_time()
+    assert launches == 10 and ms > 0.0
+    torch.cuda.synchronize()
+    assert torch.isfinite(b.solver.u[0]).all()
