@@ -1,0 +1,422 @@
+// hns_advect.hip -- BFECC semi-Lagrangian advection kernels (reference src/Cuda/Kernel.cu:118-453).
+//
+// One 8^3 leaf per 512-thread workgroup, one voxel per thread (coordinate = leaf origin + thread id: no 12 B/voxel
+// coordinate stream). The reference walks the NanoVDB tree for each of its 23-31 taps per voxel; here a tap is
+//     slot = 9*dx + 3*dy + dz (leaf offset of the tap relative to the workgroup's leaf, each in {0,1,2})
+//     index = s_base[slot] + local offset          (s_base = the 27 neighbour leaves' base indices, staged in LDS)
+// computed once per axis for the two planes of a trilinear stencil and combined for its 8 corners, branch-free. Taps
+// farther than one leaf away (|u| dt/dx > 8) take a generic path through the origin hash; it is wave-divergent but rare.
+// The arithmetic (Floor, lerp order z->y->x, fused Vec3f lerps, unfused float lerps, weight-product form of
+// advect_scalars, clamp set and order) is the reference's, so results stay bit-identical to the oracle.
+#include <cstdlib>
+#include <cstring>
+
+#include "hns_device.hpp"
+
+namespace hns {
+
+struct Taps {
+	int t[8];  // flat voxel index of corner (di,dj,dk) at t[di*4+dj*2+dk], -1 = outside the domain
+	float fx, fy, fz;
+};
+
+// stage nbr27 (for the generic path) and the neighbours' base indices leaf*512 (-1 = absent)
+__device__ __forceinline__ LeafCtx stage_leaf_base(const GridDev& g, int* s_nbr, int* s_base, int block) {
+	LeafCtx c;
+	c.leaf = g.sched ? g.sched[block] : block;
+	c.org = g.origins[c.leaf];
+	if (threadIdx.x < 27) {
+		const int nb = g.nbr27[c.leaf * 27 + threadIdx.x];
+		s_nbr[threadIdx.x] = nb;
+		s_base[threadIdx.x] = nb < 0 ? -1 : nb * 512;
+	}
+	__syncthreads();
+	return c;
+}
+
+// Floor (Stencils.hpp:25-43) + the eight corner indices of TrilinearSampler::stencil (Stencils.hpp:104-114)
+__device__ __forceinline__ Taps make_taps(const GridDev& g, const int* s_nbr, const int* s_base, const int4 org, float x, float y, float z) {
+	Taps T;
+	const int i = __float2int_rd(x), j = __float2int_rd(y), k = __float2int_rd(z);
+	T.fx = x - (float)i;
+	T.fy = y - (float)j;
+	T.fz = z - (float)k;
+	// leaf offsets (+1) of the two planes per axis; near <=> all in {0,1,2}
+	const int ax0 = (i >> 3) - (org.x >> 3) + 1, ax1 = ((i + 1) >> 3) - (org.x >> 3) + 1;
+	const int ay0 = (j >> 3) - (org.y >> 3) + 1, ay1 = ((j + 1) >> 3) - (org.y >> 3) + 1;
+	const int az0 = (k >> 3) - (org.z >> 3) + 1, az1 = ((k + 1) >> 3) - (org.z >> 3) + 1;
+	const bool near = ((unsigned)ax0 <= 2u) & ((unsigned)ax1 <= 2u) & ((unsigned)ay0 <= 2u) & ((unsigned)ay1 <= 2u) & ((unsigned)az0 <= 2u) &
+	                  ((unsigned)az1 <= 2u);
+	if (near) {
+		const int sx[2] = {ax0 * 9, ax1 * 9}, sy[2] = {ay0 * 3, ay1 * 3}, sz[2] = {az0, az1};
+		const int lx[2] = {(i & 7) << 6, ((i + 1) & 7) << 6}, ly[2] = {(j & 7) << 3, ((j + 1) & 7) << 3}, lz[2] = {k & 7, (k + 1) & 7};
+#pragma unroll
+		for (int c = 0; c < 8; ++c) {
+			const int di = c >> 2, dj = (c >> 1) & 1, dk = c & 1;
+			const int b = s_base[sx[di] + sy[dj] + sz[dk]];
+			T.t[c] = b < 0 ? -1 : b + (lx[di] | ly[dj] | lz[dk]);
+		}
+	} else {
+#pragma unroll 1
+		for (int c = 0; c < 8; ++c) T.t[c] = tap_index(g, s_nbr, org, i + (c >> 2), j + ((c >> 1) & 1), k + (c & 1));
+	}
+	return T;
+}
+
+// value or 0 outside the domain (IndexSampler<T,0>, Stencils.hpp:81-89), without a branch
+__device__ __forceinline__ float ldz(const float* __restrict__ f, int idx) {
+	const float v = f[idx < 0 ? 0 : idx];
+	return idx < 0 ? 0.0f : v;
+}
+
+// IndexSampler<float,1>: unfused a + w*(b-a), z then y then x (Stencils.hpp:140-152)
+__device__ __forceinline__ float tri_f_t(const float* __restrict__ f, const Taps& T) {
+	const float z0 = lerp_f(ldz(f, T.t[0]), ldz(f, T.t[1]), T.fz);
+	const float z1 = lerp_f(ldz(f, T.t[2]), ldz(f, T.t[3]), T.fz);
+	const float z2 = lerp_f(ldz(f, T.t[4]), ldz(f, T.t[5]), T.fz);
+	const float z3 = lerp_f(ldz(f, T.t[6]), ldz(f, T.t[7]), T.fz);
+	const float y0 = lerp_f(z0, z1, T.fy);
+	const float y1 = lerp_f(z2, z3, T.fy);
+	return lerp_f(y0, y1, T.fx);
+}
+
+// one planar component of IndexSampler<Vec3f,1> on the device branch: fmaf(w, b-a, a) (Stencils.hpp:131-135)
+__device__ __forceinline__ float tri_c_t(const float* __restrict__ f, const Taps& T) {
+	const float z0 = lerp_c(ldz(f, T.t[0]), ldz(f, T.t[1]), T.fz);
+	const float z1 = lerp_c(ldz(f, T.t[2]), ldz(f, T.t[3]), T.fz);
+	const float z2 = lerp_c(ldz(f, T.t[4]), ldz(f, T.t[5]), T.fz);
+	const float z3 = lerp_c(ldz(f, T.t[6]), ldz(f, T.t[7]), T.fz);
+	const float y0 = lerp_c(z0, z1, T.fy);
+	const float y1 = lerp_c(z2, z3, T.fy);
+	return lerp_c(y0, y1, T.fx);
+}
+
+__device__ __forceinline__ f3 tri_v_t(const float* __restrict__ ux, const float* __restrict__ uy, const float* __restrict__ uz, const Taps& T) {
+	f3 r;
+	r.x = tri_c_t(ux, T);
+	r.y = tri_c_t(uy, T);
+	r.z = tri_c_t(uz, T);
+	return r;
+}
+
+// flat index of the face neighbour of voxel n of the workgroup's leaf along AXIS in direction DIR, -1 = outside
+template <int AXIS, int DIR>
+__device__ __forceinline__ int nbr_idx(const int* s_base, int leaf, int n) {
+	constexpr int shift = AXIS == 0 ? 6 : (AXIS == 1 ? 3 : 0);
+	constexpr int stride = 1 << shift;
+	constexpr int dslot = AXIS == 0 ? 9 : (AXIS == 1 ? 3 : 1);
+	const int c = (n >> shift) & 7;
+	const bool inside = DIR > 0 ? c != 7 : c != 0;
+	const int b = s_base[13 + DIR * dslot];
+	const int in_leaf = leaf * 512 + n + DIR * stride;
+	const int out_leaf = b < 0 ? -1 : b + n - DIR * 7 * stride;
+	return inside ? in_leaf : out_leaf;
+}
+
+// the six face neighbours in the reference's order -x,+x,-y,+y,-z,+z (Kernel.cu:219,334-342,410-421)
+__device__ __forceinline__ void nbr6(const int* s_base, int leaf, int n, int (&t)[6]) {
+	t[0] = nbr_idx<0, -1>(s_base, leaf, n);
+	t[1] = nbr_idx<0, 1>(s_base, leaf, n);
+	t[2] = nbr_idx<1, -1>(s_base, leaf, n);
+	t[3] = nbr_idx<1, 1>(s_base, leaf, n);
+	t[4] = nbr_idx<2, -1>(s_base, leaf, n);
+	t[5] = nbr_idx<2, 1>(s_base, leaf, n);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// advect_vector (reference Kernel.cu:354-453): BFECC self-advection of the velocity, clamped
+// ---------------------------------------------------------------------------------------------------------------
+
+template <bool COLL>
+__global__ __launch_bounds__(512) void k_advect_vector(const GridDev g, const float* __restrict__ ux, const float* __restrict__ uy,
+                                                       const float* __restrict__ uz, float* __restrict__ ox, float* __restrict__ oy,
+                                                       float* __restrict__ oz, const float* __restrict__ sdf, const float scaled_dt,
+                                                       const float inv_dx) {
+	__shared__ int s_nbr[27];
+	__shared__ int s_base[27];
+	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x);
+	const int n = threadIdx.x;
+	const int idx = L.leaf * 512 + n;
+	const int ci = L.org.x + (n >> 6), cj = L.org.y + ((n >> 3) & 7), ck = L.org.z + (n & 7);
+	const float px = (float)ci, py = (float)cj, pz = (float)ck;
+
+	const f3 vo = {ux[idx], uy[idx], uz[idx]};
+	// forward pass (backtrace) then backward check: the same sampling code twice, kept as a 2-trip loop so that the
+	// far-tap path is emitted once
+	float sx = px - scaled_dt * vo.x, sy = py - scaled_dt * vo.y, sz = pz - scaled_dt * vo.z;  // backPos (Kernel.cu:374)
+	float rx = px, ry = py, rz = pz;                                                            // where a collision sends the trace back to
+	f3 vf = {0.0f, 0.0f, 0.0f}, vb = {0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+	for (int pass = 0; pass < 2; ++pass) {
+		Taps T = make_taps(g, s_nbr, s_base, L.org, sx, sy, sz);
+		if (COLL) {
+			if (tri_f_t(sdf, T) < 0.0f) {  // Kernel.cu:377-382 / :390-394
+				sx = rx, sy = ry, sz = rz;
+				T = make_taps(g, s_nbr, s_base, L.org, sx, sy, sz);
+			}
+		}
+		const f3 v = tri_v_t(ux, uy, uz, T);
+		if (pass == 0) {
+			vf = v;
+			rx = sx, ry = sy, rz = sz;  // fwdPos2 falls back to backPos
+			sx = sx + scaled_dt * v.x, sy = sy + scaled_dt * v.y, sz = sz + scaled_dt * v.z;  // Kernel.cu:387
+		} else {
+			vb = v;
+		}
+	}
+	f3 vc = {vf.x + 0.5f * (vo.x - vb.x), vf.y + 0.5f * (vo.y - vb.y), vf.z + 0.5f * (vo.z - vb.z)};
+
+	int nb[6];
+	nbr6(s_base, L.leaf, n, nb);
+	f3 mn = vo, mx = vo;
+#pragma unroll
+	for (int d = 0; d < 6; ++d) {
+		const f3 nv = {ldz(ux, nb[d]), ldz(uy, nb[d]), ldz(uz, nb[d])};
+		mn.x = fminf(mn.x, nv.x);
+		mx.x = fmaxf(mx.x, nv.x);
+		mn.y = fminf(mn.y, nv.y);
+		mx.y = fmaxf(mx.y, nv.y);
+		mn.z = fminf(mn.z, nv.z);
+		mx.z = fmaxf(mx.z, nv.z);
+	}
+	mn.x = fminf(mn.x, vf.x);
+	mx.x = fmaxf(mx.x, vf.x);
+	mn.y = fminf(mn.y, vf.y);
+	mx.y = fmaxf(mx.y, vf.y);
+	mn.z = fminf(mn.z, vf.z);
+	mx.z = fmaxf(mx.z, vf.z);
+	vc.x = fmaxf(mn.x, fminf(vc.x, mx.x));
+	vc.y = fmaxf(mn.y, fminf(vc.y, mx.y));
+	vc.z = fmaxf(mn.z, fminf(vc.z, mx.z));
+
+	if (COLL) {  // Kernel.cu:433-450
+		const float sv = sdf[idx];
+		if (sv < 0.0f) {
+			vc.x = vc.y = vc.z = 0.0f;
+		} else if (sv < 0.1f) {
+			const f3 nrm = sdf_normal(g, s_nbr, L.org, sdf, ci, cj, ck, inv_dx);
+			vc = no_slip_blend(vc, nrm, 1.0f - (sv / 1.5f));
+		}
+	}
+	ox[idx] = vc.x;
+	oy[idx] = vc.y;
+	oz[idx] = vc.z;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// advect_scalar (reference Kernel.cu:269-352): single field, nested-lerp trilinear
+// ---------------------------------------------------------------------------------------------------------------
+
+template <bool COLL>
+__global__ __launch_bounds__(512) void k_advect_scalar(const GridDev g, const float* __restrict__ ux, const float* __restrict__ uy,
+                                                       const float* __restrict__ uz, const float* __restrict__ in, float* __restrict__ out,
+                                                       const float* __restrict__ sdf, const float scaled_dt) {
+	__shared__ int s_nbr[27];
+	__shared__ int s_base[27];
+	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x);
+	const int n = threadIdx.x;
+	const int idx = L.leaf * 512 + n;
+	const int ci = L.org.x + (n >> 6), cj = L.org.y + ((n >> 3) & 7), ck = L.org.z + (n & 7);
+	const float px = (float)ci, py = (float)cj, pz = (float)ck;
+
+	const float phiOrig = in[idx];
+	const f3 vc = {ux[idx], uy[idx], uz[idx]};
+	float sx = px - scaled_dt * vc.x, sy = py - scaled_dt * vc.y, sz = pz - scaled_dt * vc.z;
+	float rx = px, ry = py, rz = pz;
+	float phiForward = 0.0f, phiBackward = 0.0f;
+#pragma unroll 1
+	for (int pass = 0; pass < 2; ++pass) {
+		Taps T = make_taps(g, s_nbr, s_base, L.org, sx, sy, sz);
+		if (COLL) {
+			if (tri_f_t(sdf, T) < 0.0f) {
+				sx = rx, sy = ry, sz = rz;
+				T = make_taps(g, s_nbr, s_base, L.org, sx, sy, sz);
+			}
+		}
+		const float phi = tri_f_t(in, T);
+		if (pass == 0) {
+			phiForward = phi;
+			const f3 vf = tri_v_t(ux, uy, uz, T);  // same eight taps as phiForward
+			rx = sx, ry = sy, rz = sz;
+			sx = sx + scaled_dt * vf.x, sy = sy + scaled_dt * vf.y, sz = sz + scaled_dt * vf.z;
+		} else {
+			phiBackward = phi;
+		}
+	}
+	const float error = phiOrig - phiBackward;
+	const float phiCorr = phiForward + 0.5f * error;
+	int nb[6];
+	nbr6(s_base, L.leaf, n, nb);
+	float mn = phiOrig, mx = phiOrig;
+#pragma unroll
+	for (int d = 0; d < 6; ++d) {
+		const float nv = ldz(in, nb[d]);
+		mn = fminf(mn, nv);
+		mx = fmaxf(mx, nv);
+	}
+	mn = fminf(mn, phiForward);
+	mx = fmaxf(mx, phiForward);
+	out[idx] = fmaxf(mn, fminf(phiCorr, mx));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// advect_scalars (reference Kernel.cu:118-266): one backtrace shared by up to HNS_MAX_SCALARS fields,
+// weight-product trilinear, out-of-domain taps read ELEMENT g.oob (0 in the reference: Kernel.cu:133,192,225)
+// ---------------------------------------------------------------------------------------------------------------
+
+#define HNS_MAX_SCALARS 8
+struct ScalarPtrs {
+	const float* in[HNS_MAX_SCALARS];
+	float* out[HNS_MAX_SCALARS];
+	int n;
+};
+
+// setupInterpolation (Kernel.cu:163-196): indices and weights in the order 000,100,010,110,001,101,011,111 of (x,y,z)
+__device__ __forceinline__ void interp_from_taps(const Taps& T, int oob, int (&ix)[8], float (&w)[8]) {
+	const float tx = T.fx, ty = T.fy, tz = T.fz;
+	const float itx = 1.0f - tx, ity = 1.0f - ty, itz = 1.0f - tz;
+	const float w00 = itx * ity, w10 = tx * ity, w01 = itx * ty, w11 = tx * ty;
+	w[0] = w00 * itz;
+	w[1] = w10 * itz;
+	w[2] = w01 * itz;
+	w[3] = w11 * itz;
+	w[4] = w00 * tz;
+	w[5] = w10 * tz;
+	w[6] = w01 * tz;
+	w[7] = w11 * tz;
+	const int perm[8] = {0, 4, 2, 6, 1, 5, 3, 7};  // (di,dj,dk) at t[di*4+dj*2+dk]
+#pragma unroll
+	for (int q = 0; q < 8; ++q) ix[q] = T.t[perm[q]] < 0 ? oob : T.t[perm[q]];
+}
+
+template <bool COLL>
+__global__ __launch_bounds__(512) void k_advect_scalars(const GridDev g, const float* __restrict__ ux, const float* __restrict__ uy,
+                                                        const float* __restrict__ uz, const ScalarPtrs P, const float* __restrict__ sdf,
+                                                        const float scaled_dt) {
+	__shared__ int s_nbr[27];
+	__shared__ int s_base[27];
+	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x);
+	const int n = threadIdx.x;
+	const int idx = L.leaf * 512 + n;
+	const int ci = L.org.x + (n >> 6), cj = L.org.y + ((n >> 3) & 7), ck = L.org.z + (n & 7);
+	const float px = (float)ci, py = (float)cj, pz = (float)ck;
+
+	const f3 vc = {ux[idx], uy[idx], uz[idx]};
+	float sx = px - scaled_dt * vc.x, sy = py - scaled_dt * vc.y, sz = pz - scaled_dt * vc.z;
+	float rx = px, ry = py, rz = pz;
+	int bi[8], fi[8];
+	float bw[8], fw[8];
+#pragma unroll 1
+	for (int pass = 0; pass < 2; ++pass) {
+		Taps T = make_taps(g, s_nbr, s_base, L.org, sx, sy, sz);
+		if (COLL) {  // the back-position test is made twice in the reference (Kernel.cu:142-155); the repeat cannot change the outcome
+			if (tri_f_t(sdf, T) < 0.0f) {
+				sx = rx, sy = ry, sz = rz;
+				T = make_taps(g, s_nbr, s_base, L.org, sx, sy, sz);
+			}
+		}
+		if (pass == 0) {
+			interp_from_taps(T, g.oob, bi, bw);
+			f3 vf = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+			for (int q = 0; q < 8; ++q) {  // velF = velF + v * w (Kernel.cu:201-206), unfused
+				vf.x = vf.x + bw[q] * ux[bi[q]];
+				vf.y = vf.y + bw[q] * uy[bi[q]];
+				vf.z = vf.z + bw[q] * uz[bi[q]];
+			}
+			rx = sx, ry = sy, rz = sz;
+			sx = sx + scaled_dt * vf.x, sy = sy + scaled_dt * vf.y, sz = sz + scaled_dt * vf.z;
+		} else {
+			interp_from_taps(T, g.oob, fi, fw);
+		}
+	}
+	int nb[6];
+	nbr6(s_base, L.leaf, n, nb);
+#pragma unroll
+	for (int d = 0; d < 6; ++d) nb[d] = nb[d] < 0 ? g.oob : nb[d];
+	for (int s = 0; s < P.n; ++s) {
+		const float* __restrict__ in = P.in[s];
+		const float phiOrig = in[idx];
+		float phiF = 0.0f, phiB = 0.0f;
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			phiF = __fmaf_rn(in[bi[q]], bw[q], phiF);
+			phiB = __fmaf_rn(in[fi[q]], fw[q], phiB);
+		}
+		const float error = phiOrig - phiB;
+		const float phiCorr = __fmaf_rn(0.5f, error, phiF);
+		float mn = phiOrig, mx = phiOrig;
+#pragma unroll
+		for (int d = 0; d < 6; ++d) {
+			const float v = in[nb[d]];
+			mn = fminf(mn, v);
+			mx = fmaxf(mx, v);
+		}
+		mn = fminf(mn, phiF);
+		mx = fmaxf(mx, phiF);
+		P.out[s][idx] = fmaxf(mn, fminf(phiCorr, mx));
+	}
+}
+
+}  // namespace hns
+
+using namespace hns;
+
+extern "C" {
+
+int hns_dev_advect_vector(hns_grid* g, const float* ux, const float* uy, const float* uz, float* ox, float* oy, float* oz, const float* sdf,
+                          int has_collision, float dt, float inv_dx, void* stream) {
+	if (int rc = check_grid(g, "hns_dev_advect_vector")) return rc;
+	NULLCHK(!ux || !uy || !uz || !ox || !oy || !oz, "hns_dev_advect_vector");
+	if (g->n_active == 0) return HNS_OK;
+	const float scaled_dt = dt * inv_dx;  // Kernel.cu:361
+	const dim3 grid((unsigned)g->n_active), block(512);
+	if (has_collision && sdf)
+		hipLaunchKernelGGL(k_advect_vector<true>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, ox, oy, oz, sdf, scaled_dt, inv_dx);
+	else
+		hipLaunchKernelGGL(k_advect_vector<false>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, ox, oy, oz, sdf, scaled_dt, inv_dx);
+	return launch_status("hns_dev_advect_vector");
+}
+
+int hns_dev_advect_scalar(hns_grid* g, const float* ux, const float* uy, const float* uz, const float* in, float* out, const float* sdf,
+                          int has_collision, float dt, float inv_dx, void* stream) {
+	if (int rc = check_grid(g, "hns_dev_advect_scalar")) return rc;
+	NULLCHK(!ux || !uy || !uz || !in || !out, "hns_dev_advect_scalar");
+	if (g->n_active == 0) return HNS_OK;
+	const float scaled_dt = dt * inv_dx;
+	const dim3 grid((unsigned)g->n_active), block(512);
+	if (has_collision && sdf)
+		hipLaunchKernelGGL(k_advect_scalar<true>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, in, out, sdf, scaled_dt);
+	else
+		hipLaunchKernelGGL(k_advect_scalar<false>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, in, out, sdf, scaled_dt);
+	return launch_status("hns_dev_advect_scalar");
+}
+
+int hns_dev_advect_scalars(hns_grid* g, const float* ux, const float* uy, const float* uz, const float* const* in, float* const* out, int n,
+                           const float* sdf, int has_collision, float dt, float inv_dx, void* stream) {
+	if (int rc = check_grid(g, "hns_dev_advect_scalars")) return rc;
+	NULLCHK(!ux || !uy || !uz || (n > 0 && (!in || !out)), "hns_dev_advect_scalars");
+	if (g->n_active == 0 || n <= 0) return HNS_OK;
+	const float scaled_dt = dt * inv_dx;
+	const dim3 grid((unsigned)g->n_active), block(512);
+	// the backtrace does not depend on the fields, so splitting S fields over several launches changes nothing numerically
+	for (int base = 0; base < n; base += HNS_MAX_SCALARS) {
+		ScalarPtrs P;
+		P.n = n - base < HNS_MAX_SCALARS ? n - base : HNS_MAX_SCALARS;
+		for (int s = 0; s < HNS_MAX_SCALARS; ++s) {
+			P.in[s] = s < P.n ? in[base + s] : nullptr;
+			P.out[s] = s < P.n ? out[base + s] : nullptr;
+			if (s < P.n && (!P.in[s] || !P.out[s])) {
+				set_error("hns_dev_advect_scalars: null device pointer for field %d", base + s);
+				return HNS_ERR_INVALID_ARGUMENT;
+			}
+		}
+		if (has_collision && sdf)
+			hipLaunchKernelGGL(k_advect_scalars<true>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, P, sdf, scaled_dt);
+		else
+			hipLaunchKernelGGL(k_advect_scalars<false>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, P, sdf, scaled_dt);
+	}
+	return launch_status("hns_dev_advect_scalars");
+}
+
+}  // extern "C"

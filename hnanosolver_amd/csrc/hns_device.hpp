@@ -1,0 +1,253 @@
+// hns_device.hpp -- device-side helpers shared by the kernel files: topology access (replaces the NanoVDB accessor walk
+// of reference src/Utils/Stencils.hpp:51-71), the samplers of Stencils.hpp:74-173, and the collision helpers of
+// reference src/Cuda/Kernel.cu:8-74. Arithmetic keeps the reference's association; build with -ffp-contract=off.
+#pragma once
+
+#include "hns_internal.hpp"
+
+namespace hns {
+
+// ---------------------------------------------------------------------------------------------------------------
+// topology access on the device
+// ---------------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t d_hash_origin(int x, int y, int z) {
+	uint32_t h = (uint32_t)(x >> 3) * 0x9E3779B1u;
+	h ^= (uint32_t)(y >> 3) * 0x85EBCA77u;
+	h ^= (uint32_t)(z >> 3) * 0xC2B2AE3Du;
+	h ^= h >> 15;
+	h *= 0x2C1B3C6Du;
+	h ^= h >> 12;
+	return h;
+}
+
+__device__ __forceinline__ int d_find_leaf(const GridDev& g, int ox, int oy, int oz) {
+	uint32_t s = d_hash_origin(ox, oy, oz) & g.hash_mask;
+	for (;;) {
+		const int l = g.hash[s];
+		if (l < 0) return -1;
+		const int4 o = g.origins[l];
+		if (o.x == ox && o.y == oy && o.z == oz) return l;
+		s = (s + 1) & g.hash_mask;
+	}
+}
+
+// Flat index of global voxel (i,j,k), or -1 when its leaf is absent. `org` is the workgroup's leaf origin and s_nbr its
+// 27-neighbour table (LDS). Replaces IndexOffsetSampler<0>::offset (reference Stencils.hpp:59-61), minus the +1.
+__device__ __forceinline__ int tap_index(const GridDev& g, const int* s_nbr, const int4 org, int i, int j, int k) {
+	const int dx = (i >> 3) - (org.x >> 3), dy = (j >> 3) - (org.y >> 3), dz = (k >> 3) - (org.z >> 3);
+	int leaf;
+	if ((unsigned)(dx + 1) <= 2u && (unsigned)(dy + 1) <= 2u && (unsigned)(dz + 1) <= 2u)
+		leaf = s_nbr[(dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)];
+	else
+		leaf = d_find_leaf(g, i & ~7, j & ~7, k & ~7);
+	return leaf < 0 ? -1 : leaf * 512 + (((i & 7) << 6) | ((j & 7) << 3) | (k & 7));
+}
+
+// IndexSampler<float,0> (Stencils.hpp:81-89): value, or 0 outside the domain
+__device__ __forceinline__ float ld0(const float* __restrict__ f, int idx) { return idx < 0 ? 0.0f : f[idx]; }
+
+struct f3 {
+	float x, y, z;
+};
+
+__device__ __forceinline__ f3 ld0v(const float* __restrict__ ux, const float* __restrict__ uy, const float* __restrict__ uz, int idx) {
+	f3 r;
+	r.x = idx < 0 ? 0.0f : ux[idx];
+	r.y = idx < 0 ? 0.0f : uy[idx];
+	r.z = idx < 0 ? 0.0f : uz[idx];
+	return r;
+}
+
+// The eight corner indices of the trilinear stencil at base (i,j,k): order v[di][dj][dk] -> t[di*4+dj*2+dk]
+__device__ __forceinline__ void tap8(const GridDev& g, const int* s_nbr, const int4 org, int i, int j, int k, int (&t)[8]) {
+	// Fast path: all eight corners in one leaf (true for (7/8)^3 of positions) -> one leaf lookup.
+	if ((i & 7) != 7 && (j & 7) != 7 && (k & 7) != 7) {
+		const int b = tap_index(g, s_nbr, org, i, j, k);
+		t[0] = b;
+		t[1] = b < 0 ? -1 : b + 1;
+		t[2] = b < 0 ? -1 : b + 8;
+		t[3] = b < 0 ? -1 : b + 9;
+		t[4] = b < 0 ? -1 : b + 64;
+		t[5] = b < 0 ? -1 : b + 65;
+		t[6] = b < 0 ? -1 : b + 72;
+		t[7] = b < 0 ? -1 : b + 73;
+	} else {
+		t[0] = tap_index(g, s_nbr, org, i, j, k);
+		t[1] = tap_index(g, s_nbr, org, i, j, k + 1);
+		t[2] = tap_index(g, s_nbr, org, i, j + 1, k);
+		t[3] = tap_index(g, s_nbr, org, i, j + 1, k + 1);
+		t[4] = tap_index(g, s_nbr, org, i + 1, j, k);
+		t[5] = tap_index(g, s_nbr, org, i + 1, j, k + 1);
+		t[6] = tap_index(g, s_nbr, org, i + 1, j + 1, k);
+		t[7] = tap_index(g, s_nbr, org, i + 1, j + 1, k + 1);
+	}
+}
+
+// float lerp of TrilinearSampler (Stencils.hpp:140): a + w*(b-a), unfused
+__device__ __forceinline__ float lerp_f(float a, float b, float w) { return a + w * (b - a); }
+// Vec3f lerp on the device branch (Stencils.hpp:131-135): fmaf(w, b-a, a)
+__device__ __forceinline__ float lerp_c(float a, float b, float w) { return __fmaf_rn(w, b - a, a); }
+
+// IndexSampler<float,1>(Vec3f) (Stencils.hpp:117-153): Floor, 8 taps, lerp z then y then x
+__device__ __forceinline__ float tri_f(const GridDev& g, const int* s_nbr, const int4 org, const float* __restrict__ f, float x, float y,
+                                       float z) {
+	const int i = __float2int_rd(x), j = __float2int_rd(y), k = __float2int_rd(z);
+	x -= (float)i;
+	y -= (float)j;
+	z -= (float)k;
+	int t[8];
+	tap8(g, s_nbr, org, i, j, k, t);
+	const float z0 = lerp_f(ld0(f, t[0]), ld0(f, t[1]), z);
+	const float z1 = lerp_f(ld0(f, t[2]), ld0(f, t[3]), z);
+	const float z2 = lerp_f(ld0(f, t[4]), ld0(f, t[5]), z);
+	const float z3 = lerp_f(ld0(f, t[6]), ld0(f, t[7]), z);
+	const float y0 = lerp_f(z0, z1, y);
+	const float y1 = lerp_f(z2, z3, y);
+	return lerp_f(y0, y1, x);
+}
+
+__device__ __forceinline__ float tri_c(const float* __restrict__ f, const int (&t)[8], float x, float y, float z) {
+	const float z0 = lerp_c(ld0(f, t[0]), ld0(f, t[1]), z);
+	const float z1 = lerp_c(ld0(f, t[2]), ld0(f, t[3]), z);
+	const float z2 = lerp_c(ld0(f, t[4]), ld0(f, t[5]), z);
+	const float z3 = lerp_c(ld0(f, t[6]), ld0(f, t[7]), z);
+	const float y0 = lerp_c(z0, z1, y);
+	const float y1 = lerp_c(z2, z3, y);
+	return lerp_c(y0, y1, x);
+}
+
+// IndexSampler<Vec3f,1>(Vec3f): one index set shared by the three planar components
+__device__ __forceinline__ f3 tri_v(const GridDev& g, const int* s_nbr, const int4 org, const float* __restrict__ ux,
+                                    const float* __restrict__ uy, const float* __restrict__ uz, float x, float y, float z) {
+	const int i = __float2int_rd(x), j = __float2int_rd(y), k = __float2int_rd(z);
+	x -= (float)i;
+	y -= (float)j;
+	z -= (float)k;
+	int t[8];
+	tap8(g, s_nbr, org, i, j, k, t);
+	f3 r;
+	r.x = tri_c(ux, t, x, y, z);
+	r.y = tri_c(uy, t, x, y, z);
+	r.z = tri_c(uz, t, x, y, z);
+	return r;
+}
+
+// Stage the workgroup's leaf id, origin and 27-neighbour table. Returns false for an out-of-range block.
+struct LeafCtx {
+	int leaf;
+	int4 org;
+};
+
+__device__ __forceinline__ LeafCtx stage_leaf(const GridDev& g, int* s_nbr, int block) {
+	LeafCtx c;
+	c.leaf = g.sched ? g.sched[block] : block;
+	c.org = g.origins[c.leaf];
+	if (threadIdx.x < 27) s_nbr[threadIdx.x] = g.nbr27[c.leaf * 27 + threadIdx.x];
+	__syncthreads();
+	return c;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// collision helpers (reference Kernel.cu:8-74)
+// ---------------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ f3 sdf_normal(const GridDev& g, const int* s_nbr, const int4 org, const float* __restrict__ sdf, int i, int j, int k,
+                                         float eps) {
+	const float right = ld0(sdf, tap_index(g, s_nbr, org, i + 1, j, k));
+	const float left = ld0(sdf, tap_index(g, s_nbr, org, i - 1, j, k));
+	const float top = ld0(sdf, tap_index(g, s_nbr, org, i, j + 1, k));
+	const float bottom = ld0(sdf, tap_index(g, s_nbr, org, i, j - 1, k));
+	const float front = ld0(sdf, tap_index(g, s_nbr, org, i, j, k + 1));
+	const float back = ld0(sdf, tap_index(g, s_nbr, org, i, j, k - 1));
+	const float s = 0.5f * eps;
+	f3 gr = {s * (right - left), s * (top - bottom), s * (front - back)};
+	const float len = sqrtf(gr.x * gr.x + gr.y * gr.y + gr.z * gr.z);
+	if (len > 1e-6f) {
+		const float inv = 1.0f / len;
+		gr.x = inv * gr.x;
+		gr.y = inv * gr.y;
+		gr.z = inv * gr.z;
+	} else {
+		gr.x = gr.y = gr.z = 0.0f;
+	}
+	return gr;
+}
+
+__device__ __forceinline__ f3 no_slip_blend(f3 v, f3 n, float blend) {
+	// applyNoSlipBoundary (Kernel.cu:57-74) then v*(1-blend) + no_slip*blend (Kernel.cu:114,448,824)
+	const float vdotn = v.x * n.x + v.y * n.y + v.z * n.z;
+	const f3 t = {v.x - vdotn * n.x, v.y - vdotn * n.y, v.z - vdotn * n.z};
+	const float a = 1.0f - blend;
+	f3 r = {a * v.x + blend * t.x, a * v.y + blend * t.y, a * v.z + blend * t.z};
+	return r;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// 6-neighbour access of a leaf-dense float field for thread n of the leaf's workgroup
+// ---------------------------------------------------------------------------------------------------------------
+
+// value at (x+dx, y+dy, z+dz) for a unit step along one axis; faces resolve through the neighbour table
+template <int AXIS, int DIR>
+__device__ __forceinline__ float nbr_val(const float* __restrict__ f, const int* s_nbr, int leaf, int n) {
+	constexpr int shift = AXIS == 0 ? 6 : (AXIS == 1 ? 3 : 0);
+	constexpr int stride = 1 << shift;
+	const int c = (n >> shift) & 7;
+	if (DIR > 0) {
+		if (c != 7) return f[leaf * 512 + n + stride];
+		const int nl = s_nbr[13 + (AXIS == 0 ? 9 : (AXIS == 1 ? 3 : 1))];
+		return nl < 0 ? 0.0f : f[nl * 512 + n - 7 * stride];
+	} else {
+		if (c != 0) return f[leaf * 512 + n - stride];
+		const int nl = s_nbr[13 - (AXIS == 0 ? 9 : (AXIS == 1 ? 3 : 1))];
+		return nl < 0 ? 0.0f : f[nl * 512 + n + 7 * stride];
+	}
+}
+
+
+}  // namespace hns
+
+// ---- launcher plumbing shared by the kernel files ----
+
+#define HNS_HIP(call)                                                                  \
+	do {                                                                               \
+		hipError_t e__ = (call);                                                       \
+		if (e__ != hipSuccess) {                                                       \
+			hns::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+			return HNS_ERR_HIP;                                                        \
+		}                                                                              \
+	} while (0)
+
+inline int check_grid(const hns_grid* g, const char* who) {
+	if (!g) {
+		hns::set_error("%s: null grid", who);
+		return HNS_ERR_INVALID_ARGUMENT;
+	}
+	if (!g->on_device) {
+		hns::set_error("%s: grid has no device tables (host-only grid or no HIP device); there is no CPU fallback", who);
+		return HNS_ERR_NO_DEVICE;
+	}
+	return HNS_OK;
+}
+
+inline int launch_status(const char* who) {
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) {
+		hns::set_error("%s: kernel launch failed: %s", who, hipGetErrorString(e));
+		return HNS_ERR_HIP;
+	}
+	return HNS_OK;
+}
+
+inline unsigned ew_blocks(uint64_t n) {
+	uint64_t b = (n + 255) / 256;
+	return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+#define NULLCHK(cond, who)                                \
+	if (cond) {                                           \
+		hns::set_error("%s: null device pointer", who);        \
+		return HNS_ERR_INVALID_ARGUMENT;                  \
+	}
+

@@ -1,4 +1,4 @@
-// hns_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for the HNanoSolver substep hot path.
+// hns_pressure.hip -- divergence, red-black SOR (all forms) and pressure-gradient subtraction: hand-written HIP for gfx950 / CDNA4.
 //
 // One 8^3 leaf per workgroup; wave64. All arithmetic is float32 and keeps the association of the reference kernels
 // (reference src/Cuda/Kernel.cu) so that results are reproducible against oracle/hns_oracle.c; build with
@@ -18,448 +18,9 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "hns_internal.hpp"
+#include "hns_device.hpp"
 
 namespace hns {
-
-// ---------------------------------------------------------------------------------------------------------------
-// topology access on the device
-// ---------------------------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ uint32_t d_hash_origin(int x, int y, int z) {
-	uint32_t h = (uint32_t)(x >> 3) * 0x9E3779B1u;
-	h ^= (uint32_t)(y >> 3) * 0x85EBCA77u;
-	h ^= (uint32_t)(z >> 3) * 0xC2B2AE3Du;
-	h ^= h >> 15;
-	h *= 0x2C1B3C6Du;
-	h ^= h >> 12;
-	return h;
-}
-
-__device__ __forceinline__ int d_find_leaf(const GridDev& g, int ox, int oy, int oz) {
-	uint32_t s = d_hash_origin(ox, oy, oz) & g.hash_mask;
-	for (;;) {
-		const int l = g.hash[s];
-		if (l < 0) return -1;
-		const int4 o = g.origins[l];
-		if (o.x == ox && o.y == oy && o.z == oz) return l;
-		s = (s + 1) & g.hash_mask;
-	}
-}
-
-// Flat index of global voxel (i,j,k), or -1 when its leaf is absent. `org` is the workgroup's leaf origin and s_nbr its
-// 27-neighbour table (LDS). Replaces IndexOffsetSampler<0>::offset (reference Stencils.hpp:59-61), minus the +1.
-__device__ __forceinline__ int tap_index(const GridDev& g, const int* s_nbr, const int4 org, int i, int j, int k) {
-	const int dx = (i >> 3) - (org.x >> 3), dy = (j >> 3) - (org.y >> 3), dz = (k >> 3) - (org.z >> 3);
-	int leaf;
-	if ((unsigned)(dx + 1) <= 2u && (unsigned)(dy + 1) <= 2u && (unsigned)(dz + 1) <= 2u)
-		leaf = s_nbr[(dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)];
-	else
-		leaf = d_find_leaf(g, i & ~7, j & ~7, k & ~7);
-	return leaf < 0 ? -1 : leaf * 512 + (((i & 7) << 6) | ((j & 7) << 3) | (k & 7));
-}
-
-// IndexSampler<float,0> (Stencils.hpp:81-89): value, or 0 outside the domain
-__device__ __forceinline__ float ld0(const float* __restrict__ f, int idx) { return idx < 0 ? 0.0f : f[idx]; }
-
-struct f3 {
-	float x, y, z;
-};
-
-__device__ __forceinline__ f3 ld0v(const float* __restrict__ ux, const float* __restrict__ uy, const float* __restrict__ uz, int idx) {
-	f3 r;
-	r.x = idx < 0 ? 0.0f : ux[idx];
-	r.y = idx < 0 ? 0.0f : uy[idx];
-	r.z = idx < 0 ? 0.0f : uz[idx];
-	return r;
-}
-
-// The eight corner indices of the trilinear stencil at base (i,j,k): order v[di][dj][dk] -> t[di*4+dj*2+dk]
-__device__ __forceinline__ void tap8(const GridDev& g, const int* s_nbr, const int4 org, int i, int j, int k, int (&t)[8]) {
-	// Fast path: all eight corners in one leaf (true for (7/8)^3 of positions) -> one leaf lookup.
-	if ((i & 7) != 7 && (j & 7) != 7 && (k & 7) != 7) {
-		const int b = tap_index(g, s_nbr, org, i, j, k);
-		t[0] = b;
-		t[1] = b < 0 ? -1 : b + 1;
-		t[2] = b < 0 ? -1 : b + 8;
-		t[3] = b < 0 ? -1 : b + 9;
-		t[4] = b < 0 ? -1 : b + 64;
-		t[5] = b < 0 ? -1 : b + 65;
-		t[6] = b < 0 ? -1 : b + 72;
-		t[7] = b < 0 ? -1 : b + 73;
-	} else {
-		t[0] = tap_index(g, s_nbr, org, i, j, k);
-		t[1] = tap_index(g, s_nbr, org, i, j, k + 1);
-		t[2] = tap_index(g, s_nbr, org, i, j + 1, k);
-		t[3] = tap_index(g, s_nbr, org, i, j + 1, k + 1);
-		t[4] = tap_index(g, s_nbr, org, i + 1, j, k);
-		t[5] = tap_index(g, s_nbr, org, i + 1, j, k + 1);
-		t[6] = tap_index(g, s_nbr, org, i + 1, j + 1, k);
-		t[7] = tap_index(g, s_nbr, org, i + 1, j + 1, k + 1);
-	}
-}
-
-// float lerp of TrilinearSampler (Stencils.hpp:140): a + w*(b-a), unfused
-__device__ __forceinline__ float lerp_f(float a, float b, float w) { return a + w * (b - a); }
-// Vec3f lerp on the device branch (Stencils.hpp:131-135): fmaf(w, b-a, a)
-__device__ __forceinline__ float lerp_c(float a, float b, float w) { return __fmaf_rn(w, b - a, a); }
-
-// IndexSampler<float,1>(Vec3f) (Stencils.hpp:117-153): Floor, 8 taps, lerp z then y then x
-__device__ __forceinline__ float tri_f(const GridDev& g, const int* s_nbr, const int4 org, const float* __restrict__ f, float x, float y,
-                                       float z) {
-	const int i = __float2int_rd(x), j = __float2int_rd(y), k = __float2int_rd(z);
-	x -= (float)i;
-	y -= (float)j;
-	z -= (float)k;
-	int t[8];
-	tap8(g, s_nbr, org, i, j, k, t);
-	const float z0 = lerp_f(ld0(f, t[0]), ld0(f, t[1]), z);
-	const float z1 = lerp_f(ld0(f, t[2]), ld0(f, t[3]), z);
-	const float z2 = lerp_f(ld0(f, t[4]), ld0(f, t[5]), z);
-	const float z3 = lerp_f(ld0(f, t[6]), ld0(f, t[7]), z);
-	const float y0 = lerp_f(z0, z1, y);
-	const float y1 = lerp_f(z2, z3, y);
-	return lerp_f(y0, y1, x);
-}
-
-__device__ __forceinline__ float tri_c(const float* __restrict__ f, const int (&t)[8], float x, float y, float z) {
-	const float z0 = lerp_c(ld0(f, t[0]), ld0(f, t[1]), z);
-	const float z1 = lerp_c(ld0(f, t[2]), ld0(f, t[3]), z);
-	const float z2 = lerp_c(ld0(f, t[4]), ld0(f, t[5]), z);
-	const float z3 = lerp_c(ld0(f, t[6]), ld0(f, t[7]), z);
-	const float y0 = lerp_c(z0, z1, y);
-	const float y1 = lerp_c(z2, z3, y);
-	return lerp_c(y0, y1, x);
-}
-
-// IndexSampler<Vec3f,1>(Vec3f): one index set shared by the three planar components
-__device__ __forceinline__ f3 tri_v(const GridDev& g, const int* s_nbr, const int4 org, const float* __restrict__ ux,
-                                    const float* __restrict__ uy, const float* __restrict__ uz, float x, float y, float z) {
-	const int i = __float2int_rd(x), j = __float2int_rd(y), k = __float2int_rd(z);
-	x -= (float)i;
-	y -= (float)j;
-	z -= (float)k;
-	int t[8];
-	tap8(g, s_nbr, org, i, j, k, t);
-	f3 r;
-	r.x = tri_c(ux, t, x, y, z);
-	r.y = tri_c(uy, t, x, y, z);
-	r.z = tri_c(uz, t, x, y, z);
-	return r;
-}
-
-// Stage the workgroup's leaf id, origin and 27-neighbour table. Returns false for an out-of-range block.
-struct LeafCtx {
-	int leaf;
-	int4 org;
-};
-
-__device__ __forceinline__ LeafCtx stage_leaf(const GridDev& g, int* s_nbr, int block) {
-	LeafCtx c;
-	c.leaf = g.sched ? g.sched[block] : block;
-	c.org = g.origins[c.leaf];
-	if (threadIdx.x < 27) s_nbr[threadIdx.x] = g.nbr27[c.leaf * 27 + threadIdx.x];
-	__syncthreads();
-	return c;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// collision helpers (reference Kernel.cu:8-74)
-// ---------------------------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ f3 sdf_normal(const GridDev& g, const int* s_nbr, const int4 org, const float* __restrict__ sdf, int i, int j, int k,
-                                         float eps) {
-	const float right = ld0(sdf, tap_index(g, s_nbr, org, i + 1, j, k));
-	const float left = ld0(sdf, tap_index(g, s_nbr, org, i - 1, j, k));
-	const float top = ld0(sdf, tap_index(g, s_nbr, org, i, j + 1, k));
-	const float bottom = ld0(sdf, tap_index(g, s_nbr, org, i, j - 1, k));
-	const float front = ld0(sdf, tap_index(g, s_nbr, org, i, j, k + 1));
-	const float back = ld0(sdf, tap_index(g, s_nbr, org, i, j, k - 1));
-	const float s = 0.5f * eps;
-	f3 gr = {s * (right - left), s * (top - bottom), s * (front - back)};
-	const float len = sqrtf(gr.x * gr.x + gr.y * gr.y + gr.z * gr.z);
-	if (len > 1e-6f) {
-		const float inv = 1.0f / len;
-		gr.x = inv * gr.x;
-		gr.y = inv * gr.y;
-		gr.z = inv * gr.z;
-	} else {
-		gr.x = gr.y = gr.z = 0.0f;
-	}
-	return gr;
-}
-
-__device__ __forceinline__ f3 no_slip_blend(f3 v, f3 n, float blend) {
-	// applyNoSlipBoundary (Kernel.cu:57-74) then v*(1-blend) + no_slip*blend (Kernel.cu:114,448,824)
-	const float vdotn = v.x * n.x + v.y * n.y + v.z * n.z;
-	const f3 t = {v.x - vdotn * n.x, v.y - vdotn * n.y, v.z - vdotn * n.z};
-	const float a = 1.0f - blend;
-	f3 r = {a * v.x + blend * t.x, a * v.y + blend * t.y, a * v.z + blend * t.z};
-	return r;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// advect_vector (reference Kernel.cu:354-453): BFECC self-advection of the velocity, clamped
-// ---------------------------------------------------------------------------------------------------------------
-
-template <bool COLL>
-__global__ __launch_bounds__(512) void k_advect_vector(const GridDev g, const float* __restrict__ ux, const float* __restrict__ uy,
-                                                       const float* __restrict__ uz, float* __restrict__ ox, float* __restrict__ oy,
-                                                       float* __restrict__ oz, const float* __restrict__ sdf, const float scaled_dt,
-                                                       const float inv_dx) {
-	__shared__ int s_nbr[27];
-	const LeafCtx L = stage_leaf(g, s_nbr, blockIdx.x);
-	const int n = threadIdx.x;
-	const int idx = L.leaf * 512 + n;
-	const int ci = L.org.x + (n >> 6), cj = L.org.y + ((n >> 3) & 7), ck = L.org.z + (n & 7);
-	const float px = (float)ci, py = (float)cj, pz = (float)ck;
-
-	const f3 vo = {ux[idx], uy[idx], uz[idx]};
-	float bx = px - scaled_dt * vo.x, by = py - scaled_dt * vo.y, bz = pz - scaled_dt * vo.z;
-	if (COLL) {
-		if (tri_f(g, s_nbr, L.org, sdf, bx, by, bz) < 0.0f) {
-			bx = px;
-			by = py;
-			bz = pz;
-		}
-	}
-	const f3 vf = tri_v(g, s_nbr, L.org, ux, uy, uz, bx, by, bz);
-	float fx = bx + scaled_dt * vf.x, fy = by + scaled_dt * vf.y, fz = bz + scaled_dt * vf.z;
-	if (COLL) {
-		if (tri_f(g, s_nbr, L.org, sdf, fx, fy, fz) < 0.0f) {
-			fx = bx;
-			fy = by;
-			fz = bz;
-		}
-	}
-	const f3 vb = tri_v(g, s_nbr, L.org, ux, uy, uz, fx, fy, fz);
-	f3 vc = {vf.x + 0.5f * (vo.x - vb.x), vf.y + 0.5f * (vo.y - vb.y), vf.z + 0.5f * (vo.z - vb.z)};
-
-	f3 mn = vo, mx = vo;
-#pragma unroll
-	for (int d = 0; d < 6; ++d) {  // order -x,+x,-y,+y,-z,+z (Kernel.cu:410-421)
-		const int s = (d & 1) ? 1 : -1;
-		const int t = tap_index(g, s_nbr, L.org, ci + (d < 2 ? s : 0), cj + ((d >> 1) == 1 ? s : 0), ck + (d >= 4 ? s : 0));
-		const f3 nv = ld0v(ux, uy, uz, t);
-		mn.x = fminf(mn.x, nv.x);
-		mx.x = fmaxf(mx.x, nv.x);
-		mn.y = fminf(mn.y, nv.y);
-		mx.y = fmaxf(mx.y, nv.y);
-		mn.z = fminf(mn.z, nv.z);
-		mx.z = fmaxf(mx.z, nv.z);
-	}
-	mn.x = fminf(mn.x, vf.x);
-	mx.x = fmaxf(mx.x, vf.x);
-	mn.y = fminf(mn.y, vf.y);
-	mx.y = fmaxf(mx.y, vf.y);
-	mn.z = fminf(mn.z, vf.z);
-	mx.z = fmaxf(mx.z, vf.z);
-	vc.x = fmaxf(mn.x, fminf(vc.x, mx.x));
-	vc.y = fmaxf(mn.y, fminf(vc.y, mx.y));
-	vc.z = fmaxf(mn.z, fminf(vc.z, mx.z));
-
-	if (COLL) {  // Kernel.cu:433-450
-		const float sv = sdf[idx];
-		if (sv < 0.0f) {
-			vc.x = vc.y = vc.z = 0.0f;
-		} else if (sv < 0.1f) {
-			const f3 nrm = sdf_normal(g, s_nbr, L.org, sdf, ci, cj, ck, inv_dx);
-			vc = no_slip_blend(vc, nrm, 1.0f - (sv / 1.5f));
-		}
-	}
-	ox[idx] = vc.x;
-	oy[idx] = vc.y;
-	oz[idx] = vc.z;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// advect_scalar (reference Kernel.cu:269-352): single field, nested-lerp trilinear
-// ---------------------------------------------------------------------------------------------------------------
-
-template <bool COLL>
-__global__ __launch_bounds__(512) void k_advect_scalar(const GridDev g, const float* __restrict__ ux, const float* __restrict__ uy,
-                                                       const float* __restrict__ uz, const float* __restrict__ in, float* __restrict__ out,
-                                                       const float* __restrict__ sdf, const float scaled_dt) {
-	__shared__ int s_nbr[27];
-	const LeafCtx L = stage_leaf(g, s_nbr, blockIdx.x);
-	const int n = threadIdx.x;
-	const int idx = L.leaf * 512 + n;
-	const int ci = L.org.x + (n >> 6), cj = L.org.y + ((n >> 3) & 7), ck = L.org.z + (n & 7);
-	const float px = (float)ci, py = (float)cj, pz = (float)ck;
-
-	const float phiOrig = in[idx];
-	const f3 vc = {ux[idx], uy[idx], uz[idx]};
-	float bx = px - scaled_dt * vc.x, by = py - scaled_dt * vc.y, bz = pz - scaled_dt * vc.z;
-	if (COLL) {
-		if (tri_f(g, s_nbr, L.org, sdf, bx, by, bz) < 0.0f) {
-			bx = px;
-			by = py;
-			bz = pz;
-		}
-	}
-	const float phiForward = tri_f(g, s_nbr, L.org, in, bx, by, bz);
-	const f3 vf = tri_v(g, s_nbr, L.org, ux, uy, uz, bx, by, bz);
-	float fx = bx + scaled_dt * vf.x, fy = by + scaled_dt * vf.y, fz = bz + scaled_dt * vf.z;
-	if (COLL) {
-		if (tri_f(g, s_nbr, L.org, sdf, fx, fy, fz) < 0.0f) {
-			fx = bx;
-			fy = by;
-			fz = bz;
-		}
-	}
-	const float phiBackward = tri_f(g, s_nbr, L.org, in, fx, fy, fz);
-	const float error = phiOrig - phiBackward;
-	float phiCorr = phiForward + 0.5f * error;
-	float mn = phiOrig, mx = phiOrig;
-#pragma unroll
-	for (int d = 0; d < 6; ++d) {
-		const int s = (d & 1) ? 1 : -1;
-		const int t = tap_index(g, s_nbr, L.org, ci + (d < 2 ? s : 0), cj + ((d >> 1) == 1 ? s : 0), ck + (d >= 4 ? s : 0));
-		const float nv = ld0(in, t);
-		mn = fminf(mn, nv);
-		mx = fmaxf(mx, nv);
-	}
-	mn = fminf(mn, phiForward);
-	mx = fmaxf(mx, phiForward);
-	out[idx] = fmaxf(mn, fminf(phiCorr, mx));
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// advect_scalars (reference Kernel.cu:118-266): one backtrace shared by up to HNS_MAX_SCALARS fields,
-// weight-product trilinear, out-of-domain taps read ELEMENT 0 (Kernel.cu:133,192,225)
-// ---------------------------------------------------------------------------------------------------------------
-
-#define HNS_MAX_SCALARS 8
-struct ScalarPtrs {
-	const float* in[HNS_MAX_SCALARS];
-	float* out[HNS_MAX_SCALARS];
-	int n;
-};
-
-__device__ __forceinline__ void setup_interp(const GridDev& g, const int* s_nbr, const int4 org, float x, float y, float z, int (&ix)[8],
-                                             float (&w)[8]) {
-	// setupInterpolation (Kernel.cu:163-196): order 000,100,010,110,001,101,011,111 in (x,y,z)
-	const int i0 = __float2int_rd(x), j0 = __float2int_rd(y), k0 = __float2int_rd(z);
-	const float tx = x - (float)i0, ty = y - (float)j0, tz = z - (float)k0;
-	const float itx = 1.0f - tx, ity = 1.0f - ty, itz = 1.0f - tz;
-	const float w00 = itx * ity, w10 = tx * ity, w01 = itx * ty, w11 = tx * ty;
-	w[0] = w00 * itz;
-	w[1] = w10 * itz;
-	w[2] = w01 * itz;
-	w[3] = w11 * itz;
-	w[4] = w00 * tz;
-	w[5] = w10 * tz;
-	w[6] = w01 * tz;
-	w[7] = w11 * tz;
-	int t[8];
-	tap8(g, s_nbr, org, i0, j0, k0, t);  // t[di*4+dj*2+dk]
-	ix[0] = t[0];
-	ix[1] = t[4];
-	ix[2] = t[2];
-	ix[3] = t[6];
-	ix[4] = t[1];
-	ix[5] = t[5];
-	ix[6] = t[3];
-	ix[7] = t[7];
-#pragma unroll
-	for (int q = 0; q < 8; ++q) ix[q] = ix[q] < 0 ? g.oob : ix[q];
-}
-
-template <bool COLL>
-__global__ __launch_bounds__(512) void k_advect_scalars(const GridDev g, const float* __restrict__ ux, const float* __restrict__ uy,
-                                                        const float* __restrict__ uz, const ScalarPtrs P, const float* __restrict__ sdf,
-                                                        const float scaled_dt) {
-	__shared__ int s_nbr[27];
-	const LeafCtx L = stage_leaf(g, s_nbr, blockIdx.x);
-	const int n = threadIdx.x;
-	const int idx = L.leaf * 512 + n;
-	const int ci = L.org.x + (n >> 6), cj = L.org.y + ((n >> 3) & 7), ck = L.org.z + (n & 7);
-	const float px = (float)ci, py = (float)cj, pz = (float)ck;
-
-	const f3 vc = {ux[idx], uy[idx], uz[idx]};
-	float bx = px - scaled_dt * vc.x, by = py - scaled_dt * vc.y, bz = pz - scaled_dt * vc.z;
-	if (COLL) {  // tested twice in the reference (Kernel.cu:142-155); the second test cannot change the outcome of the first
-		if (tri_f(g, s_nbr, L.org, sdf, bx, by, bz) < 0.0f) {
-			bx = px;
-			by = py;
-			bz = pz;
-		}
-		if (tri_f(g, s_nbr, L.org, sdf, bx, by, bz) < 0.0f) {
-			bx = px;
-			by = py;
-			bz = pz;
-		}
-	}
-	int bi[8], fi[8];
-	float bw[8], fw[8];
-	setup_interp(g, s_nbr, L.org, bx, by, bz, bi, bw);
-	f3 vf = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-	for (int q = 0; q < 8; ++q) {  // velF = velF + v * w (Kernel.cu:201-206), unfused
-		vf.x = vf.x + bw[q] * ux[bi[q]];
-		vf.y = vf.y + bw[q] * uy[bi[q]];
-		vf.z = vf.z + bw[q] * uz[bi[q]];
-	}
-	float fx = bx + scaled_dt * vf.x, fy = by + scaled_dt * vf.y, fz = bz + scaled_dt * vf.z;
-	if (COLL) {
-		if (tri_f(g, s_nbr, L.org, sdf, fx, fy, fz) < 0.0f) {
-			fx = bx;
-			fy = by;
-			fz = bz;
-		}
-	}
-	setup_interp(g, s_nbr, L.org, fx, fy, fz, fi, fw);
-	int nb[6];
-#pragma unroll
-	for (int d = 0; d < 6; ++d) {  // -x,+x,-y,+y,-z,+z (Kernel.cu:219)
-		const int s = (d & 1) ? 1 : -1;
-		const int t = tap_index(g, s_nbr, L.org, ci + (d < 2 ? s : 0), cj + ((d >> 1) == 1 ? s : 0), ck + (d >= 4 ? s : 0));
-		nb[d] = t < 0 ? g.oob : t;
-	}
-	for (int s = 0; s < P.n; ++s) {
-		const float* __restrict__ in = P.in[s];
-		const float phiOrig = in[idx];
-		float phiF = 0.0f, phiB = 0.0f;
-#pragma unroll
-		for (int q = 0; q < 8; ++q) {
-			phiF = __fmaf_rn(in[bi[q]], bw[q], phiF);
-			phiB = __fmaf_rn(in[fi[q]], fw[q], phiB);
-		}
-		const float error = phiOrig - phiB;
-		const float phiCorr = __fmaf_rn(0.5f, error, phiF);
-		float mn = phiOrig, mx = phiOrig;
-#pragma unroll
-		for (int d = 0; d < 6; ++d) {
-			const float v = in[nb[d]];
-			mn = fminf(mn, v);
-			mx = fmaxf(mx, v);
-		}
-		mn = fminf(mn, phiF);
-		mx = fmaxf(mx, phiF);
-		P.out[s][idx] = fmaxf(mn, fminf(phiCorr, mx));
-	}
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// 6-neighbour access of a leaf-dense float field for thread n of the leaf's workgroup
-// ---------------------------------------------------------------------------------------------------------------
-
-// value at (x+dx, y+dy, z+dz) for a unit step along one axis; faces resolve through the neighbour table
-template <int AXIS, int DIR>
-__device__ __forceinline__ float nbr_val(const float* __restrict__ f, const int* s_nbr, int leaf, int n) {
-	constexpr int shift = AXIS == 0 ? 6 : (AXIS == 1 ? 3 : 0);
-	constexpr int stride = 1 << shift;
-	const int c = (n >> shift) & 7;
-	if (DIR > 0) {
-		if (c != 7) return f[leaf * 512 + n + stride];
-		const int nl = s_nbr[13 + (AXIS == 0 ? 9 : (AXIS == 1 ? 3 : 1))];
-		return nl < 0 ? 0.0f : f[nl * 512 + n - 7 * stride];
-	} else {
-		if (c != 0) return f[leaf * 512 + n - stride];
-		const int nl = s_nbr[13 - (AXIS == 0 ? 9 : (AXIS == 1 ? 3 : 1))];
-		return nl < 0 ? 0.0f : f[nl * 512 + n + 7 * stride];
-	}
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // divergence (reference Kernel.cu:499-519 and :455-496)
@@ -480,6 +41,7 @@ __global__ __launch_bounds__(512) void k_divergence(const GridDev g, const float
 	const float zm = (cz + nbr_val<2, -1>(uz, s_nbr, L.leaf, n)) * 0.5f;
 	div[idx] = (xp - xm + yp - ym + zp - zm) * inv_dx;
 }
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // red-black SOR, two-launch form: one colour in place (reference Kernel.cu:591-623 / :521-588)
@@ -1047,6 +609,7 @@ __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs,
 	}
 }
 
+
 // ---------------------------------------------------------------------------------------------------------------
 // subtractPressureGradient (reference Kernel.cu:765-829 / :694-762)
 // ---------------------------------------------------------------------------------------------------------------
@@ -1078,273 +641,12 @@ __global__ __launch_bounds__(512) void k_subtract_gradient(const GridDev g, cons
 	oz[idx] = u.z;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// element-wise kernels
-// ---------------------------------------------------------------------------------------------------------------
-
-// combustion_oxygen (reference Kernel.cu:923-966)
-__global__ __launch_bounds__(256) void k_combustion_oxygen(const float* __restrict__ fuelData, const float* __restrict__ wasteData,
-                                                           const float* __restrict__ temperatureData, float* __restrict__ divergenceData,
-                                                           const float* __restrict__ flameData, float* __restrict__ outFuel,
-                                                           float* __restrict__ outWaste, float* __restrict__ outTemperature,
-                                                           float* __restrict__ outFlame, const float temp_gain, const float expansion,
-                                                           const uint64_t n) {
-	for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (uint64_t)gridDim.x * blockDim.x) {
-		float fuel = fuelData[idx];
-		const float waste = wasteData[idx];
-		const float temperature = temperatureData[idx];
-		const float flame = flameData[idx];
-		if (fuel < 0.001f) fuel = 0.0f;
-		const float oxygen = 1.0f - fuel - waste;
-		if (oxygen < 0.0f) {
-			outFuel[idx] = fuel;
-			outWaste[idx] = waste;
-			outTemperature[idx] = temperature;
-			outFlame[idx] = flame;
-			continue;
-		}
-		const float burn = fminf(oxygen, fuel);
-		outFuel[idx] = fuel - burn;
-		outWaste[idx] = waste + burn * 2.0f;
-		outTemperature[idx] = temperature + burn * temp_gain;
-		divergenceData[idx] += burn * expansion;
-		outFlame[idx] = fmaxf(flame, fminf(1.0f, burn * 10.0f));
-	}
-}
-
-// temperature_buoyancy (reference Kernel.cu:831-847); x and z are vel + 0*dt == vel, so only uy is touched
-__global__ __launch_bounds__(256) void k_temperature_buoyancy(const float* uy, const float* __restrict__ temp, float* out_uy, const float dt,
-                                                              const float ambient, const float strength, const uint64_t n) {
-	for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (uint64_t)gridDim.x * blockDim.x) {
-		const float v = uy[idx];
-		const float t = temp[idx];
-		if (t <= ambient) {
-			out_uy[idx] = v;
-			continue;
-		}
-		const float tempDiff = t - ambient;
-		out_uy[idx] = v + dt * fmaxf(0.0f, tempDiff * strength);
-	}
-}
-
-__global__ __launch_bounds__(256) void k_aos_to_soa(const float* __restrict__ aos, float* __restrict__ x, float* __restrict__ y,
-                                                    float* __restrict__ z, const uint64_t n) {
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-		x[i] = aos[3 * i];
-		y[i] = aos[3 * i + 1];
-		z[i] = aos[3 * i + 2];
-	}
-}
-
-__global__ __launch_bounds__(256) void k_soa_to_aos(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-                                                    float* __restrict__ aos, const uint64_t n) {
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-		aos[3 * i] = x[i];
-		aos[3 * i + 1] = y[i];
-		aos[3 * i + 2] = z[i];
-	}
-}
-
-// whole-leaf gather/scatter for halo exchange: one float4 per thread, 128 threads per leaf
-__global__ __launch_bounds__(128) void k_pack_leaves(const float* __restrict__ field, const int* __restrict__ ids, float* __restrict__ packed) {
-	const int l = ids[blockIdx.x];
-	reinterpret_cast<float4*>(packed + (size_t)blockIdx.x * 512)[threadIdx.x] = reinterpret_cast<const float4*>(field + (size_t)l * 512)[threadIdx.x];
-}
-__global__ __launch_bounds__(128) void k_unpack_leaves(const float* __restrict__ packed, const int* __restrict__ ids, float* __restrict__ field) {
-	const int l = ids[blockIdx.x];
-	reinterpret_cast<float4*>(field + (size_t)l * 512)[threadIdx.x] = reinterpret_cast<const float4*>(packed + (size_t)blockIdx.x * 512)[threadIdx.x];
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// vorticityConfinement (reference Kernel.cu:970-1024 + Utils.cuh:226-243), out of place
-// ---------------------------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ f3 curl_at(const GridDev& g, const int* s_nbr, const int4 org, const float* __restrict__ ux,
-                                      const float* __restrict__ uy, const float* __restrict__ uz, int i, int j, int k, float factor) {
-	const int tpx = tap_index(g, s_nbr, org, i + 1, j, k), tmx = tap_index(g, s_nbr, org, i - 1, j, k);
-	const int tpy = tap_index(g, s_nbr, org, i, j + 1, k), tmy = tap_index(g, s_nbr, org, i, j - 1, k);
-	const int tpz = tap_index(g, s_nbr, org, i, j, k + 1), tmz = tap_index(g, s_nbr, org, i, j, k - 1);
-	f3 w;
-	w.x = ((ld0(uz, tpy) - ld0(uz, tmy)) - (ld0(uy, tpz) - ld0(uy, tmz))) * factor;
-	w.y = ((ld0(ux, tpz) - ld0(ux, tmz)) - (ld0(uz, tpx) - ld0(uz, tmx))) * factor;
-	w.z = ((ld0(uy, tpx) - ld0(uy, tmx)) - (ld0(ux, tpy) - ld0(ux, tmy))) * factor;
-	return w;
-}
-
-__device__ __forceinline__ float curl_mag(const GridDev& g, const int* s_nbr, const int4 org, const float* __restrict__ ux,
-                                          const float* __restrict__ uy, const float* __restrict__ uz, int i, int j, int k, float factor) {
-	const f3 w = curl_at(g, s_nbr, org, ux, uy, uz, i, j, k, factor);
-	return sqrtf(w.x * w.x + w.y * w.y + w.z * w.z);
-}
-
-__global__ __launch_bounds__(512) void k_vorticity(const GridDev g, const float* __restrict__ ux, const float* __restrict__ uy,
-                                                   const float* __restrict__ uz, float* __restrict__ ox, float* __restrict__ oy,
-                                                   float* __restrict__ oz, const float dt, const float inv_dx, const float scale, const int fs) {
-	__shared__ int s_nbr[27];
-	const LeafCtx L = stage_leaf(g, s_nbr, blockIdx.x);
-	const int n = threadIdx.x;
-	const int idx = L.leaf * 512 + n;
-	const int ci = L.org.x + (n >> 6), cj = L.org.y + ((n >> 3) & 7), ck = L.org.z + (n & 7);
-	const float factor = 0.5f * inv_dx;
-	const f3 w = curl_at(g, s_nbr, L.org, ux, uy, uz, ci, cj, ck, factor);
-	const float m_pX = curl_mag(g, s_nbr, L.org, ux, uy, uz, ci + fs, cj, ck, factor), m_mX = curl_mag(g, s_nbr, L.org, ux, uy, uz, ci - fs, cj, ck, factor);
-	const float m_pY = curl_mag(g, s_nbr, L.org, ux, uy, uz, ci, cj + fs, ck, factor), m_mY = curl_mag(g, s_nbr, L.org, ux, uy, uz, ci, cj - fs, ck, factor);
-	const float m_pZ = curl_mag(g, s_nbr, L.org, ux, uy, uz, ci, cj, ck + fs, factor), m_mZ = curl_mag(g, s_nbr, L.org, ux, uy, uz, ci, cj, ck - fs, factor);
-	const float grad_x = (m_pX - m_mX) * 0.5f * inv_dx;
-	const float grad_y = (m_pY - m_mY) * 0.5f * inv_dx;
-	const float grad_z = (m_pZ - m_mZ) * 0.5f * inv_dx;
-	const float gradLen = sqrtf(grad_x * grad_x + grad_y * grad_y + grad_z * grad_z) + 1e-5f;
-	const float Nx = grad_x / gradLen, Ny = grad_y / gradLen, Nz = grad_z / gradLen;
-	ox[idx] = ux[idx] + dt * (scale * (Ny * w.z - Nz * w.y));
-	oy[idx] = uy[idx] + dt * (scale * (Nz * w.x - Nx * w.z));
-	oz[idx] = uz[idx] + dt * (scale * (Nx * w.y - Ny * w.x));
-}
-
-// enforceCollisionBoundaries (reference Kernel.cu:77-116)
-__global__ __launch_bounds__(512) void k_enforce_collision(const GridDev g, float* ux, float* uy, float* uz, const float* __restrict__ sdf,
-                                                           const float inv_dx) {
-	__shared__ int s_nbr[27];
-	const LeafCtx L = stage_leaf(g, s_nbr, blockIdx.x);
-	const int n = threadIdx.x;
-	const int idx = L.leaf * 512 + n;
-	const float sv = sdf[idx];
-	if (sv < 0.0f) {
-		ux[idx] = 0.0f;
-		uy[idx] = 0.0f;
-		uz[idx] = 0.0f;
-		return;
-	}
-	const float margin = 0.1f;
-	if (sv < margin) {
-		const int ci = L.org.x + (n >> 6), cj = L.org.y + ((n >> 3) & 7), ck = L.org.z + (n & 7);
-		const f3 nrm = sdf_normal(g, s_nbr, L.org, sdf, ci, cj, ck, inv_dx);
-		const f3 v = {ux[idx], uy[idx], uz[idx]};
-		const f3 r = no_slip_blend(v, nrm, 1.0f - (sv / margin));
-		ux[idx] = r.x;
-		uy[idx] = r.y;
-		uz[idx] = r.z;
-	}
-}
 
 }  // namespace hns
 
-// ===============================================================================================================
-// launchers (C ABI, include/hns.h "Kernel-level entry points")
-// ===============================================================================================================
-
 using namespace hns;
 
-#define HNS_HIP(call)                                                                  \
-	do {                                                                               \
-		hipError_t e__ = (call);                                                       \
-		if (e__ != hipSuccess) {                                                       \
-			set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
-			return HNS_ERR_HIP;                                                        \
-		}                                                                              \
-	} while (0)
-
-static inline int check_grid(const hns_grid* g, const char* who) {
-	if (!g) {
-		set_error("%s: null grid", who);
-		return HNS_ERR_INVALID_ARGUMENT;
-	}
-	if (!g->on_device) {
-		set_error("%s: grid has no device tables (host-only grid or no HIP device); there is no CPU fallback", who);
-		return HNS_ERR_NO_DEVICE;
-	}
-	return HNS_OK;
-}
-
-static inline int launch_status(const char* who) {
-	hipError_t e = hipGetLastError();
-	if (e != hipSuccess) {
-		set_error("%s: kernel launch failed: %s", who, hipGetErrorString(e));
-		return HNS_ERR_HIP;
-	}
-	return HNS_OK;
-}
-
-static inline unsigned ew_blocks(uint64_t n) {
-	uint64_t b = (n + 255) / 256;
-	return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
-}
-
-#define NULLCHK(cond, who)                                \
-	if (cond) {                                           \
-		set_error("%s: null device pointer", who);        \
-		return HNS_ERR_INVALID_ARGUMENT;                  \
-	}
-
 extern "C" {
-
-int hns_dev_aos_to_soa(const float* aos3, float* x, float* y, float* z, uint64_t n, void* stream) {
-	NULLCHK(!aos3 || !x || !y || !z, "hns_dev_aos_to_soa");
-	if (n == 0) return HNS_OK;
-	hipLaunchKernelGGL(k_aos_to_soa, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, aos3, x, y, z, n);
-	return launch_status("hns_dev_aos_to_soa");
-}
-
-int hns_dev_soa_to_aos(const float* x, const float* y, const float* z, float* aos3, uint64_t n, void* stream) {
-	NULLCHK(!aos3 || !x || !y || !z, "hns_dev_soa_to_aos");
-	if (n == 0) return HNS_OK;
-	hipLaunchKernelGGL(k_soa_to_aos, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, z, aos3, n);
-	return launch_status("hns_dev_soa_to_aos");
-}
-
-int hns_dev_advect_vector(hns_grid* g, const float* ux, const float* uy, const float* uz, float* ox, float* oy, float* oz, const float* sdf,
-                          int has_collision, float dt, float inv_dx, void* stream) {
-	if (int rc = check_grid(g, "hns_dev_advect_vector")) return rc;
-	NULLCHK(!ux || !uy || !uz || !ox || !oy || !oz, "hns_dev_advect_vector");
-	if (g->n_active == 0) return HNS_OK;
-	const float scaled_dt = dt * inv_dx;  // Kernel.cu:361
-	const dim3 grid((unsigned)g->n_active), block(512);
-	if (has_collision && sdf)
-		hipLaunchKernelGGL(k_advect_vector<true>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, ox, oy, oz, sdf, scaled_dt, inv_dx);
-	else
-		hipLaunchKernelGGL(k_advect_vector<false>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, ox, oy, oz, sdf, scaled_dt, inv_dx);
-	return launch_status("hns_dev_advect_vector");
-}
-
-int hns_dev_advect_scalar(hns_grid* g, const float* ux, const float* uy, const float* uz, const float* in, float* out, const float* sdf,
-                          int has_collision, float dt, float inv_dx, void* stream) {
-	if (int rc = check_grid(g, "hns_dev_advect_scalar")) return rc;
-	NULLCHK(!ux || !uy || !uz || !in || !out, "hns_dev_advect_scalar");
-	if (g->n_active == 0) return HNS_OK;
-	const float scaled_dt = dt * inv_dx;
-	const dim3 grid((unsigned)g->n_active), block(512);
-	if (has_collision && sdf)
-		hipLaunchKernelGGL(k_advect_scalar<true>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, in, out, sdf, scaled_dt);
-	else
-		hipLaunchKernelGGL(k_advect_scalar<false>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, in, out, sdf, scaled_dt);
-	return launch_status("hns_dev_advect_scalar");
-}
-
-int hns_dev_advect_scalars(hns_grid* g, const float* ux, const float* uy, const float* uz, const float* const* in, float* const* out, int n,
-                           const float* sdf, int has_collision, float dt, float inv_dx, void* stream) {
-	if (int rc = check_grid(g, "hns_dev_advect_scalars")) return rc;
-	NULLCHK(!ux || !uy || !uz || (n > 0 && (!in || !out)), "hns_dev_advect_scalars");
-	if (g->n_active == 0 || n <= 0) return HNS_OK;
-	const float scaled_dt = dt * inv_dx;
-	const dim3 grid((unsigned)g->n_active), block(512);
-	// the backtrace does not depend on the fields, so splitting S fields over several launches changes nothing numerically
-	for (int base = 0; base < n; base += HNS_MAX_SCALARS) {
-		ScalarPtrs P;
-		P.n = n - base < HNS_MAX_SCALARS ? n - base : HNS_MAX_SCALARS;
-		for (int s = 0; s < HNS_MAX_SCALARS; ++s) {
-			P.in[s] = s < P.n ? in[base + s] : nullptr;
-			P.out[s] = s < P.n ? out[base + s] : nullptr;
-			if (s < P.n && (!P.in[s] || !P.out[s])) {
-				set_error("hns_dev_advect_scalars: null device pointer for field %d", base + s);
-				return HNS_ERR_INVALID_ARGUMENT;
-			}
-		}
-		if (has_collision && sdf)
-			hipLaunchKernelGGL(k_advect_scalars<true>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, P, sdf, scaled_dt);
-		else
-			hipLaunchKernelGGL(k_advect_scalars<false>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, P, sdf, scaled_dt);
-	}
-	return launch_status("hns_dev_advect_scalars");
-}
 
 int hns_dev_divergence(hns_grid* g, const float* ux, const float* uy, const float* uz, float* div, float inv_dx, void* stream) {
 	if (int rc = check_grid(g, "hns_dev_divergence")) return rc;
@@ -1435,61 +737,6 @@ int hns_dev_subtract_pressure_gradient(hns_grid* g, const float* ux, const float
 	else
 		hipLaunchKernelGGL(k_subtract_gradient<false>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, p, ox, oy, oz, sdf, inv_dx);
 	return launch_status("hns_dev_subtract_pressure_gradient");
-}
-
-int hns_dev_combustion_oxygen(const float* fuel, const float* waste, const float* temperature, float* divergence, const float* flame,
-                              float* out_fuel, float* out_waste, float* out_temperature, float* out_flame, float temp_gain, float expansion,
-                              uint64_t n, void* stream) {
-	NULLCHK(!fuel || !waste || !temperature || !divergence || !flame || !out_fuel || !out_waste || !out_temperature || !out_flame,
-	        "hns_dev_combustion_oxygen");
-	if (n == 0) return HNS_OK;
-	hipLaunchKernelGGL(k_combustion_oxygen, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, fuel, waste, temperature, divergence, flame,
-	                   out_fuel, out_waste, out_temperature, out_flame, temp_gain, expansion, n);
-	return launch_status("hns_dev_combustion_oxygen");
-}
-
-int hns_dev_temperature_buoyancy(const float* uy, const float* temperature, float* out_uy, float dt, float ambient, float strength, uint64_t n,
-                                 void* stream) {
-	NULLCHK(!uy || !temperature || !out_uy, "hns_dev_temperature_buoyancy");
-	if (n == 0) return HNS_OK;
-	hipLaunchKernelGGL(k_temperature_buoyancy, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, uy, temperature, out_uy, dt, ambient, strength,
-	                   n);
-	return launch_status("hns_dev_temperature_buoyancy");
-}
-
-int hns_dev_vorticity_confinement(hns_grid* g, const float* ux, const float* uy, const float* uz, float* ox, float* oy, float* oz, float dt,
-                                  float inv_dx, float confinement_scale, float factor_scale, void* stream) {
-	if (int rc = check_grid(g, "hns_dev_vorticity_confinement")) return rc;
-	NULLCHK(!ux || !uy || !uz || !ox || !oy || !oz, "hns_dev_vorticity_confinement");
-	if (ux == ox || uy == oy || uz == oz) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dev_vorticity_confinement: output must not alias input");
-	if (g->n_active == 0) return HNS_OK;
-	const int fs = (int)factor_scale;  // nanovdb::Coord(factorScale,0,0) truncates (Kernel.cu:998)
-	hipLaunchKernelGGL(k_vorticity, dim3((unsigned)g->n_active), dim3(512), 0, (hipStream_t)stream, g->dev(), ux, uy, uz, ox, oy, oz, dt, inv_dx,
-	                   confinement_scale, fs);
-	return launch_status("hns_dev_vorticity_confinement");
-}
-
-int hns_dev_enforce_collision_boundaries(hns_grid* g, float* ux, float* uy, float* uz, const float* sdf, float voxel_size, void* stream) {
-	if (int rc = check_grid(g, "hns_dev_enforce_collision_boundaries")) return rc;
-	NULLCHK(!ux || !uy || !uz, "hns_dev_enforce_collision_boundaries");
-	if (!sdf || g->n_active == 0) return HNS_OK;  // Kernel.cu:83
-	hipLaunchKernelGGL(k_enforce_collision, dim3((unsigned)g->n_active), dim3(512), 0, (hipStream_t)stream, g->dev(), ux, uy, uz, sdf,
-	                   1.0f / voxel_size);
-	return launch_status("hns_dev_enforce_collision_boundaries");
-}
-
-int hns_dev_pack_leaves(const float* field, const int32_t* leaf_ids, uint64_t n, float* packed, void* stream) {
-	NULLCHK((!field || !leaf_ids || !packed) && n, "hns_dev_pack_leaves");
-	if (n == 0) return HNS_OK;
-	hipLaunchKernelGGL(k_pack_leaves, dim3((unsigned)n), dim3(128), 0, (hipStream_t)stream, field, leaf_ids, packed);
-	return launch_status("hns_dev_pack_leaves");
-}
-
-int hns_dev_unpack_leaves(const float* packed, const int32_t* leaf_ids, uint64_t n, float* field, void* stream) {
-	NULLCHK((!field || !leaf_ids || !packed) && n, "hns_dev_unpack_leaves");
-	if (n == 0) return HNS_OK;
-	hipLaunchKernelGGL(k_unpack_leaves, dim3((unsigned)n), dim3(128), 0, (hipStream_t)stream, packed, leaf_ids, field);
-	return launch_status("hns_dev_unpack_leaves");
 }
 
 }  // extern "C"
