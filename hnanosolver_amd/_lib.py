@@ -71,25 +71,23 @@ SIGNATURES = {
     "hns_sim_pressure_solve": (_i, [_vp, _i, _f, _vp]),
     "hns_sim_timing": (_i, [_vp, _i]),
     "hns_sim_pressure_time": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_longlong)]),
-    "hns_sim_velocity_ptr": (_vp, [_vp, _i]),
+    "hns_sim_velocity_ptr": (_vp, [_vp]),
     "hns_sim_field_ptr": (_vp, [_vp, C.c_char_p]),
     "hns_sim_divergence_ptr": (_vp, [_vp]),
     "hns_sim_pressure_ptr": (_vp, [_vp]),
-    "hns_dev_aos_to_soa": (_i, [_fp, _fp, _fp, _fp, _u64, _vp]),
-    "hns_dev_soa_to_aos": (_i, [_fp, _fp, _fp, _fp, _u64, _vp]),
-    "hns_dev_advect_vector": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _f, _f, _vp]),
-    "hns_dev_advect_scalar": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _f, _f, _vp]),
-    "hns_dev_advect_scalars": (_i, [_vp, _fp, _fp, _fp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i, _fp, _i, _f, _f, _vp]),
-    "hns_dev_divergence": (_i, [_vp, _fp, _fp, _fp, _fp, _f, _vp]),
+    "hns_dev_advect_vector": (_i, [_vp, _fp, _fp, _fp, _i, _f, _f, _vp]),
+    "hns_dev_advect_scalar": (_i, [_vp, _fp, _fp, _fp, _fp, _i, _f, _f, _vp]),
+    "hns_dev_advect_scalars": (_i, [_vp, _fp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i, _fp, _i, _f, _f, _vp]),
+    "hns_dev_divergence": (_i, [_vp, _fp, _fp, _f, _vp]),
     "hns_dev_rbgs_color": (_i, [_vp, _fp, _fp, _f, _f, _i, _vp]),
     "hns_dev_rbgs_iterate": (_i, [_vp, _fp, _fp, _fp, _f, _f, _i, _ip, _vp]),
-    "hns_dev_subtract_pressure_gradient": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _f, _vp]),
+    "hns_dev_subtract_pressure_gradient": (_i, [_vp, _fp, _fp, _fp, _fp, _i, _f, _vp]),
     "hns_dev_combustion_oxygen": (_i, [_fp] * 9 + [_f, _f, _u64, _vp]),
     "hns_dev_temperature_buoyancy": (_i, [_fp, _fp, _fp, _f, _f, _f, _u64, _vp]),
-    "hns_dev_vorticity_confinement": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _f, _f, _vp]),
-    "hns_dev_enforce_collision_boundaries": (_i, [_vp, _fp, _fp, _fp, _fp, _f, _vp]),
-    "hns_dev_pack_leaves": (_i, [_fp, _vp, _u64, _fp, _vp]),
-    "hns_dev_unpack_leaves": (_i, [_fp, _vp, _u64, _fp, _vp]),
+    "hns_dev_vorticity_confinement": (_i, [_vp, _fp, _fp, _f, _f, _f, _f, _vp]),
+    "hns_dev_enforce_collision_boundaries": (_i, [_vp, _fp, _fp, _f, _vp]),
+    "hns_dev_pack_leaves": (_i, [_fp, _vp, _u64, _fp, _i, _vp]),
+    "hns_dev_unpack_leaves": (_i, [_fp, _vp, _u64, _fp, _i, _vp]),
     "hns_dev_time_rbgs": (_i, [_vp, _fp, _fp, _fp, _f, _f, _i, _i, C.POINTER(C.c_float), _vp]),
 }
 

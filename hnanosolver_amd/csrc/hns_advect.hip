@@ -80,22 +80,25 @@ __device__ __forceinline__ float tri_f_t(const float* __restrict__ f, const Taps
 	return lerp_f(y0, y1, T.fx);
 }
 
-// one planar component of IndexSampler<Vec3f,1> on the device branch: fmaf(w, b-a, a) (Stencils.hpp:131-135)
-__device__ __forceinline__ float tri_c_t(const float* __restrict__ f, const Taps& T) {
-	const float z0 = lerp_c(ldz(f, T.t[0]), ldz(f, T.t[1]), T.fz);
-	const float z1 = lerp_c(ldz(f, T.t[2]), ldz(f, T.t[3]), T.fz);
-	const float z2 = lerp_c(ldz(f, T.t[4]), ldz(f, T.t[5]), T.fz);
-	const float z3 = lerp_c(ldz(f, T.t[6]), ldz(f, T.t[7]), T.fz);
+// IndexSampler<Vec3f,1> on the device branch: per component fmaf(w, b-a, a) (Stencils.hpp:131-135); eight 12-byte taps
+__device__ __forceinline__ float tri_c8(float c0, float c1, float c2, float c3, float c4, float c5, float c6, float c7, const Taps& T) {
+	const float z0 = lerp_c(c0, c1, T.fz);
+	const float z1 = lerp_c(c2, c3, T.fz);
+	const float z2 = lerp_c(c4, c5, T.fz);
+	const float z3 = lerp_c(c6, c7, T.fz);
 	const float y0 = lerp_c(z0, z1, T.fy);
 	const float y1 = lerp_c(z2, z3, T.fy);
 	return lerp_c(y0, y1, T.fx);
 }
 
-__device__ __forceinline__ f3 tri_v_t(const float* __restrict__ ux, const float* __restrict__ uy, const float* __restrict__ uz, const Taps& T) {
+__device__ __forceinline__ f3 tri_v_t(const float* __restrict__ u, const Taps& T) {
+	f3 c[8];
+#pragma unroll
+	for (int q = 0; q < 8; ++q) c[q] = ld3z(u, T.t[q]);
 	f3 r;
-	r.x = tri_c_t(ux, T);
-	r.y = tri_c_t(uy, T);
-	r.z = tri_c_t(uz, T);
+	r.x = tri_c8(c[0].x, c[1].x, c[2].x, c[3].x, c[4].x, c[5].x, c[6].x, c[7].x, T);
+	r.y = tri_c8(c[0].y, c[1].y, c[2].y, c[3].y, c[4].y, c[5].y, c[6].y, c[7].y, T);
+	r.z = tri_c8(c[0].z, c[1].z, c[2].z, c[3].z, c[4].z, c[5].z, c[6].z, c[7].z, T);
 	return r;
 }
 
@@ -128,10 +131,8 @@ __device__ __forceinline__ void nbr6(const int* s_base, int leaf, int n, int (&t
 // ---------------------------------------------------------------------------------------------------------------
 
 template <bool COLL>
-__global__ __launch_bounds__(512) void k_advect_vector(const GridDev g, const float* __restrict__ ux, const float* __restrict__ uy,
-                                                       const float* __restrict__ uz, float* __restrict__ ox, float* __restrict__ oy,
-                                                       float* __restrict__ oz, const float* __restrict__ sdf, const float scaled_dt,
-                                                       const float inv_dx) {
+__global__ __launch_bounds__(512) void k_advect_vector(const GridDev g, const float* __restrict__ u, float* __restrict__ out,
+                                                       const float* __restrict__ sdf, const float scaled_dt, const float inv_dx) {
 	__shared__ int s_nbr[27];
 	__shared__ int s_base[27];
 	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x);
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(512) void k_advect_vector(const GridDev g, const fl
 	const int ci = L.org.x + (n >> 6), cj = L.org.y + ((n >> 3) & 7), ck = L.org.z + (n & 7);
 	const float px = (float)ci, py = (float)cj, pz = (float)ck;
 
-	const f3 vo = {ux[idx], uy[idx], uz[idx]};
+	const f3 vo = ld3(u, idx);
 	// forward pass (backtrace) then backward check: the same sampling code twice, kept as a 2-trip loop so that the
 	// far-tap path is emitted once
 	float sx = px - scaled_dt * vo.x, sy = py - scaled_dt * vo.y, sz = pz - scaled_dt * vo.z;  // backPos (Kernel.cu:374)
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(512) void k_advect_vector(const GridDev g, const fl
 				T = make_taps(g, s_nbr, s_base, L.org, sx, sy, sz);
 			}
 		}
-		const f3 v = tri_v_t(ux, uy, uz, T);
+		const f3 v = tri_v_t(u, T);
 		if (pass == 0) {
 			vf = v;
 			rx = sx, ry = sy, rz = sz;  // fwdPos2 falls back to backPos
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(512) void k_advect_vector(const GridDev g, const fl
 	f3 mn = vo, mx = vo;
 #pragma unroll
 	for (int d = 0; d < 6; ++d) {
-		const f3 nv = {ldz(ux, nb[d]), ldz(uy, nb[d]), ldz(uz, nb[d])};
+		const f3 nv = ld3z(u, nb[d]);
 		mn.x = fminf(mn.x, nv.x);
 		mx.x = fmaxf(mx.x, nv.x);
 		mn.y = fminf(mn.y, nv.y);
@@ -198,9 +199,7 @@ __global__ __launch_bounds__(512) void k_advect_vector(const GridDev g, const fl
 			vc = no_slip_blend(vc, nrm, 1.0f - (sv / 1.5f));
 		}
 	}
-	ox[idx] = vc.x;
-	oy[idx] = vc.y;
-	oz[idx] = vc.z;
+	st3(out, idx, vc);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -208,9 +207,8 @@ __global__ __launch_bounds__(512) void k_advect_vector(const GridDev g, const fl
 // ---------------------------------------------------------------------------------------------------------------
 
 template <bool COLL>
-__global__ __launch_bounds__(512) void k_advect_scalar(const GridDev g, const float* __restrict__ ux, const float* __restrict__ uy,
-                                                       const float* __restrict__ uz, const float* __restrict__ in, float* __restrict__ out,
-                                                       const float* __restrict__ sdf, const float scaled_dt) {
+__global__ __launch_bounds__(512) void k_advect_scalar(const GridDev g, const float* __restrict__ u, const float* __restrict__ in,
+                                                       float* __restrict__ out, const float* __restrict__ sdf, const float scaled_dt) {
 	__shared__ int s_nbr[27];
 	__shared__ int s_base[27];
 	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x);
@@ -220,7 +218,7 @@ __global__ __launch_bounds__(512) void k_advect_scalar(const GridDev g, const fl
 	const float px = (float)ci, py = (float)cj, pz = (float)ck;
 
 	const float phiOrig = in[idx];
-	const f3 vc = {ux[idx], uy[idx], uz[idx]};
+	const f3 vc = ld3(u, idx);
 	float sx = px - scaled_dt * vc.x, sy = py - scaled_dt * vc.y, sz = pz - scaled_dt * vc.z;
 	float rx = px, ry = py, rz = pz;
 	float phiForward = 0.0f, phiBackward = 0.0f;
@@ -236,7 +234,7 @@ __global__ __launch_bounds__(512) void k_advect_scalar(const GridDev g, const fl
 		const float phi = tri_f_t(in, T);
 		if (pass == 0) {
 			phiForward = phi;
-			const f3 vf = tri_v_t(ux, uy, uz, T);  // same eight taps as phiForward
+			const f3 vf = tri_v_t(u, T);  // same eight taps as phiForward
 			rx = sx, ry = sy, rz = sz;
 			sx = sx + scaled_dt * vf.x, sy = sy + scaled_dt * vf.y, sz = sz + scaled_dt * vf.z;
 		} else {
@@ -290,9 +288,8 @@ __device__ __forceinline__ void interp_from_taps(const Taps& T, int oob, int (&i
 }
 
 template <bool COLL>
-__global__ __launch_bounds__(512) void k_advect_scalars(const GridDev g, const float* __restrict__ ux, const float* __restrict__ uy,
-                                                        const float* __restrict__ uz, const ScalarPtrs P, const float* __restrict__ sdf,
-                                                        const float scaled_dt) {
+__global__ __launch_bounds__(512) void k_advect_scalars(const GridDev g, const float* __restrict__ u, const ScalarPtrs P,
+                                                        const float* __restrict__ sdf, const float scaled_dt) {
 	__shared__ int s_nbr[27];
 	__shared__ int s_base[27];
 	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x);
@@ -301,7 +298,7 @@ __global__ __launch_bounds__(512) void k_advect_scalars(const GridDev g, const f
 	const int ci = L.org.x + (n >> 6), cj = L.org.y + ((n >> 3) & 7), ck = L.org.z + (n & 7);
 	const float px = (float)ci, py = (float)cj, pz = (float)ck;
 
-	const f3 vc = {ux[idx], uy[idx], uz[idx]};
+	const f3 vc = ld3(u, idx);
 	float sx = px - scaled_dt * vc.x, sy = py - scaled_dt * vc.y, sz = pz - scaled_dt * vc.z;
 	float rx = px, ry = py, rz = pz;
 	int bi[8], fi[8];
@@ -320,9 +317,10 @@ __global__ __launch_bounds__(512) void k_advect_scalars(const GridDev g, const f
 			f3 vf = {0.0f, 0.0f, 0.0f};
 #pragma unroll
 			for (int q = 0; q < 8; ++q) {  // velF = velF + v * w (Kernel.cu:201-206), unfused
-				vf.x = vf.x + bw[q] * ux[bi[q]];
-				vf.y = vf.y + bw[q] * uy[bi[q]];
-				vf.z = vf.z + bw[q] * uz[bi[q]];
+				const f3 v = ld3(u, bi[q]);
+				vf.x = vf.x + bw[q] * v.x;
+				vf.y = vf.y + bw[q] * v.y;
+				vf.z = vf.z + bw[q] * v.z;
 			}
 			rx = sx, ry = sy, rz = sz;
 			sx = sx + scaled_dt * vf.x, sy = sy + scaled_dt * vf.y, sz = sz + scaled_dt * vf.z;
@@ -364,38 +362,38 @@ using namespace hns;
 
 extern "C" {
 
-int hns_dev_advect_vector(hns_grid* g, const float* ux, const float* uy, const float* uz, float* ox, float* oy, float* oz, const float* sdf,
-                          int has_collision, float dt, float inv_dx, void* stream) {
+int hns_dev_advect_vector(hns_grid* g, const float* vel3, float* out3, const float* sdf, int has_collision, float dt, float inv_dx, void* stream) {
 	if (int rc = check_grid(g, "hns_dev_advect_vector")) return rc;
-	NULLCHK(!ux || !uy || !uz || !ox || !oy || !oz, "hns_dev_advect_vector");
+	NULLCHK(!vel3 || !out3, "hns_dev_advect_vector");
+	if (vel3 == out3) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dev_advect_vector: output must not alias input");
 	if (g->n_active == 0) return HNS_OK;
 	const float scaled_dt = dt * inv_dx;  // Kernel.cu:361
 	const dim3 grid((unsigned)g->n_active), block(512);
 	if (has_collision && sdf)
-		hipLaunchKernelGGL(k_advect_vector<true>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, ox, oy, oz, sdf, scaled_dt, inv_dx);
+		hipLaunchKernelGGL(k_advect_vector<true>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, out3, sdf, scaled_dt, inv_dx);
 	else
-		hipLaunchKernelGGL(k_advect_vector<false>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, ox, oy, oz, sdf, scaled_dt, inv_dx);
+		hipLaunchKernelGGL(k_advect_vector<false>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, out3, sdf, scaled_dt, inv_dx);
 	return launch_status("hns_dev_advect_vector");
 }
 
-int hns_dev_advect_scalar(hns_grid* g, const float* ux, const float* uy, const float* uz, const float* in, float* out, const float* sdf,
-                          int has_collision, float dt, float inv_dx, void* stream) {
+int hns_dev_advect_scalar(hns_grid* g, const float* vel3, const float* in, float* out, const float* sdf, int has_collision, float dt, float inv_dx,
+                          void* stream) {
 	if (int rc = check_grid(g, "hns_dev_advect_scalar")) return rc;
-	NULLCHK(!ux || !uy || !uz || !in || !out, "hns_dev_advect_scalar");
+	NULLCHK(!vel3 || !in || !out, "hns_dev_advect_scalar");
 	if (g->n_active == 0) return HNS_OK;
 	const float scaled_dt = dt * inv_dx;
 	const dim3 grid((unsigned)g->n_active), block(512);
 	if (has_collision && sdf)
-		hipLaunchKernelGGL(k_advect_scalar<true>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, in, out, sdf, scaled_dt);
+		hipLaunchKernelGGL(k_advect_scalar<true>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, in, out, sdf, scaled_dt);
 	else
-		hipLaunchKernelGGL(k_advect_scalar<false>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, in, out, sdf, scaled_dt);
+		hipLaunchKernelGGL(k_advect_scalar<false>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, in, out, sdf, scaled_dt);
 	return launch_status("hns_dev_advect_scalar");
 }
 
-int hns_dev_advect_scalars(hns_grid* g, const float* ux, const float* uy, const float* uz, const float* const* in, float* const* out, int n,
-                           const float* sdf, int has_collision, float dt, float inv_dx, void* stream) {
+int hns_dev_advect_scalars(hns_grid* g, const float* vel3, const float* const* in, float* const* out, int n, const float* sdf, int has_collision,
+                           float dt, float inv_dx, void* stream) {
 	if (int rc = check_grid(g, "hns_dev_advect_scalars")) return rc;
-	NULLCHK(!ux || !uy || !uz || (n > 0 && (!in || !out)), "hns_dev_advect_scalars");
+	NULLCHK(!vel3 || (n > 0 && (!in || !out)), "hns_dev_advect_scalars");
 	if (g->n_active == 0 || n <= 0) return HNS_OK;
 	const float scaled_dt = dt * inv_dx;
 	const dim3 grid((unsigned)g->n_active), block(512);
@@ -412,9 +410,9 @@ int hns_dev_advect_scalars(hns_grid* g, const float* ux, const float* uy, const 
 			}
 		}
 		if (has_collision && sdf)
-			hipLaunchKernelGGL(k_advect_scalars<true>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, P, sdf, scaled_dt);
+			hipLaunchKernelGGL(k_advect_scalars<true>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, P, sdf, scaled_dt);
 		else
-			hipLaunchKernelGGL(k_advect_scalars<false>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, P, sdf, scaled_dt);
+			hipLaunchKernelGGL(k_advect_scalars<false>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, P, sdf, scaled_dt);
 	}
 	return launch_status("hns_dev_advect_scalars");
 }

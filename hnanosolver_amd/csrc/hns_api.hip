@@ -190,14 +190,13 @@ struct hns_sim {
 	std::vector<std::string> names;
 	std::vector<float*> cur;  // current value of each float field (the reference's d_inputs)
 	std::vector<float*> nxt;  // scratch / next value        (the reference's d_outputs)
-	float* vel[3] = {nullptr, nullptr, nullptr};  // d_velocity
-	float* adv[3] = {nullptr, nullptr, nullptr};  // d_advectedVel
-	float* tmp[3] = {nullptr, nullptr, nullptr};  // out-of-place vorticity target
+	float* vel = nullptr;  // d_velocity      (Vec3f AoS, 3n floats: the host/reference layout, so H2D/D2H are plain copies)
+	float* adv = nullptr;  // d_advectedVel
+	float* tmp = nullptr;  // out-of-place vorticity target
 	float* div = nullptr;
 	float* p_a = nullptr;
 	float* p_b = nullptr;
 	float* p_result = nullptr;  // whichever of p_a/p_b holds the last solve
-	float* stage = nullptr;     // 3n floats, AoS staging for H2D/D2H
 	// optional hipEvent bracketing of the pressure hot loop (hns_sim_timing), on the stream the kernels run on
 	bool timing = false;
 	std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -220,15 +219,12 @@ extern "C" void hns_sim_destroy(hns_sim* s) {
 	if (!s) return;
 	for (float* p : s->cur) hipFree(p);
 	for (float* p : s->nxt) hipFree(p);
-	for (int c = 0; c < 3; ++c) {
-		hipFree(s->vel[c]);
-		hipFree(s->adv[c]);
-		hipFree(s->tmp[c]);
-	}
+	hipFree(s->vel);
+	hipFree(s->adv);
+	hipFree(s->tmp);
 	hipFree(s->div);
 	hipFree(s->p_a);
 	hipFree(s->p_b);
-	hipFree(s->stage);
 	for (hipEvent_t e : s->ev) hipEventDestroy(e);
 	delete s;
 }
@@ -260,15 +256,12 @@ extern "C" hns_sim* hns_sim_create(hns_grid* g, const char* const* float_names, 
 			HNS_TRY(sim_alloc(&s->cur.back(), s->n));
 			HNS_TRY(sim_alloc(&s->nxt.back(), s->n));
 		}
-		for (int c = 0; c < 3; ++c) {
-			HNS_TRY(sim_alloc(&s->vel[c], s->n));
-			HNS_TRY(sim_alloc(&s->adv[c], s->n));
-			HNS_TRY(sim_alloc(&s->tmp[c], s->n));
-		}
+		HNS_TRY(sim_alloc(&s->vel, 3 * s->n));
+		HNS_TRY(sim_alloc(&s->adv, 3 * s->n));
+		HNS_TRY(sim_alloc(&s->tmp, 3 * s->n));
 		HNS_TRY(sim_alloc(&s->div, s->n));
 		HNS_TRY(sim_alloc(&s->p_a, s->n));
 		HNS_TRY(sim_alloc(&s->p_b, s->n));
-		HNS_TRY(sim_alloc(&s->stage, 3 * s->n));
 		s->p_result = s->p_a;
 		return HNS_OK;
 	};
@@ -291,10 +284,7 @@ extern "C" int hns_sim_upload(hns_sim* s, const hns_field* fields, int n_fields,
 			return HNS_ERR_RUNTIME;
 		}
 		if (f.ncomp == 3) {
-			HNS_HIP(hipMemcpyAsync(s->stage, f.host, sizeof(float) * 3 * (size_t)s->n, hipMemcpyHostToDevice, st));
-			HNS_TRY(hns_dev_aos_to_soa(s->stage, s->vel[0], s->vel[1], s->vel[2], s->n, stream));
-			// the staging buffer is reused by the next Vec3f transfer: order them on the stream, and pageable host memory
-			// makes hipMemcpyAsync return only after the host buffer has been consumed
+			HNS_HIP(hipMemcpyAsync(s->vel, f.host, sizeof(float) * 3 * (size_t)s->n, hipMemcpyHostToDevice, st));
 		} else if (f.ncomp == 1) {
 			const int k = f.name ? s->find(f.name) : -1;
 			if (k < 0) {
@@ -316,9 +306,7 @@ extern "C" int hns_sim_download(hns_sim* s, hns_field* fields, int n_fields, voi
 		hns_field& f = fields[i];
 		if (!f.host) return fail(HNS_ERR_RUNTIME, "hns_sim_download: null host pointer");
 		if (f.ncomp == 3) {
-			HNS_TRY(hns_dev_soa_to_aos(s->vel[0], s->vel[1], s->vel[2], s->stage, s->n, stream));
-			HNS_HIP(hipMemcpyAsync(f.host, s->stage, sizeof(float) * 3 * (size_t)s->n, hipMemcpyDeviceToHost, st));
-			HNS_HIP(hipStreamSynchronize(st));
+			HNS_HIP(hipMemcpyAsync(f.host, s->vel, sizeof(float) * 3 * (size_t)s->n, hipMemcpyDeviceToHost, st));
 		} else if (f.ncomp == 1) {
 			const int k = f.name ? s->find(f.name) : -1;
 			if (k < 0) {
@@ -334,7 +322,7 @@ extern "C" int hns_sim_download(hns_sim* s, hns_field* fields, int n_fields, voi
 	return HNS_OK;
 }
 
-extern "C" float* hns_sim_velocity_ptr(hns_sim* s, int c) { return (s && c >= 0 && c < 3) ? s->vel[c] : nullptr; }
+extern "C" float* hns_sim_velocity_ptr(hns_sim* s) { return s ? s->vel : nullptr; }
 extern "C" float* hns_sim_field_ptr(hns_sim* s, const char* name) {
 	if (!s || !name) return nullptr;
 	const int k = s->find(name);
@@ -414,7 +402,7 @@ static int sim_advect_scalars(hns_sim* s, const float* sdf, bool coll, float dt,
 		outs.push_back(s->nxt[i]);
 		which.push_back((int)i);
 	}
-	HNS_TRY(hns_dev_advect_scalars(s->grid, s->vel[0], s->vel[1], s->vel[2], ins.data(), outs.data(), (int)ins.size(), sdf, coll, dt, inv_dx,
+	HNS_TRY(hns_dev_advect_scalars(s->grid, s->vel, ins.data(), outs.data(), (int)ins.size(), sdf, coll, dt, inv_dx,
 	                               stream));
 	for (int i : which) std::swap(s->cur[i], s->nxt[i]);
 	return HNS_OK;
@@ -441,24 +429,24 @@ extern "C" int hns_sim_substep(hns_sim* s, int iterations, float dt, float voxel
 	const float inv_dx = 1.0f / voxel_size;
 	hns_grid* g = s->grid;
 
-	if (coll) HNS_TRY(hns_dev_enforce_collision_boundaries(g, s->vel[0], s->vel[1], s->vel[2], sdf, voxel_size, stream));  // :153-157
-	HNS_TRY(hns_dev_advect_vector(g, s->vel[0], s->vel[1], s->vel[2], s->adv[0], s->adv[1], s->adv[2], sdf, coll, dt, inv_dx, stream));  // :162-170
+	if (coll) HNS_TRY(hns_dev_enforce_collision_boundaries(g, s->vel, sdf, voxel_size, stream));  // :153-157
+	HNS_TRY(hns_dev_advect_vector(g, s->vel, s->adv, sdf, coll, dt, inv_dx, stream));  // :162-170
 	if ((int)params->factorScale != 0) {  // :172-176. With (int)factorScale == 0 every vorticity-magnitude tap collapses onto the centre, the
 		// gradient is 0, N = 0/(0+1e-5) = 0 and the kernel writes u + dt*(scale*0) = u: a bit-exact copy, skipped.
-		HNS_TRY(hns_dev_vorticity_confinement(g, s->adv[0], s->adv[1], s->adv[2], s->tmp[0], s->tmp[1], s->tmp[2], dt, inv_dx,
+		HNS_TRY(hns_dev_vorticity_confinement(g, s->adv, s->tmp, dt, inv_dx,
 		                                      params->vorticityScale, params->factorScale, stream));
-		for (int c = 0; c < 3; ++c) std::swap(s->adv[c], s->tmp[c]);
+		std::swap(s->adv, s->tmp);
 	}
-	HNS_TRY(hns_dev_divergence(g, s->adv[0], s->adv[1], s->adv[2], s->div, inv_dx, stream));  // :181-188
+	HNS_TRY(hns_dev_divergence(g, s->adv, s->div, inv_dx, stream));  // :181-188
 	HNS_TRY(hns_dev_combustion_oxygen(s->cur[ci[0]], s->cur[ci[1]], s->cur[ci[2]], s->div, s->cur[ci[3]], s->nxt[ci[0]], s->nxt[ci[1]],
 	                                  s->nxt[ci[2]], s->nxt[ci[3]], params->temperatureRelease, params->expansionRate, s->n, stream));  // :211-221
-	HNS_TRY(hns_dev_temperature_buoyancy(s->adv[1], s->nxt[ci[2]], s->adv[1], dt, params->ambientTemp, params->buoyancyStrength, s->n,
+	HNS_TRY(hns_dev_temperature_buoyancy(s->adv, s->nxt[ci[2]], s->adv, dt, params->ambientTemp, params->buoyancyStrength, s->n,
 	                                     stream));  // :226-234 (temperature AFTER combustion)
 	for (int c = 0; c < 4; ++c) std::swap(s->cur[ci[c]], s->nxt[ci[c]]);  // :239-246
 	HNS_TRY(sim_pressure(s, iterations, voxel_size, omega_compute(voxel_size), stream));  // :256-272
-	HNS_TRY(hns_dev_subtract_pressure_gradient(g, s->adv[0], s->adv[1], s->adv[2], s->p_result, s->vel[0], s->vel[1], s->vel[2], sdf, coll,
+	HNS_TRY(hns_dev_subtract_pressure_gradient(g, s->adv, s->p_result, s->vel, sdf, coll,
 	                                           inv_dx, stream));  // :278-289
-	if (coll) HNS_TRY(hns_dev_enforce_collision_boundaries(g, s->vel[0], s->vel[1], s->vel[2], sdf, voxel_size, stream));  // :292-296
+	if (coll) HNS_TRY(hns_dev_enforce_collision_boundaries(g, s->vel, sdf, voxel_size, stream));  // :292-296
 	return sim_advect_scalars(s, sdf, coll, dt, inv_dx, stream);  // :321-356
 }
 
@@ -468,10 +456,10 @@ extern "C" int hns_sim_core_substep(hns_sim* s, int iterations, float dt, float 
 	if (s->n == 0) return HNS_OK;
 	const float inv_dx = 1.0f / voxel_size;
 	hns_grid* g = s->grid;
-	HNS_TRY(hns_dev_advect_vector(g, s->vel[0], s->vel[1], s->vel[2], s->adv[0], s->adv[1], s->adv[2], nullptr, 0, dt, inv_dx, stream));
-	HNS_TRY(hns_dev_divergence(g, s->adv[0], s->adv[1], s->adv[2], s->div, inv_dx, stream));
+	HNS_TRY(hns_dev_advect_vector(g, s->vel, s->adv, nullptr, 0, dt, inv_dx, stream));
+	HNS_TRY(hns_dev_divergence(g, s->adv, s->div, inv_dx, stream));
 	HNS_TRY(sim_pressure(s, iterations, voxel_size, omega_compute(voxel_size), stream));
-	HNS_TRY(hns_dev_subtract_pressure_gradient(g, s->adv[0], s->adv[1], s->adv[2], s->p_result, s->vel[0], s->vel[1], s->vel[2], nullptr, 0,
+	HNS_TRY(hns_dev_subtract_pressure_gradient(g, s->adv, s->p_result, s->vel, nullptr, 0,
 	                                           inv_dx, stream));
 	return sim_advect_scalars(s, nullptr, false, dt, inv_dx, stream);
 }
@@ -576,7 +564,7 @@ extern "C" int hns_advect_index_grid(hns_grid* g, hns_field* fields, int n_field
 	HNS_TRY(hns_sim_upload(s, fields, n_fields, stream));
 	const float inv_dx = 1.0f / voxel_size;
 	for (size_t i = 0; i < s->names.size(); ++i) {  // one advect_scalar per float block (Advection.cu:88-91)
-		HNS_TRY(hns_dev_advect_scalar(g, s->vel[0], s->vel[1], s->vel[2], s->cur[i], s->nxt[i], nullptr, 0, dt, inv_dx, stream));
+		HNS_TRY(hns_dev_advect_scalar(g, s->vel, s->cur[i], s->nxt[i], nullptr, 0, dt, inv_dx, stream));
 		std::swap(s->cur[i], s->nxt[i]);
 	}
 	std::vector<hns_field> outs;
@@ -599,8 +587,8 @@ extern "C" int hns_advect_index_grid_velocity(hns_grid* g, hns_field* fields, in
 	HNS_TRY(make_sim(g, only_vel, guard));
 	hns_sim* s = guard.s;
 	HNS_TRY(hns_sim_upload(s, fs.velocity, 1, stream));
-	HNS_TRY(hns_dev_advect_vector(g, s->vel[0], s->vel[1], s->vel[2], s->adv[0], s->adv[1], s->adv[2], nullptr, 0, dt, 1.0f / voxel_size, stream));
-	for (int c = 0; c < 3; ++c) std::swap(s->vel[c], s->adv[c]);
+	HNS_TRY(hns_dev_advect_vector(g, s->vel, s->adv, nullptr, 0, dt, 1.0f / voxel_size, stream));
+	std::swap(s->vel, s->adv);
 	return hns_sim_download(s, fs.velocity, 1, stream);
 }
 
@@ -622,9 +610,9 @@ extern "C" int hns_project_non_divergent(hns_grid* g, hns_field* fields, int n_f
 	hns_sim* s = guard.s;
 	HNS_TRY(hns_sim_upload(s, fs.velocity, 1, stream));
 	const float inv_dx = 1.0f / voxel_size;
-	HNS_TRY(hns_dev_divergence(g, s->vel[0], s->vel[1], s->vel[2], s->div, inv_dx, stream));              // :48
+	HNS_TRY(hns_dev_divergence(g, s->vel, s->div, inv_dx, stream));              // :48
 	HNS_TRY(sim_pressure(s, (int)iterations, voxel_size, omega_project(voxel_size), stream));            // :51-60 (0 iterations leaves p = 0)
-	HNS_TRY(hns_dev_subtract_pressure_gradient(g, s->vel[0], s->vel[1], s->vel[2], s->p_result, s->vel[0], s->vel[1], s->vel[2], nullptr, 0,
+	HNS_TRY(hns_dev_subtract_pressure_gradient(g, s->vel, s->p_result, s->vel, nullptr, 0,
 	                                           inv_dx, stream));  // :64, in place
 	return hns_sim_download(s, fs.velocity, 1, stream);
 }
@@ -649,7 +637,7 @@ extern "C" int hns_divergence(hns_grid* g, hns_field* fields, int n_fields, floa
 	HNS_TRY(make_sim(g, only_vel, guard));
 	hns_sim* s = guard.s;
 	HNS_TRY(hns_sim_upload(s, fs.velocity, 1, stream));
-	HNS_TRY(hns_dev_divergence(g, s->vel[0], s->vel[1], s->vel[2], s->div, 1.0f / voxel_size, stream));
+	HNS_TRY(hns_dev_divergence(g, s->vel, s->div, 1.0f / voxel_size, stream));
 	HNS_HIP(hipMemcpyAsync(out->host, s->div, sizeof(float) * (size_t)s->n, hipMemcpyDeviceToHost, (hipStream_t)stream));
 	HNS_HIP(hipStreamSynchronize((hipStream_t)stream));
 	return HNS_OK;

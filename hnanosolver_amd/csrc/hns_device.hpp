@@ -206,6 +206,36 @@ __device__ __forceinline__ float nbr_val(const float* __restrict__ f, const int*
 }
 
 
+// Vec3f element idx of an AoS velocity array (12-byte stride, exactly the reference's nanovdb::Vec3f[]): one 12-byte access
+__device__ __forceinline__ f3 ld3(const float* u, int idx) {
+	const float3 v = *reinterpret_cast<const float3*>(u + 3 * (size_t)idx);
+	f3 r = {v.x, v.y, v.z};
+	return r;
+}
+__device__ __forceinline__ f3 ld3z(const float* u, int idx) {  // zero outside the domain (IndexSampler<Vec3f,0>)
+	const f3 v = ld3(u, idx < 0 ? 0 : idx);
+	f3 r = {idx < 0 ? 0.0f : v.x, idx < 0 ? 0.0f : v.y, idx < 0 ? 0.0f : v.z};
+	return r;
+}
+__device__ __forceinline__ void st3(float* u, int idx, f3 v) { *reinterpret_cast<float3*>(u + 3 * (size_t)idx) = make_float3(v.x, v.y, v.z); }
+
+// component COMP of the velocity at the face neighbour of voxel n along AXIS (0 outside the domain)
+template <int AXIS, int DIR, int COMP>
+__device__ __forceinline__ float nbr_val3(const float* __restrict__ u, const int* s_nbr, int leaf, int n) {
+	constexpr int shift = AXIS == 0 ? 6 : (AXIS == 1 ? 3 : 0);
+	constexpr int stride = 1 << shift;
+	const int c = (n >> shift) & 7;
+	if (DIR > 0) {
+		if (c != 7) return u[3 * (size_t)(leaf * 512 + n + stride) + COMP];
+		const int nl = s_nbr[13 + (AXIS == 0 ? 9 : (AXIS == 1 ? 3 : 1))];
+		return nl < 0 ? 0.0f : u[3 * (size_t)(nl * 512 + n - 7 * stride) + COMP];
+	} else {
+		if (c != 0) return u[3 * (size_t)(leaf * 512 + n - stride) + COMP];
+		const int nl = s_nbr[13 - (AXIS == 0 ? 9 : (AXIS == 1 ? 3 : 1))];
+		return nl < 0 ? 0.0f : u[3 * (size_t)(nl * 512 + n + 7 * stride) + COMP];
+	}
+}
+
 }  // namespace hns
 
 // ---- launcher plumbing shared by the kernel files ----

@@ -1,5 +1,5 @@
 // hns_pointwise.hip -- element-wise and small-stencil side kernels of Compute_Sim (combustion, buoyancy, vorticity
-// confinement, collision), layout transposes and the leaf pack/unpack used by the halo exchange.
+// confinement, collision) and the leaf pack/unpack used by the halo exchange.
 #include <cstdlib>
 #include <cstring>
 
@@ -41,120 +41,103 @@ __global__ __launch_bounds__(256) void k_combustion_oxygen(const float* __restri
 	}
 }
 
-// temperature_buoyancy (reference Kernel.cu:831-847); x and z are vel + 0*dt == vel, so only uy is touched
-__global__ __launch_bounds__(256) void k_temperature_buoyancy(const float* uy, const float* __restrict__ temp, float* out_uy, const float dt,
+// temperature_buoyancy (reference Kernel.cu:831-847): vel + (0, max(0,(T-Tamb)*k), 0) * dt. The x and z results are
+// vel + 0*dt; they are passed through the same add so that the stored bits equal the reference's (-0 + 0 = +0).
+__global__ __launch_bounds__(256) void k_temperature_buoyancy(const float* u, const float* __restrict__ temp, float* out, const float dt,
                                                               const float ambient, const float strength, const uint64_t n) {
 	for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (uint64_t)gridDim.x * blockDim.x) {
-		const float v = uy[idx];
+		const f3 v = ld3(u, (int)idx);
 		const float t = temp[idx];
 		if (t <= ambient) {
-			out_uy[idx] = v;
+			st3(out, (int)idx, v);
 			continue;
 		}
 		const float tempDiff = t - ambient;
-		out_uy[idx] = v + dt * fmaxf(0.0f, tempDiff * strength);
+		const f3 r = {v.x + dt * 0.0f, v.y + dt * fmaxf(0.0f, tempDiff * strength), v.z + dt * 0.0f};
+		st3(out, (int)idx, r);
 	}
 }
 
-__global__ __launch_bounds__(256) void k_aos_to_soa(const float* __restrict__ aos, float* __restrict__ x, float* __restrict__ y,
-                                                    float* __restrict__ z, const uint64_t n) {
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-		x[i] = aos[3 * i];
-		y[i] = aos[3 * i + 1];
-		z[i] = aos[3 * i + 2];
-	}
-}
-
-__global__ __launch_bounds__(256) void k_soa_to_aos(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-                                                    float* __restrict__ aos, const uint64_t n) {
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-		aos[3 * i] = x[i];
-		aos[3 * i + 1] = y[i];
-		aos[3 * i + 2] = z[i];
-	}
-}
-
-// whole-leaf gather/scatter for halo exchange: one float4 per thread, 128 threads per leaf
-__global__ __launch_bounds__(128) void k_pack_leaves(const float* __restrict__ field, const int* __restrict__ ids, float* __restrict__ packed) {
+// whole-leaf gather/scatter for the halo exchange: a leaf payload is 512*ncomp floats (ncomp 1 = float field, 3 = Vec3f
+// field), moved as float4 by 128 threads
+__global__ __launch_bounds__(128) void k_pack_leaves(const float* __restrict__ field, const int* __restrict__ ids, float* __restrict__ packed,
+                                                     const int ncomp) {
 	const int l = ids[blockIdx.x];
-	reinterpret_cast<float4*>(packed + (size_t)blockIdx.x * 512)[threadIdx.x] = reinterpret_cast<const float4*>(field + (size_t)l * 512)[threadIdx.x];
+	const float4* src = reinterpret_cast<const float4*>(field + (size_t)l * 512 * ncomp);
+	float4* dst = reinterpret_cast<float4*>(packed + (size_t)blockIdx.x * 512 * ncomp);
+	for (int i = threadIdx.x; i < 128 * ncomp; i += 128) dst[i] = src[i];
 }
-__global__ __launch_bounds__(128) void k_unpack_leaves(const float* __restrict__ packed, const int* __restrict__ ids, float* __restrict__ field) {
+__global__ __launch_bounds__(128) void k_unpack_leaves(const float* __restrict__ packed, const int* __restrict__ ids, float* __restrict__ field,
+                                                       const int ncomp) {
 	const int l = ids[blockIdx.x];
-	reinterpret_cast<float4*>(field + (size_t)l * 512)[threadIdx.x] = reinterpret_cast<const float4*>(packed + (size_t)blockIdx.x * 512)[threadIdx.x];
+	const float4* src = reinterpret_cast<const float4*>(packed + (size_t)blockIdx.x * 512 * ncomp);
+	float4* dst = reinterpret_cast<float4*>(field + (size_t)l * 512 * ncomp);
+	for (int i = threadIdx.x; i < 128 * ncomp; i += 128) dst[i] = src[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // vorticityConfinement (reference Kernel.cu:970-1024 + Utils.cuh:226-243), out of place
 // ---------------------------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ f3 curl_at(const GridDev& g, const int* s_nbr, const int4 org, const float* __restrict__ ux,
-                                      const float* __restrict__ uy, const float* __restrict__ uz, int i, int j, int k, float factor) {
-	const int tpx = tap_index(g, s_nbr, org, i + 1, j, k), tmx = tap_index(g, s_nbr, org, i - 1, j, k);
-	const int tpy = tap_index(g, s_nbr, org, i, j + 1, k), tmy = tap_index(g, s_nbr, org, i, j - 1, k);
-	const int tpz = tap_index(g, s_nbr, org, i, j, k + 1), tmz = tap_index(g, s_nbr, org, i, j, k - 1);
+__device__ __forceinline__ f3 curl_at(const GridDev& g, const int* s_nbr, const int4 org, const float* __restrict__ u, int i, int j, int k,
+                                      float factor) {
+	const f3 pX = ld3z(u, tap_index(g, s_nbr, org, i + 1, j, k)), mX = ld3z(u, tap_index(g, s_nbr, org, i - 1, j, k));
+	const f3 pY = ld3z(u, tap_index(g, s_nbr, org, i, j + 1, k)), mY = ld3z(u, tap_index(g, s_nbr, org, i, j - 1, k));
+	const f3 pZ = ld3z(u, tap_index(g, s_nbr, org, i, j, k + 1)), mZ = ld3z(u, tap_index(g, s_nbr, org, i, j, k - 1));
 	f3 w;
-	w.x = ((ld0(uz, tpy) - ld0(uz, tmy)) - (ld0(uy, tpz) - ld0(uy, tmz))) * factor;
-	w.y = ((ld0(ux, tpz) - ld0(ux, tmz)) - (ld0(uz, tpx) - ld0(uz, tmx))) * factor;
-	w.z = ((ld0(uy, tpx) - ld0(uy, tmx)) - (ld0(ux, tpy) - ld0(ux, tmy))) * factor;
+	w.x = ((pY.z - mY.z) - (pZ.y - mZ.y)) * factor;
+	w.y = ((pZ.x - mZ.x) - (pX.z - mX.z)) * factor;
+	w.z = ((pX.y - mX.y) - (pY.x - mY.x)) * factor;
 	return w;
 }
 
-__device__ __forceinline__ float curl_mag(const GridDev& g, const int* s_nbr, const int4 org, const float* __restrict__ ux,
-                                          const float* __restrict__ uy, const float* __restrict__ uz, int i, int j, int k, float factor) {
-	const f3 w = curl_at(g, s_nbr, org, ux, uy, uz, i, j, k, factor);
+__device__ __forceinline__ float curl_mag(const GridDev& g, const int* s_nbr, const int4 org, const float* __restrict__ u, int i, int j, int k,
+                                          float factor) {
+	const f3 w = curl_at(g, s_nbr, org, u, i, j, k, factor);
 	return sqrtf(w.x * w.x + w.y * w.y + w.z * w.z);
 }
 
-__global__ __launch_bounds__(512) void k_vorticity(const GridDev g, const float* __restrict__ ux, const float* __restrict__ uy,
-                                                   const float* __restrict__ uz, float* __restrict__ ox, float* __restrict__ oy,
-                                                   float* __restrict__ oz, const float dt, const float inv_dx, const float scale, const int fs) {
+__global__ __launch_bounds__(512) void k_vorticity(const GridDev g, const float* __restrict__ u, float* __restrict__ out, const float dt,
+                                                   const float inv_dx, const float scale, const int fs) {
 	__shared__ int s_nbr[27];
 	const LeafCtx L = stage_leaf(g, s_nbr, blockIdx.x);
 	const int n = threadIdx.x;
 	const int idx = L.leaf * 512 + n;
 	const int ci = L.org.x + (n >> 6), cj = L.org.y + ((n >> 3) & 7), ck = L.org.z + (n & 7);
 	const float factor = 0.5f * inv_dx;
-	const f3 w = curl_at(g, s_nbr, L.org, ux, uy, uz, ci, cj, ck, factor);
-	const float m_pX = curl_mag(g, s_nbr, L.org, ux, uy, uz, ci + fs, cj, ck, factor), m_mX = curl_mag(g, s_nbr, L.org, ux, uy, uz, ci - fs, cj, ck, factor);
-	const float m_pY = curl_mag(g, s_nbr, L.org, ux, uy, uz, ci, cj + fs, ck, factor), m_mY = curl_mag(g, s_nbr, L.org, ux, uy, uz, ci, cj - fs, ck, factor);
-	const float m_pZ = curl_mag(g, s_nbr, L.org, ux, uy, uz, ci, cj, ck + fs, factor), m_mZ = curl_mag(g, s_nbr, L.org, ux, uy, uz, ci, cj, ck - fs, factor);
+	const f3 w = curl_at(g, s_nbr, L.org, u, ci, cj, ck, factor);
+	const float m_pX = curl_mag(g, s_nbr, L.org, u, ci + fs, cj, ck, factor), m_mX = curl_mag(g, s_nbr, L.org, u, ci - fs, cj, ck, factor);
+	const float m_pY = curl_mag(g, s_nbr, L.org, u, ci, cj + fs, ck, factor), m_mY = curl_mag(g, s_nbr, L.org, u, ci, cj - fs, ck, factor);
+	const float m_pZ = curl_mag(g, s_nbr, L.org, u, ci, cj, ck + fs, factor), m_mZ = curl_mag(g, s_nbr, L.org, u, ci, cj, ck - fs, factor);
 	const float grad_x = (m_pX - m_mX) * 0.5f * inv_dx;
 	const float grad_y = (m_pY - m_mY) * 0.5f * inv_dx;
 	const float grad_z = (m_pZ - m_mZ) * 0.5f * inv_dx;
 	const float gradLen = sqrtf(grad_x * grad_x + grad_y * grad_y + grad_z * grad_z) + 1e-5f;
 	const float Nx = grad_x / gradLen, Ny = grad_y / gradLen, Nz = grad_z / gradLen;
-	ox[idx] = ux[idx] + dt * (scale * (Ny * w.z - Nz * w.y));
-	oy[idx] = uy[idx] + dt * (scale * (Nz * w.x - Nx * w.z));
-	oz[idx] = uz[idx] + dt * (scale * (Nx * w.y - Ny * w.x));
+	const f3 v = ld3(u, idx);
+	const f3 r = {v.x + dt * (scale * (Ny * w.z - Nz * w.y)), v.y + dt * (scale * (Nz * w.x - Nx * w.z)), v.z + dt * (scale * (Nx * w.y - Ny * w.x))};
+	st3(out, idx, r);
 }
 
-// enforceCollisionBoundaries (reference Kernel.cu:77-116)
-__global__ __launch_bounds__(512) void k_enforce_collision(const GridDev g, float* ux, float* uy, float* uz, const float* __restrict__ sdf,
-                                                           const float inv_dx) {
+// enforceCollisionBoundaries (reference Kernel.cu:77-116), in place
+__global__ __launch_bounds__(512) void k_enforce_collision(const GridDev g, float* u, const float* __restrict__ sdf, const float inv_dx) {
 	__shared__ int s_nbr[27];
 	const LeafCtx L = stage_leaf(g, s_nbr, blockIdx.x);
 	const int n = threadIdx.x;
 	const int idx = L.leaf * 512 + n;
 	const float sv = sdf[idx];
 	if (sv < 0.0f) {
-		ux[idx] = 0.0f;
-		uy[idx] = 0.0f;
-		uz[idx] = 0.0f;
+		const f3 z = {0.0f, 0.0f, 0.0f};
+		st3(u, idx, z);
 		return;
 	}
 	const float margin = 0.1f;
 	if (sv < margin) {
 		const int ci = L.org.x + (n >> 6), cj = L.org.y + ((n >> 3) & 7), ck = L.org.z + (n & 7);
 		const f3 nrm = sdf_normal(g, s_nbr, L.org, sdf, ci, cj, ck, inv_dx);
-		const f3 v = {ux[idx], uy[idx], uz[idx]};
-		const f3 r = no_slip_blend(v, nrm, 1.0f - (sv / margin));
-		ux[idx] = r.x;
-		uy[idx] = r.y;
-		uz[idx] = r.z;
+		st3(u, idx, no_slip_blend(ld3(u, idx), nrm, 1.0f - (sv / margin)));
 	}
 }
-
 
 }  // namespace hns
 
@@ -162,19 +145,7 @@ using namespace hns;
 
 extern "C" {
 
-int hns_dev_aos_to_soa(const float* aos3, float* x, float* y, float* z, uint64_t n, void* stream) {
-	NULLCHK(!aos3 || !x || !y || !z, "hns_dev_aos_to_soa");
-	if (n == 0) return HNS_OK;
-	hipLaunchKernelGGL(k_aos_to_soa, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, aos3, x, y, z, n);
-	return launch_status("hns_dev_aos_to_soa");
-}
 
-int hns_dev_soa_to_aos(const float* x, const float* y, const float* z, float* aos3, uint64_t n, void* stream) {
-	NULLCHK(!aos3 || !x || !y || !z, "hns_dev_soa_to_aos");
-	if (n == 0) return HNS_OK;
-	hipLaunchKernelGGL(k_soa_to_aos, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, z, aos3, n);
-	return launch_status("hns_dev_soa_to_aos");
-}
 
 int hns_dev_combustion_oxygen(const float* fuel, const float* waste, const float* temperature, float* divergence, const float* flame,
                               float* out_fuel, float* out_waste, float* out_temperature, float* out_flame, float temp_gain, float expansion,
@@ -187,47 +158,48 @@ int hns_dev_combustion_oxygen(const float* fuel, const float* waste, const float
 	return launch_status("hns_dev_combustion_oxygen");
 }
 
-int hns_dev_temperature_buoyancy(const float* uy, const float* temperature, float* out_uy, float dt, float ambient, float strength, uint64_t n,
+int hns_dev_temperature_buoyancy(const float* vel3, const float* temperature, float* out3, float dt, float ambient, float strength, uint64_t n,
                                  void* stream) {
-	NULLCHK(!uy || !temperature || !out_uy, "hns_dev_temperature_buoyancy");
+	NULLCHK(!vel3 || !temperature || !out3, "hns_dev_temperature_buoyancy");
 	if (n == 0) return HNS_OK;
-	hipLaunchKernelGGL(k_temperature_buoyancy, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, uy, temperature, out_uy, dt, ambient, strength,
+	hipLaunchKernelGGL(k_temperature_buoyancy, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, vel3, temperature, out3, dt, ambient, strength,
 	                   n);
 	return launch_status("hns_dev_temperature_buoyancy");
 }
 
-int hns_dev_vorticity_confinement(hns_grid* g, const float* ux, const float* uy, const float* uz, float* ox, float* oy, float* oz, float dt,
-                                  float inv_dx, float confinement_scale, float factor_scale, void* stream) {
+int hns_dev_vorticity_confinement(hns_grid* g, const float* vel3, float* out3, float dt, float inv_dx, float confinement_scale, float factor_scale,
+                                  void* stream) {
 	if (int rc = check_grid(g, "hns_dev_vorticity_confinement")) return rc;
-	NULLCHK(!ux || !uy || !uz || !ox || !oy || !oz, "hns_dev_vorticity_confinement");
-	if (ux == ox || uy == oy || uz == oz) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dev_vorticity_confinement: output must not alias input");
+	NULLCHK(!vel3 || !out3, "hns_dev_vorticity_confinement");
+	if (vel3 == out3) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dev_vorticity_confinement: output must not alias input");
 	if (g->n_active == 0) return HNS_OK;
 	const int fs = (int)factor_scale;  // nanovdb::Coord(factorScale,0,0) truncates (Kernel.cu:998)
-	hipLaunchKernelGGL(k_vorticity, dim3((unsigned)g->n_active), dim3(512), 0, (hipStream_t)stream, g->dev(), ux, uy, uz, ox, oy, oz, dt, inv_dx,
-	                   confinement_scale, fs);
+	hipLaunchKernelGGL(k_vorticity, dim3((unsigned)g->n_active), dim3(512), 0, (hipStream_t)stream, g->dev(), vel3, out3, dt, inv_dx, confinement_scale,
+	                   fs);
 	return launch_status("hns_dev_vorticity_confinement");
 }
 
-int hns_dev_enforce_collision_boundaries(hns_grid* g, float* ux, float* uy, float* uz, const float* sdf, float voxel_size, void* stream) {
+int hns_dev_enforce_collision_boundaries(hns_grid* g, float* vel3, const float* sdf, float voxel_size, void* stream) {
 	if (int rc = check_grid(g, "hns_dev_enforce_collision_boundaries")) return rc;
-	NULLCHK(!ux || !uy || !uz, "hns_dev_enforce_collision_boundaries");
+	NULLCHK(!vel3, "hns_dev_enforce_collision_boundaries");
 	if (!sdf || g->n_active == 0) return HNS_OK;  // Kernel.cu:83
-	hipLaunchKernelGGL(k_enforce_collision, dim3((unsigned)g->n_active), dim3(512), 0, (hipStream_t)stream, g->dev(), ux, uy, uz, sdf,
-	                   1.0f / voxel_size);
+	hipLaunchKernelGGL(k_enforce_collision, dim3((unsigned)g->n_active), dim3(512), 0, (hipStream_t)stream, g->dev(), vel3, sdf, 1.0f / voxel_size);
 	return launch_status("hns_dev_enforce_collision_boundaries");
 }
 
-int hns_dev_pack_leaves(const float* field, const int32_t* leaf_ids, uint64_t n, float* packed, void* stream) {
+int hns_dev_pack_leaves(const float* field, const int32_t* leaf_ids, uint64_t n, float* packed, int ncomp, void* stream) {
 	NULLCHK((!field || !leaf_ids || !packed) && n, "hns_dev_pack_leaves");
+	if (ncomp != 1 && ncomp != 3) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dev_pack_leaves: ncomp must be 1 or 3");
 	if (n == 0) return HNS_OK;
-	hipLaunchKernelGGL(k_pack_leaves, dim3((unsigned)n), dim3(128), 0, (hipStream_t)stream, field, leaf_ids, packed);
+	hipLaunchKernelGGL(k_pack_leaves, dim3((unsigned)n), dim3(128), 0, (hipStream_t)stream, field, leaf_ids, packed, ncomp);
 	return launch_status("hns_dev_pack_leaves");
 }
 
-int hns_dev_unpack_leaves(const float* packed, const int32_t* leaf_ids, uint64_t n, float* field, void* stream) {
+int hns_dev_unpack_leaves(const float* packed, const int32_t* leaf_ids, uint64_t n, float* field, int ncomp, void* stream) {
 	NULLCHK((!field || !leaf_ids || !packed) && n, "hns_dev_unpack_leaves");
+	if (ncomp != 1 && ncomp != 3) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dev_unpack_leaves: ncomp must be 1 or 3");
 	if (n == 0) return HNS_OK;
-	hipLaunchKernelGGL(k_unpack_leaves, dim3((unsigned)n), dim3(128), 0, (hipStream_t)stream, packed, leaf_ids, field);
+	hipLaunchKernelGGL(k_unpack_leaves, dim3((unsigned)n), dim3(128), 0, (hipStream_t)stream, packed, leaf_ids, field, ncomp);
 	return launch_status("hns_dev_unpack_leaves");
 }
 

@@ -9,7 +9,7 @@
 //   * no per-voxel coordinate stream: a voxel's coordinate is leaf origin + thread id (saves 12 B/voxel/kernel);
 //   * no NanoVDB tree walk: a tap resolves its leaf through the 27-entry neighbour table of the workgroup's leaf
 //     (staged in LDS) or, beyond one leaf away, an origin hash;
-//   * velocity is planar (ux, uy, uz) on the device, so every component is a leaf-dense float field and every
+//   * velocity is Vec3f AoS on the device (the host layout): one 12-byte access per tap, and every
 //     2 KB leaf payload is one fully coalesced run;
 //   * the red-black SOR loop runs ONE launch per iteration: the workgroup stages its leaf plus a two-voxel halo of
 //     p in LDS, recomputes the red updates of the face-adjacent halo voxels itself (bit-identical to what the
@@ -26,22 +26,20 @@ namespace hns {
 // divergence (reference Kernel.cu:499-519 and :455-496)
 // ---------------------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(512) void k_divergence(const GridDev g, const float* __restrict__ ux, const float* __restrict__ uy,
-                                                    const float* __restrict__ uz, float* __restrict__ div, const float inv_dx) {
+__global__ __launch_bounds__(512) void k_divergence(const GridDev g, const float* __restrict__ u, float* __restrict__ div, const float inv_dx) {
 	__shared__ int s_nbr[27];
 	const LeafCtx L = stage_leaf(g, s_nbr, blockIdx.x);
 	const int n = threadIdx.x;
 	const int idx = L.leaf * 512 + n;
-	const float cx = ux[idx], cy = uy[idx], cz = uz[idx];
-	const float xp = (cx + nbr_val<0, 1>(ux, s_nbr, L.leaf, n)) * 0.5f;
-	const float xm = (cx + nbr_val<0, -1>(ux, s_nbr, L.leaf, n)) * 0.5f;
-	const float yp = (cy + nbr_val<1, 1>(uy, s_nbr, L.leaf, n)) * 0.5f;
-	const float ym = (cy + nbr_val<1, -1>(uy, s_nbr, L.leaf, n)) * 0.5f;
-	const float zp = (cz + nbr_val<2, 1>(uz, s_nbr, L.leaf, n)) * 0.5f;
-	const float zm = (cz + nbr_val<2, -1>(uz, s_nbr, L.leaf, n)) * 0.5f;
+	const f3 c = ld3(u, idx);
+	const float xp = (c.x + nbr_val3<0, 1, 0>(u, s_nbr, L.leaf, n)) * 0.5f;
+	const float xm = (c.x + nbr_val3<0, -1, 0>(u, s_nbr, L.leaf, n)) * 0.5f;
+	const float yp = (c.y + nbr_val3<1, 1, 1>(u, s_nbr, L.leaf, n)) * 0.5f;
+	const float ym = (c.y + nbr_val3<1, -1, 1>(u, s_nbr, L.leaf, n)) * 0.5f;
+	const float zp = (c.z + nbr_val3<2, 1, 2>(u, s_nbr, L.leaf, n)) * 0.5f;
+	const float zm = (c.z + nbr_val3<2, -1, 2>(u, s_nbr, L.leaf, n)) * 0.5f;
 	div[idx] = (xp - xm + yp - ym + zp - zm) * inv_dx;
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // red-black SOR, two-launch form: one colour in place (reference Kernel.cu:591-623 / :521-588)
@@ -615,9 +613,8 @@ __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs,
 // ---------------------------------------------------------------------------------------------------------------
 
 template <bool COLL>
-__global__ __launch_bounds__(512) void k_subtract_gradient(const GridDev g, const float* __restrict__ ux, const float* __restrict__ uy,
-                                                           const float* __restrict__ uz, const float* __restrict__ p, float* ox, float* oy,
-                                                           float* oz, const float* __restrict__ sdf, const float inv_dx) {
+__global__ __launch_bounds__(512) void k_subtract_gradient(const GridDev g, const float* u, const float* __restrict__ p, float* out,
+                                                           const float* __restrict__ sdf, const float inv_dx) {
 	__shared__ int s_nbr[27];
 	const LeafCtx L = stage_leaf(g, s_nbr, blockIdx.x);
 	const int n = threadIdx.x;
@@ -625,22 +622,20 @@ __global__ __launch_bounds__(512) void k_subtract_gradient(const GridDev g, cons
 	const float gx = ((nbr_val<0, 1>(p, s_nbr, L.leaf, n) - nbr_val<0, -1>(p, s_nbr, L.leaf, n)) * 0.5f) * inv_dx;
 	const float gy = ((nbr_val<1, 1>(p, s_nbr, L.leaf, n) - nbr_val<1, -1>(p, s_nbr, L.leaf, n)) * 0.5f) * inv_dx;
 	const float gz = ((nbr_val<2, 1>(p, s_nbr, L.leaf, n) - nbr_val<2, -1>(p, s_nbr, L.leaf, n)) * 0.5f) * inv_dx;
-	f3 u = {ux[idx] - gx, uy[idx] - gy, uz[idx] - gz};
+	const f3 us = ld3(u, idx);  // `out` may alias `u`: each voxel reads only its own velocity (PressureProjection.cu:64)
+	f3 r = {us.x - gx, us.y - gy, us.z - gz};
 	if (COLL) {  // Kernel.cu:809-826
 		const float sv = sdf[idx];
 		if (sv < 0.0f) {
-			u.x = u.y = u.z = 0.0f;
+			r.x = r.y = r.z = 0.0f;
 		} else if (sv < 0.1f) {
 			const int ci = L.org.x + (n >> 6), cj = L.org.y + ((n >> 3) & 7), ck = L.org.z + (n & 7);
 			const f3 nrm = sdf_normal(g, s_nbr, L.org, sdf, ci, cj, ck, inv_dx);
-			u = no_slip_blend(u, nrm, 1.0f - (sv / 0.1f));
+			r = no_slip_blend(r, nrm, 1.0f - (sv / 0.1f));
 		}
 	}
-	ox[idx] = u.x;
-	oy[idx] = u.y;
-	oz[idx] = u.z;
+	st3(out, idx, r);
 }
-
 
 }  // namespace hns
 
@@ -648,11 +643,11 @@ using namespace hns;
 
 extern "C" {
 
-int hns_dev_divergence(hns_grid* g, const float* ux, const float* uy, const float* uz, float* div, float inv_dx, void* stream) {
+int hns_dev_divergence(hns_grid* g, const float* vel3, float* div, float inv_dx, void* stream) {
 	if (int rc = check_grid(g, "hns_dev_divergence")) return rc;
-	NULLCHK(!ux || !uy || !uz || !div, "hns_dev_divergence");
+	NULLCHK(!vel3 || !div, "hns_dev_divergence");
 	if (g->n_active == 0) return HNS_OK;
-	hipLaunchKernelGGL(k_divergence, dim3((unsigned)g->n_active), dim3(512), 0, (hipStream_t)stream, g->dev(), ux, uy, uz, div, inv_dx);
+	hipLaunchKernelGGL(k_divergence, dim3((unsigned)g->n_active), dim3(512), 0, (hipStream_t)stream, g->dev(), vel3, div, inv_dx);
 	return launch_status("hns_dev_divergence");
 }
 
@@ -726,16 +721,16 @@ int hns_dev_time_rbgs(hns_grid* g, const float* div, float* p_a, float* p_b, flo
 	return rc;
 }
 
-int hns_dev_subtract_pressure_gradient(hns_grid* g, const float* ux, const float* uy, const float* uz, const float* p, float* ox, float* oy,
-                                       float* oz, const float* sdf, int has_collision, float inv_dx, void* stream) {
+int hns_dev_subtract_pressure_gradient(hns_grid* g, const float* vel3, const float* p, float* out3, const float* sdf, int has_collision, float inv_dx,
+                                       void* stream) {
 	if (int rc = check_grid(g, "hns_dev_subtract_pressure_gradient")) return rc;
-	NULLCHK(!ux || !uy || !uz || !p || !ox || !oy || !oz, "hns_dev_subtract_pressure_gradient");
+	NULLCHK(!vel3 || !p || !out3, "hns_dev_subtract_pressure_gradient");
 	if (g->n_active == 0) return HNS_OK;
 	const dim3 grid((unsigned)g->n_active), block(512);
 	if (has_collision && sdf)
-		hipLaunchKernelGGL(k_subtract_gradient<true>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, p, ox, oy, oz, sdf, inv_dx);
+		hipLaunchKernelGGL(k_subtract_gradient<true>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, p, out3, sdf, inv_dx);
 	else
-		hipLaunchKernelGGL(k_subtract_gradient<false>, grid, block, 0, (hipStream_t)stream, g->dev(), ux, uy, uz, p, ox, oy, oz, sdf, inv_dx);
+		hipLaunchKernelGGL(k_subtract_gradient<false>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, p, out3, sdf, inv_dx);
 	return launch_status("hns_dev_subtract_pressure_gradient");
 }
 

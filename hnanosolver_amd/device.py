@@ -1,8 +1,8 @@
 """Kernel-level calls of libhns.so on device-resident torch tensors.
 
 PyTorch is plumbing here: it owns device memory and streams; every computation is a HIP kernel of libhns.so reached
-through the C ABI (``hns_dev_*`` / ``hns_sim_*`` in include/hns.h). Velocity is planar on the device: ``(3, N)``
-float32 tensors whose rows are ux, uy, uz. There is no CPU path: tensors must live on a HIP device.
+through the C ABI (``hns_dev_*`` / ``hns_sim_*`` in include/hns.h). Velocity tensors are ``(N, 3)`` float32 (Vec3f AoS, the
+host layout). There is no CPU path: tensors must live on a HIP device.
 """
 from __future__ import annotations
 
@@ -38,32 +38,13 @@ def current_stream() -> int:
     return int(_torch().cuda.current_stream().cuda_stream)
 
 
-def to_planar(vel_aos):
-    """(N,3) AoS device tensor -> (3,N) planar, through the library's own transpose kernel."""
-    torch = _torch()
-    n = vel_aos.shape[0]
-    out = torch.empty((3, n), dtype=torch.float32, device=vel_aos.device)
-    _raise(lib.hns_dev_aos_to_soa(_ptr(vel_aos), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), n, current_stream()))
-    return out
-
-
-def to_aos(vel_planar):
-    torch = _torch()
-    n = vel_planar.shape[1]
-    out = torch.empty((n, 3), dtype=torch.float32, device=vel_planar.device)
-    _raise(lib.hns_dev_soa_to_aos(_ptr(vel_planar[0]), _ptr(vel_planar[1]), _ptr(vel_planar[2]), _ptr(out), n, current_stream()))
-    return out
-
-
 def advect_vector(grid: IndexGridHandle, u, out, dt: float, inv_dx: float, sdf=None, has_collision: bool = False):
-    _raise(lib.hns_dev_advect_vector(grid.ptr, _ptr(u[0]), _ptr(u[1]), _ptr(u[2]), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(sdf),
-                                     int(has_collision), dt, inv_dx, current_stream()))
+    _raise(lib.hns_dev_advect_vector(grid.ptr, _ptr(u), _ptr(out), _ptr(sdf), int(has_collision), dt, inv_dx, current_stream()))
     return out
 
 
 def advect_scalar(grid: IndexGridHandle, u, src, dst, dt: float, inv_dx: float, sdf=None, has_collision: bool = False):
-    _raise(lib.hns_dev_advect_scalar(grid.ptr, _ptr(u[0]), _ptr(u[1]), _ptr(u[2]), _ptr(src), _ptr(dst), _ptr(sdf), int(has_collision), dt, inv_dx,
-                                     current_stream()))
+    _raise(lib.hns_dev_advect_scalar(grid.ptr, _ptr(u), _ptr(src), _ptr(dst), _ptr(sdf), int(has_collision), dt, inv_dx, current_stream()))
     return dst
 
 
@@ -71,13 +52,12 @@ def advect_scalars(grid: IndexGridHandle, u, srcs: Sequence, dsts: Sequence, dt:
     n = len(srcs)
     ins = (C.c_void_p * max(1, n))(*[_ptr(t) for t in srcs])
     outs = (C.c_void_p * max(1, n))(*[_ptr(t) for t in dsts])
-    _raise(lib.hns_dev_advect_scalars(grid.ptr, _ptr(u[0]), _ptr(u[1]), _ptr(u[2]), ins, outs, n, _ptr(sdf), int(has_collision), dt, inv_dx,
-                                      current_stream()))
+    _raise(lib.hns_dev_advect_scalars(grid.ptr, _ptr(u), ins, outs, n, _ptr(sdf), int(has_collision), dt, inv_dx, current_stream()))
     return dsts
 
 
 def divergence(grid: IndexGridHandle, u, div, inv_dx: float):
-    _raise(lib.hns_dev_divergence(grid.ptr, _ptr(u[0]), _ptr(u[1]), _ptr(u[2]), _ptr(div), inv_dx, current_stream()))
+    _raise(lib.hns_dev_divergence(grid.ptr, _ptr(u), _ptr(div), inv_dx, current_stream()))
     return div
 
 
@@ -101,8 +81,7 @@ def time_rbgs(grid: IndexGridHandle, div, p_a, p_b, dx: float, omega: float, ite
 
 
 def subtract_pressure_gradient(grid: IndexGridHandle, u, p, out, inv_dx: float, sdf=None, has_collision: bool = False):
-    _raise(lib.hns_dev_subtract_pressure_gradient(grid.ptr, _ptr(u[0]), _ptr(u[1]), _ptr(u[2]), _ptr(p), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
-                                                  _ptr(sdf), int(has_collision), inv_dx, current_stream()))
+    _raise(lib.hns_dev_subtract_pressure_gradient(grid.ptr, _ptr(u), _ptr(p), _ptr(out), _ptr(sdf), int(has_collision), inv_dx, current_stream()))
     return out
 
 
@@ -111,28 +90,28 @@ def combustion_oxygen(fuel, waste, temperature, div, flame, out_fuel, out_waste,
                                          _ptr(out_temperature), _ptr(out_flame), temp_gain, expansion, fuel.numel(), current_stream()))
 
 
-def temperature_buoyancy(uy, temperature, out_uy, dt: float, ambient: float, strength: float):
-    _raise(lib.hns_dev_temperature_buoyancy(_ptr(uy), _ptr(temperature), _ptr(out_uy), dt, ambient, strength, uy.numel(), current_stream()))
+def temperature_buoyancy(u, temperature, out, dt: float, ambient: float, strength: float):
+    _raise(lib.hns_dev_temperature_buoyancy(_ptr(u), _ptr(temperature), _ptr(out), dt, ambient, strength, temperature.numel(), current_stream()))
+    return out
 
 
 def vorticity_confinement(grid: IndexGridHandle, u, out, dt: float, inv_dx: float, scale: float, factor_scale: float):
-    _raise(lib.hns_dev_vorticity_confinement(grid.ptr, _ptr(u[0]), _ptr(u[1]), _ptr(u[2]), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), dt, inv_dx, scale,
-                                             factor_scale, current_stream()))
+    _raise(lib.hns_dev_vorticity_confinement(grid.ptr, _ptr(u), _ptr(out), dt, inv_dx, scale, factor_scale, current_stream()))
     return out
 
 
 def enforce_collision_boundaries(grid: IndexGridHandle, u, sdf, voxel_size: float):
-    _raise(lib.hns_dev_enforce_collision_boundaries(grid.ptr, _ptr(u[0]), _ptr(u[1]), _ptr(u[2]), _ptr(sdf), voxel_size, current_stream()))
+    _raise(lib.hns_dev_enforce_collision_boundaries(grid.ptr, _ptr(u), _ptr(sdf), voxel_size, current_stream()))
     return u
 
 
-def pack_leaves(field, leaf_ids, packed):
-    _raise(lib.hns_dev_pack_leaves(_ptr(field), _ptr(leaf_ids), leaf_ids.numel(), _ptr(packed), current_stream()))
+def pack_leaves(field, leaf_ids, packed, ncomp: int = 1):
+    _raise(lib.hns_dev_pack_leaves(_ptr(field), _ptr(leaf_ids), leaf_ids.numel(), _ptr(packed), ncomp, current_stream()))
     return packed
 
 
-def unpack_leaves(packed, leaf_ids, field):
-    _raise(lib.hns_dev_unpack_leaves(_ptr(packed), _ptr(leaf_ids), leaf_ids.numel(), _ptr(field), current_stream()))
+def unpack_leaves(packed, leaf_ids, field, ncomp: int = 1):
+    _raise(lib.hns_dev_unpack_leaves(_ptr(packed), _ptr(leaf_ids), leaf_ids.numel(), _ptr(field), ncomp, current_stream()))
     return field
 
 

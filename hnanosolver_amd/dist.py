@@ -175,8 +175,8 @@ class HipEngine:
     def ids(self, a: np.ndarray):
         return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
 
-    def pack(self, fld, ids, out):
-        return self.D.pack_leaves(fld, ids, out)
+    def pack(self, fld, ids, out, ncomp):
+        return self.D.pack_leaves(fld, ids, out, ncomp)
 
     def advect_vector(self, u, out, dt, inv_dx):
         self.D.advect_vector(self.grid, u, out, dt, inv_dx)
@@ -213,44 +213,53 @@ class HaloExchanger:
         self.send_ids = {q: engine.ids(ids) for q, ids in plan.send_local.items()}
         self._bufs: Dict[Tuple[int, int], Tuple[object, object]] = {}
 
-    def _buffers(self, q: int, nf: int):
-        key = (q, nf)
+    def _ncomp(self, f) -> int:
+        return int(f.numel()) // (self.plan.n_local * LEAF_VOXELS)  # 1 = float field, 3 = Vec3f field
+
+    def _buffers(self, q: int, units: int):
+        key = (q, units)
         if key not in self._bufs:
             ns = len(self.plan.send_local.get(q, ()))
             r0, r1 = self.plan.recv_ranges.get(q, (0, 0))
-            self._bufs[key] = (self.engine.zeros(max(1, nf * ns * LEAF_VOXELS)), self.engine.zeros(max(1, nf * (r1 - r0) * LEAF_VOXELS)))
+            self._bufs[key] = (self.engine.zeros(max(1, units * ns * LEAF_VOXELS)), self.engine.zeros(max(1, units * (r1 - r0) * LEAF_VOXELS)))
         return self._bufs[key]
 
     def pack_sends(self, fields: Sequence) -> Dict[int, object]:
         """Gather, per peer, the owned leaves it mirrors (all `fields` back to back) into that peer's send buffer."""
-        nf, out = len(fields), {}
+        comps = [self._ncomp(f) for f in fields]
+        units, out = sum(comps), {}
         for q, ids in self.send_ids.items():
-            sb, _ = self._buffers(q, nf)
-            ns = len(self.plan.send_local[q])
-            for k, f in enumerate(fields):
-                self.engine.pack(f, ids, sb[k * ns * LEAF_VOXELS:(k + 1) * ns * LEAF_VOXELS])
-            out[q] = sb[: nf * ns * LEAF_VOXELS]
+            sb, _ = self._buffers(q, units)
+            ns, pos = len(self.plan.send_local[q]), 0
+            for f, c in zip(fields, comps):
+                self.engine.pack(f, ids, sb[pos:pos + c * ns * LEAF_VOXELS], c)
+                pos += c * ns * LEAF_VOXELS
+            out[q] = sb[:pos]
         return out
 
     def recv_targets(self, fields: Sequence) -> Dict[int, object]:
         """Per peer, the tensor its message lands in: the ghost range itself for one field (ghosts of a peer are
         contiguous), a staging buffer for several."""
-        nf, out = len(fields), {}
+        comps = [self._ncomp(f) for f in fields]
+        units, out = sum(comps), {}
         for q, (r0, r1) in self.plan.recv_ranges.items():
-            if nf == 1:
-                out[q] = fields[0][r0 * LEAF_VOXELS:r1 * LEAF_VOXELS]
+            if len(fields) == 1:
+                c = comps[0]
+                out[q] = fields[0].view(-1)[r0 * c * LEAF_VOXELS:r1 * c * LEAF_VOXELS]
             else:
-                out[q] = self._buffers(q, nf)[1][: nf * (r1 - r0) * LEAF_VOXELS]
+                out[q] = self._buffers(q, units)[1][: units * (r1 - r0) * LEAF_VOXELS]
         return out
 
     def finish(self, fields: Sequence) -> None:
-        nf = len(fields)
-        if nf == 1:
+        if len(fields) == 1:
             return
+        comps = [self._ncomp(f) for f in fields]
+        units = sum(comps)
         for q, (r0, r1) in self.plan.recv_ranges.items():
-            rb, nr = self._buffers(q, nf)[1], r1 - r0
-            for k, f in enumerate(fields):
-                f[r0 * LEAF_VOXELS:r1 * LEAF_VOXELS].copy_(rb[k * nr * LEAF_VOXELS:(k + 1) * nr * LEAF_VOXELS])
+            rb, nr, pos = self._buffers(q, units)[1], r1 - r0, 0
+            for f, c in zip(fields, comps):
+                f.view(-1)[r0 * c * LEAF_VOXELS:r1 * c * LEAF_VOXELS].copy_(rb[pos:pos + c * nr * LEAF_VOXELS])
+                pos += c * nr * LEAF_VOXELS
 
     def exchange(self, fields: Sequence) -> None:
         """Refresh the ghost leaves of every tensor in `fields` (one message per peer carrying all of them)."""
@@ -279,14 +288,14 @@ def omega_compute(voxel_size: float) -> float:
 class DistributedSolver:
     """Core substep (advect_vector -> divergence -> RB-SOR -> projection -> advect_scalars) on one rank's leaves.
 
-    State tensors are flat over LOCAL leaves (owned then ghosts); velocity is three planar components."""
+    State tensors are flat over LOCAL leaves (owned then ghosts); velocity is (n_local*512, 3) Vec3f AoS."""
 
     def __init__(self, plan: RankPlan, engine, voxel_size: float, n_scalars: int = 1, group=None):
         self.plan, self.e, self.vs = plan, engine, float(np.float32(voxel_size))
         self.inv_dx = float(np.float32(1.0) / np.float32(voxel_size))
         n = plan.n_local * LEAF_VOXELS
-        self.u = [engine.zeros(n) for _ in range(3)]
-        self.adv = [engine.zeros(n) for _ in range(3)]
+        self.u = engine.zeros(3 * n).view(-1, 3)
+        self.adv = engine.zeros(3 * n).view(-1, 3)
         self.div, self.p_a, self.p_b = engine.zeros(n), engine.zeros(n), engine.zeros(n)
         self.phi = [engine.zeros(n) for _ in range(n_scalars)]
         self.phi_next = [engine.zeros(n) for _ in range(n_scalars)]
@@ -297,8 +306,7 @@ class DistributedSolver:
 
     def load_local(self, vel_aos: np.ndarray, scalars: Sequence[np.ndarray]) -> None:
         """Initial data for the LOCAL leaves (owned + ghosts), velocity as (n_local*512, 3) AoS."""
-        for c in range(3):
-            self.u[c].copy_(self.e.from_numpy(vel_aos[:, c]))
+        self.u.copy_(self.e.from_numpy(vel_aos).view(-1, 3))
         for k, s in enumerate(scalars):
             self.phi[k].copy_(self.e.from_numpy(s))
 
@@ -314,14 +322,14 @@ class DistributedSolver:
 
     def core_substep(self, iterations: int, dt: float) -> None:
         e, h = self.e, self.halo
-        h.exchange(self.u + self.phi)
+        h.exchange([self.u] + self.phi)
         e.advect_vector(self.u, self.adv, dt, self.inv_dx)
-        h.exchange(self.adv)
+        h.exchange([self.adv])
         e.divergence(self.adv, self.div, self.inv_dx)
         h.exchange([self.div])
         self.pressure_solve(iterations)
         e.subtract_pressure_gradient(self.adv, self.p, self.u, self.inv_dx)
-        h.exchange(self.u)
+        h.exchange([self.u])
         e.advect_scalars(self.u, self.phi, self.phi_next, dt, self.inv_dx)
         self.phi, self.phi_next = self.phi_next, self.phi
 
@@ -373,9 +381,9 @@ class SlabBench:
             return
         # same as DistributedSolver.core_substep with the pressure loop bracketed by events on the launch stream
         e, h = s.e, s.halo
-        h.exchange(s.u + s.phi)
+        h.exchange([s.u] + s.phi)
         e.advect_vector(s.u, s.adv, self.dt, s.inv_dx)
-        h.exchange(s.adv)
+        h.exchange([s.adv])
         e.divergence(s.adv, s.div, s.inv_dx)
         h.exchange([s.div])
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -385,7 +393,7 @@ class SlabBench:
         self._ev.append((a, b))
         self._launches += self.iterations
         e.subtract_pressure_gradient(s.adv, s.p, s.u, s.inv_dx)
-        h.exchange(s.u)
+        h.exchange([s.u])
         e.advect_scalars(s.u, s.phi, s.phi_next, self.dt, s.inv_dx)
         s.phi, s.phi_next = s.phi_next, s.phi
 

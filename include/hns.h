@@ -137,31 +137,27 @@ int hns_sim_pressure_solve(hns_sim*, int iterations, float voxel_size, void* str
  * number of fused-iteration launches they contained. hns_sim_timing(sim, 0) switches it off. */
 int hns_sim_timing(hns_sim*, int max_solves);
 int hns_sim_pressure_time(hns_sim*, float* total_ms, long long* launches);
-/* Raw device pointers of the sim's buffers (ux,uy,uz planar velocity, float fields, divergence, pressure). */
-float* hns_sim_velocity_ptr(hns_sim*, int component);
+/* Raw device pointers of the sim's buffers (Vec3f AoS velocity, float fields, divergence, pressure). */
+float* hns_sim_velocity_ptr(hns_sim*);
 float* hns_sim_field_ptr(hns_sim*, const char* name);
 float* hns_sim_divergence_ptr(hns_sim*);
 float* hns_sim_pressure_ptr(hns_sim*);
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Kernel-level entry points on caller-owned DEVICE memory (asynchronous on `stream`).                           */
-/* Velocity is planar on the device: three float arrays (ux, uy, uz), each leaf-dense like a float field.        */
+/* Velocity fields are Vec3f AoS on the device too (3 floats per voxel, `vel3`), exactly the host/reference layout.  */
 /* ------------------------------------------------------------------------------------------------------------ */
 
-int hns_dev_aos_to_soa(const float* aos3, float* x, float* y, float* z, uint64_t n, void* stream);
-int hns_dev_soa_to_aos(const float* x, const float* y, const float* z, float* aos3, uint64_t n, void* stream);
-
-/* advect_vector (Kernel.cu:354-453) */
-int hns_dev_advect_vector(hns_grid*, const float* ux, const float* uy, const float* uz, float* ox, float* oy, float* oz, const float* sdf,
-                          int has_collision, float dt, float inv_dx, void* stream);
+/* advect_vector (Kernel.cu:354-453); out3 must not alias vel3 */
+int hns_dev_advect_vector(hns_grid*, const float* vel3, float* out3, const float* sdf, int has_collision, float dt, float inv_dx, void* stream);
 /* advect_scalar (Kernel.cu:269-352) */
-int hns_dev_advect_scalar(hns_grid*, const float* ux, const float* uy, const float* uz, const float* in, float* out, const float* sdf,
-                          int has_collision, float dt, float inv_dx, void* stream);
+int hns_dev_advect_scalar(hns_grid*, const float* vel3, const float* in, float* out, const float* sdf, int has_collision, float dt, float inv_dx,
+                          void* stream);
 /* advect_scalars (Kernel.cu:118-266); in/out are HOST arrays of n device pointers */
-int hns_dev_advect_scalars(hns_grid*, const float* ux, const float* uy, const float* uz, const float* const* in, float* const* out, int n,
-                           const float* sdf, int has_collision, float dt, float inv_dx, void* stream);
+int hns_dev_advect_scalars(hns_grid*, const float* vel3, const float* const* in, float* const* out, int n, const float* sdf, int has_collision,
+                           float dt, float inv_dx, void* stream);
 /* divergence / divergence_opt (Kernel.cu:455-519) */
-int hns_dev_divergence(hns_grid*, const float* ux, const float* uy, const float* uz, float* div, float inv_dx, void* stream);
+int hns_dev_divergence(hns_grid*, const float* vel3, float* div, float inv_dx, void* stream);
 /* One colour of redBlackGaussSeidelUpdate(_opt) in place (Kernel.cu:521-623): the two-launch form. */
 int hns_dev_rbgs_color(hns_grid*, const float* div, float* p, float dx, float omega, int color, void* stream);
 /* `iterations` full (red, black) iterations with one fused launch per iteration, ping-ponging p_a -> p_b -> p_a ...
@@ -169,26 +165,26 @@ int hns_dev_rbgs_color(hns_grid*, const float* div, float* p, float dx, float om
  * (*result_in_b tells). p_a and p_b must not alias. */
 int hns_dev_rbgs_iterate(hns_grid*, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int* result_in_b,
                          void* stream);
-/* subtractPressureGradient(_opt) (Kernel.cu:694-829); out may alias u (each voxel reads only its own u) */
-int hns_dev_subtract_pressure_gradient(hns_grid*, const float* ux, const float* uy, const float* uz, const float* p, float* ox, float* oy,
-                                       float* oz, const float* sdf, int has_collision, float inv_dx, void* stream);
+/* subtractPressureGradient(_opt) (Kernel.cu:694-829); out3 may alias vel3 (each voxel reads only its own velocity) */
+int hns_dev_subtract_pressure_gradient(hns_grid*, const float* vel3, const float* p, float* out3, const float* sdf, int has_collision, float inv_dx,
+                                       void* stream);
 /* combustion_oxygen (Kernel.cu:923-966) */
 int hns_dev_combustion_oxygen(const float* fuel, const float* waste, const float* temperature, float* divergence, const float* flame,
                               float* out_fuel, float* out_waste, float* out_temperature, float* out_flame, float temp_gain, float expansion,
                               uint64_t n, void* stream);
-/* temperature_buoyancy (Kernel.cu:831-847): only the y component changes */
-int hns_dev_temperature_buoyancy(const float* uy, const float* temperature, float* out_uy, float dt, float ambient, float strength, uint64_t n,
+/* temperature_buoyancy (Kernel.cu:831-847); out3 may alias vel3 */
+int hns_dev_temperature_buoyancy(const float* vel3, const float* temperature, float* out3, float dt, float ambient, float strength, uint64_t n,
                                  void* stream);
 /* vorticityConfinement (Kernel.cu:970-1024), out-of-place (the reference's in-place launch races when factor_scale >= 1) */
-int hns_dev_vorticity_confinement(hns_grid*, const float* ux, const float* uy, const float* uz, float* ox, float* oy, float* oz, float dt,
-                                  float inv_dx, float confinement_scale, float factor_scale, void* stream);
+int hns_dev_vorticity_confinement(hns_grid*, const float* vel3, float* out3, float dt, float inv_dx, float confinement_scale, float factor_scale,
+                                  void* stream);
 /* enforceCollisionBoundaries (Kernel.cu:77-116), in place */
-int hns_dev_enforce_collision_boundaries(hns_grid*, float* ux, float* uy, float* uz, const float* sdf, float voxel_size, void* stream);
+int hns_dev_enforce_collision_boundaries(hns_grid*, float* vel3, const float* sdf, float voxel_size, void* stream);
 
-/* Halo support for leaf-partitioned multi-GPU runs: copy whole leaves (512 floats each) between a field and a packed
- * buffer. leaf_ids is a DEVICE array of n leaf indices. */
-int hns_dev_pack_leaves(const float* field, const int32_t* leaf_ids, uint64_t n, float* packed, void* stream);
-int hns_dev_unpack_leaves(const float* packed, const int32_t* leaf_ids, uint64_t n, float* field, void* stream);
+/* Halo support for leaf-partitioned multi-GPU runs: copy whole leaves (512*ncomp floats each; ncomp 1 = float field,
+ * 3 = Vec3f field) between a field and a packed buffer. leaf_ids is a DEVICE array of n leaf indices. */
+int hns_dev_pack_leaves(const float* field, const int32_t* leaf_ids, uint64_t n, float* packed, int ncomp, void* stream);
+int hns_dev_unpack_leaves(const float* packed, const int32_t* leaf_ids, uint64_t n, float* field, int ncomp, void* stream);
 
 /* Timing helper: runs `iterations` fused RB-SOR iterations `reps` times on `stream`, bracketing each launch group with
  * hipEvents on that stream, and returns the mean milliseconds per fused-iteration launch. */

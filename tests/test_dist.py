@@ -88,20 +88,18 @@ class OracleEngine:
     def ids(self, a):
         return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64))
 
-    def pack(self, fld, ids, out):
-        out.copy_(fld.view(-1, 512)[ids].reshape(-1))
+    def pack(self, fld, ids, out, ncomp):
+        out.copy_(fld.reshape(-1, 512 * ncomp)[ids].reshape(-1))
         return out
 
     def _aos(self, u):
-        return np.ascontiguousarray(np.stack([c.numpy() for c in u], axis=1))
+        return np.ascontiguousarray(u.numpy().reshape(-1, 3))
 
     def _put(self, dst, src_np):  # only owned leaves are written, like the HIP kernels (n_active)
         dst[: self.no].copy_(self.torch.from_numpy(np.ascontiguousarray(src_np))[: self.no])
 
     def advect_vector(self, u, out, dt, inv_dx):
-        r = self.G.advect_vector(self._aos(u), dt, inv_dx)
-        for c in range(3):
-            self._put(out[c], r[:, c])
+        self._put(out, self.G.advect_vector(self._aos(u), dt, inv_dx))
 
     def advect_scalars(self, u, srcs, dsts, dt, inv_dx):
         r = self.G.advect_scalars(self._aos(u), [s.numpy() for s in srcs], dt, inv_dx)
@@ -118,9 +116,7 @@ class OracleEngine:
         self._put(p_out, p)
 
     def subtract_pressure_gradient(self, u, p, out, inv_dx):
-        r = self.G.subtract_pressure_gradient(self._aos(u), p.numpy(), inv_dx)
-        for c in range(3):
-            self._put(out[c], r[:, c])
+        self._put(out, self.G.subtract_pressure_gradient(self._aos(u), p.numpy(), inv_dx))
 
     def synchronize(self):
         pass
@@ -160,7 +156,7 @@ def _worker(rank, world, port, name, iters, out_dir):
         for _ in range(2):
             sol.core_substep(iters, 1.0 / 24.0)
         no = plan.n_owned * 512
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), owned=plan.owned_global, u=np.stack([c[:no].numpy() for c in sol.u], 1),
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), owned=plan.owned_global, u=sol.u[:no].numpy(),
                  phi0=sol.phi[0][:no].numpy(), phi1=sol.phi[1][:no].numpy(), p=sol.p[:no].numpy())
     finally:
         dist.destroy_process_group()

@@ -57,10 +57,10 @@ def test_emulated_ranks_match_single_grid(name, world):
         solvers.append(sol)
 
     for _ in range(2):  # DistributedSolver.core_substep, stage by stage, all ranks in lockstep
-        lockstep_exchange(solvers, [s.u + s.phi for s in solvers])
+        lockstep_exchange(solvers, [[s.u] + s.phi for s in solvers])
         for s in solvers:
             s.e.advect_vector(s.u, s.adv, dt, s.inv_dx)
-        lockstep_exchange(solvers, [s.adv for s in solvers])
+        lockstep_exchange(solvers, [[s.adv] for s in solvers])
         for s in solvers:
             s.e.divergence(s.adv, s.div, s.inv_dx)
         lockstep_exchange(solvers, [[s.div] for s in solvers])
@@ -77,7 +77,7 @@ def test_emulated_ranks_match_single_grid(name, world):
         for s in solvers:
             s.p = s._src
             s.e.subtract_pressure_gradient(s.adv, s.p, s.u, s.inv_dx)
-        lockstep_exchange(solvers, [s.u for s in solvers])
+        lockstep_exchange(solvers, [[s.u] for s in solvers])
         for s in solvers:
             s.e.advect_scalars(s.u, s.phi, s.phi_next, dt, s.inv_dx)
             s.phi, s.phi_next = s.phi_next, s.phi
@@ -85,7 +85,7 @@ def test_emulated_ranks_match_single_grid(name, world):
     for s in solvers:
         own = s.plan.owned_global
         sel = (own[:, None] * 512 + np.arange(512)[None, :]).reshape(-1)
-        u = np.stack([s.owned(c).cpu().numpy() for c in s.u], 1)
+        u = s.owned(s.u).cpu().numpy()
         assert np.array_equal(u, arrays["vel"][sel]), f"rank {s.plan.rank} velocity"
         assert np.array_equal(s.owned(s.phi[0]).cpu().numpy(), arrays["density"][sel]), f"rank {s.plan.rank} density"
         assert np.array_equal(s.owned(s.phi[1]).cpu().numpy(), arrays["temperature"][sel]), f"rank {s.plan.rank} temperature"
@@ -110,7 +110,7 @@ def test_world_size_one_solver_equals_sim():
     sim.core_substep(iters, dt, vs, D.current_stream())
     sim.download(arrays)
     torch.cuda.synchronize()
-    assert np.array_equal(np.stack([c.cpu().numpy() for c in sol.u], 1), arrays["vel"])
+    assert np.array_equal(sol.u.cpu().numpy(), arrays["vel"])
     assert np.array_equal(sol.phi[0].cpu().numpy(), arrays["density"])
 
 
@@ -126,4 +126,4 @@ def test_slab_bench_driver_single_rank():
     ms, launches = b.pressure_time()
     assert launches == 10 and ms > 0.0
     torch.cuda.synchronize()
-    assert torch.isfinite(b.solver.u[0]).all()
+    assert torch.isfinite(b.solver.u).all()

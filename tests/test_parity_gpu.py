@@ -77,12 +77,12 @@ class Case:
     def dev(self, a):
         return self.torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
-    def planar(self, vel_aos):
-        return self.dev(np.ascontiguousarray(vel_aos.T))
+    def planar(self, vel_aos):  # velocity lives on the device as Vec3f AoS, the host layout
+        return self.dev(vel_aos)
 
     @staticmethod
-    def aos(planar_t):
-        return np.ascontiguousarray(planar_t.cpu().numpy().T)
+    def aos(t):
+        return t.cpu().numpy().reshape(-1, 3)
 
 
 @pytest.fixture(scope="module", params=list(CASES.keys()))
@@ -106,15 +106,6 @@ def test_offsets_match_oracle(case):
 # ---------------------------------------------------------------------------------------------------------------
 # kernels
 # ---------------------------------------------------------------------------------------------------------------
-
-
-def test_aos_soa_roundtrip(case):
-    from hnanosolver_amd import device as D
-
-    v = case.dev(case.f["vel"])
-    p = D.to_planar(v)
-    assert np.array_equal(p.cpu().numpy(), case.f["vel"].T)
-    assert np.array_equal(D.to_aos(p).cpu().numpy(), case.f["vel"])
 
 
 def test_divergence(case):
@@ -225,7 +216,7 @@ def test_combustion_and_buoyancy(case):
     for got, w, name in zip(outs + [div], want, ["fuel", "waste", "temperature", "flame", "divergence"]):
         assert_close(got.cpu().numpy(), w, f"combustion {name}")
     u = case.planar(f["vel"])
-    D.temperature_buoyancy(u[1], case.dev(f["temperature"]), u[1], case.dt, 23.0, 1.0)
+    D.temperature_buoyancy(u, case.dev(f["temperature"]), u, case.dt, 23.0, 1.0)
     assert_close(Case.aos(u), case.oracle.temperature_buoyancy(f["vel"], f["temperature"], case.dt, 23.0, 1.0), "buoyancy")
 
 
@@ -284,3 +275,13 @@ def test_pack_unpack_leaves(case):
     ref = np.zeros((nl, 512), np.float32)
     ref[ids_h] = case.f["density"].reshape(nl, 512)[ids_h]
     assert np.array_equal(dst.cpu().numpy(), ref.reshape(-1))
+    # Vec3f payloads: 1536 floats per leaf
+    v = case.dev(case.f["vel"])
+    pv = t.zeros(len(ids_h) * 1536, device="cuda")
+    D.pack_leaves(v, ids, pv, 3)
+    assert np.array_equal(pv.cpu().numpy(), case.f["vel"].reshape(nl, 1536)[ids_h].reshape(-1))
+    dv = t.zeros((case.N, 3), device="cuda")
+    D.unpack_leaves(pv, ids, dv, 3)
+    refv = np.zeros((nl, 1536), np.float32)
+    refv[ids_h] = case.f["vel"].reshape(nl, 1536)[ids_h]
+    assert np.array_equal(dv.cpu().numpy().reshape(-1), refv.reshape(-1))
