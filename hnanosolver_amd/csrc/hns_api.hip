@@ -67,6 +67,8 @@ int hns_grid_upload_schedule(hns_grid* g) {
 	if (g->d_singles) hipFree(g->d_singles);
 	g->d_pairs = g->d_singles = nullptr;
 	g->n_pairs = g->n_singles = 0;
+	for (auto& e : g->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);  // captured launches hold the old lists
+	g->graphs.clear();
 	const int64_t n = (int64_t)g->n_active;
 	if (n == 0) return HNS_OK;
 	const char* mode = getenv("HNS_SCHEDULE");
@@ -169,6 +171,13 @@ int hns_grid_upload(hns_grid* g) {
 
 void hns_grid_free_device(hns_grid* g) {
 	if (!g) return;
+	for (auto& e : g->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);
+	g->graphs.clear();
+	if (g->cap_stream) (void)hipStreamDestroy((hipStream_t)g->cap_stream);
+	if (g->cap_side) (void)hipStreamDestroy((hipStream_t)g->cap_side);
+	if (g->cap_fork) (void)hipEventDestroy((hipEvent_t)g->cap_fork);
+	if (g->cap_join) (void)hipEventDestroy((hipEvent_t)g->cap_join);
+	g->cap_stream = g->cap_side = g->cap_fork = g->cap_join = nullptr;
 	if (g->d_origins) hipFree(g->d_origins);
 	if (g->d_nbr27) hipFree(g->d_nbr27);
 	if (g->d_hash) hipFree(g->d_hash);

@@ -53,6 +53,16 @@ struct GridDev {
 	int oob;  // element read by advect_scalars for out-of-domain taps (0 on an unpartitioned grid)
 };
 
+// a captured pressure loop (hipGraphExec_t) and the arguments it was captured for
+struct RbgsGraph {
+	const float* div;
+	float* p_a;
+	float* p_b;
+	float dx2, omega;
+	int iterations, mode;
+	void* exec;
+};
+
 }  // namespace hns
 
 struct hns_grid {
@@ -71,6 +81,11 @@ struct hns_grid {
 	void* d_pairs = nullptr;    // launch-ordered records of z-adjacent leaf pairs: {leaf0, nbr27, leaf1, nbr27} (56 ints)
 	void* d_singles = nullptr;  // {leaf, nbr27} records (28 ints) of the active leaves that are in no pair
 	uint64_t n_pairs = 0, n_singles = 0;
+	std::vector<hns::RbgsGraph> graphs;  // cached hipGraph replays of the pressure loop (dropped when the schedule changes)
+	void* cap_stream = nullptr;          // private capture streams / events
+	void* cap_side = nullptr;
+	void* cap_fork = nullptr;
+	void* cap_join = nullptr;
 	hns::GridDev dev() const;
 };
 

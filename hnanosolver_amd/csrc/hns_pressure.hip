@@ -660,6 +660,33 @@ int hns_dev_rbgs_color(hns_grid* g, const float* div, float* p, float dx, float 
 	return launch_status("hns_dev_rbgs_color");
 }
 
+// one full (red, black) iteration src -> dst; `side` (may be null) carries the unpaired leaves concurrently when capturing
+static void launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* div, const float* src, float* dst, float dx2, float omega, int mode,
+                                  hipStream_t st, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
+	if (mode == 1) {
+		hipLaunchKernelGGL(k_rbgs_fused, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, src, dst, dx2, omega);
+	} else if (mode == 2 || !g->d_pairs) {
+		hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_active), dim3(64), 0, st, gd, div, src, dst, dx2, omega);
+	} else {
+		// paired leaves and the unpaired remainder are disjoint, both read src and write dst: two independent launches
+		const bool par = side && g->n_pairs && g->n_singles;
+		if (par) {
+			(void)hipEventRecord(fork, st);
+			(void)hipStreamWaitEvent(side, fork, 0);
+		}
+		if (g->n_pairs) hipLaunchKernelGGL(k_rbgs_pair, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, src, dst, dx2, omega);
+		if (g->n_singles) {
+			GridDev gs = gd;
+			gs.blk = (const int*)g->d_singles;
+			hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_singles), dim3(64), 0, par ? side : st, gs, div, src, dst, dx2, omega);
+		}
+		if (par) {
+			(void)hipEventRecord(join, side);
+			(void)hipStreamWaitEvent(st, join, 0);
+		}
+	}
+}
+
 int hns_dev_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int* result_in_b,
                          void* stream) {
 	if (int rc = check_grid(g, "hns_dev_rbgs_iterate")) return rc;
@@ -667,29 +694,60 @@ int hns_dev_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, 
 	if (p_a == p_b) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dev_rbgs_iterate: p_a and p_b must be distinct buffers");
 	if (iterations < 0) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dev_rbgs_iterate: negative iteration count");
 	if (result_in_b) *result_in_b = iterations & 1;
-	if (g->n_active == 0) return HNS_OK;
+	if (g->n_active == 0 || iterations == 0) return HNS_OK;
 	const float dx2 = dx * dx;  // Kernel.cu:608
 	const GridDev gd = g->dev();
+	static const int mode = !getenv("HNS_RBGS") ? 0 : (strcmp(getenv("HNS_RBGS"), "block") == 0 ? 1 : (strcmp(getenv("HNS_RBGS"), "wave") == 0 ? 2 : 0));
+	static const bool use_graph = !(getenv("HNS_GRAPH") && strcmp(getenv("HNS_GRAPH"), "0") == 0);
+
+	// The loop is launch-bound on small grids (a 128^3 sweep is a few microseconds): replay it as one hipGraph. The graph
+	// is captured once per (buffers, parameters) on a private stream and cached in the grid; the caller's stream only
+	// sees one hipGraphLaunch.
+	if (use_graph && iterations >= 4) {
+		hns::RbgsGraph* hit = nullptr;
+		for (auto& e : g->graphs)
+			if (e.div == div && e.p_a == p_a && e.p_b == p_b && e.dx2 == dx2 && e.omega == omega && e.iterations == iterations && e.mode == mode) hit = &e;
+		if (!hit) {
+			if (!g->cap_stream) {
+				HNS_HIP(hipStreamCreateWithFlags((hipStream_t*)&g->cap_stream, hipStreamNonBlocking));
+				HNS_HIP(hipStreamCreateWithFlags((hipStream_t*)&g->cap_side, hipStreamNonBlocking));
+				HNS_HIP(hipEventCreateWithFlags((hipEvent_t*)&g->cap_fork, hipEventDisableTiming));
+				HNS_HIP(hipEventCreateWithFlags((hipEvent_t*)&g->cap_join, hipEventDisableTiming));
+			}
+			hipStream_t cs = (hipStream_t)g->cap_stream;
+			hipGraph_t graph = nullptr;
+			HNS_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+			float* src = p_a;
+			float* dst = p_b;
+			for (int it = 0; it < iterations; ++it) {
+				launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode, cs, (hipStream_t)g->cap_side, (hipEvent_t)g->cap_fork, (hipEvent_t)g->cap_join);
+				float* tmp = src;
+				src = dst;
+				dst = tmp;
+			}
+			HNS_HIP(hipStreamEndCapture(cs, &graph));
+			hipGraphExec_t exec = nullptr;
+			hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+			(void)hipGraphDestroy(graph);
+			if (ie != hipSuccess) {
+				set_error("hns_dev_rbgs_iterate: hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+				return HNS_ERR_HIP;
+			}
+			if (g->graphs.size() >= 8) {  // small cache: drop the oldest
+				(void)hipGraphExecDestroy((hipGraphExec_t)g->graphs.front().exec);
+				g->graphs.erase(g->graphs.begin());
+			}
+			g->graphs.push_back(hns::RbgsGraph{div, p_a, p_b, dx2, omega, iterations, mode, (void*)exec});
+			hit = &g->graphs.back();
+		}
+		HNS_HIP(hipGraphLaunch((hipGraphExec_t)hit->exec, (hipStream_t)stream));
+		return HNS_OK;
+	}
+
 	float* src = p_a;
 	float* dst = p_b;
-	static const bool use_lds_kernel = getenv("HNS_RBGS") && strcmp(getenv("HNS_RBGS"), "block") == 0;  // A/B switch: 256-thread LDS-tile form
-	static const bool use_wave_kernel = getenv("HNS_RBGS") && strcmp(getenv("HNS_RBGS"), "wave") == 0;   // A/B switch: one leaf per wave everywhere
 	for (int it = 0; it < iterations; ++it) {
-		if (use_lds_kernel)
-			hipLaunchKernelGGL(k_rbgs_fused, dim3((unsigned)g->n_active), dim3(256), 0, (hipStream_t)stream, gd, div, (const float*)src, dst, dx2, omega);
-		else if (use_wave_kernel || !g->d_pairs)
-			hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, div, (const float*)src, dst, dx2, omega);
-		else {
-			// paired leaves and the unpaired remainder are disjoint and both read src / write dst: two independent launches
-			if (g->n_pairs)
-				hipLaunchKernelGGL(k_rbgs_pair, dim3((unsigned)g->n_pairs), dim3(64), 0, (hipStream_t)stream, (const int*)g->d_pairs, div, (const float*)src,
-				                   dst, dx2, omega);
-			if (g->n_singles) {
-				GridDev gs = gd;
-				gs.blk = (const int*)g->d_singles;
-				hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_singles), dim3(64), 0, (hipStream_t)stream, gs, div, (const float*)src, dst, dx2, omega);
-			}
-		}
+		launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode, (hipStream_t)stream, nullptr, nullptr, nullptr);
 		float* tmp = src;
 		src = dst;
 		dst = tmp;
