@@ -499,112 +499,151 @@ constexpr PairLaneTab make_pair_lane_tab() {
 }
 __device__ const PairLaneTab g_pair_lane_tab = make_pair_lane_tab();
 
-__global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs, const float* __restrict__ div, const float* __restrict__ p_in,
-                                                  float* __restrict__ p_out, const float dx2, const float omega) {
-	__shared__ __attribute__((aligned(16))) PairTile S;
-	const int l = threadIdx.x;
-	// record: {leaf0, nbr27 of leaf0, leaf1, nbr27 of leaf1}; leaf1 is the +z neighbour of leaf0
-	const int* __restrict__ rec = pairs + (size_t)blockIdx.x * 56;
-	const int leaf0 = __builtin_amdgcn_readfirstlane(rec[0]), leaf1 = __builtin_amdgcn_readfirstlane(rec[28]);
-	const int n_zm = __builtin_amdgcn_readfirstlane(rec[1 + 12]), n_zp = __builtin_amdgcn_readfirstlane(rec[28 + 1 + 14]);
-	const int x = l >> 3, y = l & 7;
-	const bool par = (x + y) & 1;  // false: even z red, true: odd z red (both leaves: their z origins differ by 8)
+// everything one wave reads from global memory for one leaf pair
+struct PairIn {
+	int leaf0, leaf1;
+	RowP P0, P1, D0, D1;  // own rows of p and div
+	float2 zlo, zhi;      // p(x,y,-2..-1) below leaf0, p(x,y,8..9) above leaf1
+	float d_zh;           // div at this lane's z-halo red voxel
+	bool zh_ok;           // ... and whether that voxel's leaf exists
+	RowP HA, HB, HD;      // halo-row duty: adjacent row, the row behind it, div of the adjacent row
+	bool f_ok;            // the face neighbour leaf exists
+	float e_val;          // the halo row's z-neighbour outside the pair
+	RowP ER;              // edge row (lanes 0..7)
+};
 
-	// ---- every global load up front ----
-	const RowP P0 = glb_rowp(p_in, leaf0, l), P1 = glb_rowp(p_in, leaf1, l);
-	const RowP D0 = glb_rowp(div, leaf0, l), D1 = glb_rowp(div, leaf1, l);
-	// p(x,y,-2..-1) below leaf0 and p(x,y,8..9) above leaf1; n_zm / n_zp are wave-uniform
-	float2 zlo = *reinterpret_cast<const float2*>(p_in + (size_t)(n_zm < 0 ? 0 : n_zm) * 512 + l * 8 + 6);
-	float2 zhi = *reinterpret_cast<const float2*>(p_in + (size_t)(n_zp < 0 ? 0 : n_zp) * 512 + l * 8);
-	if (n_zm < 0) zlo = make_float2(0.0f, 0.0f);
-	if (n_zp < 0) zhi = make_float2(0.0f, 0.0f);
-	const int n_zh = par ? n_zm : n_zp;  // this lane's z-halo red voxel: below leaf0 if par, else above leaf1
-	float d_zh = div[(size_t)(n_zh < 0 ? 0 : n_zh) * 512 + l * 8 + (par ? 7 : 0)];
+// per-lane constants (do not depend on the pair)
+struct PairLaneCtx {
+	int l, x, y, w, I, R_xm, R_xp, R_ym, R_yp;
+	bool par;
+	int slotF, srcA, srcB, RA, RB, H_xm, H_xp, H_ym, H_yp, slotE;
+	bool hpar;
+	int ew, ea, eb;
+};
 
-	// halo-row duty: lanes 0..31 -> leaf0, 32..63 -> leaf1; 4 faces x 8 rows each (constants from g_pair_lane_tab)
-	const int w = l >> 5;
-	const int4* __restrict__ lt = reinterpret_cast<const int4*>(&g_pair_lane_tab.t[l]);
+__device__ __forceinline__ PairLaneCtx pair_lane_ctx() {
+	PairLaneCtx c;
+	c.l = threadIdx.x;
+	c.x = c.l >> 3, c.y = c.l & 7;
+	c.par = (c.x + c.y) & 1;  // false: even z red, true: odd z red (both leaves: their z origins differ by 8)
+	c.w = c.l >> 5;
+	const int4* __restrict__ lt = reinterpret_cast<const int4*>(&g_pair_lane_tab.t[c.l]);
 	const int4 t0 = lt[0], t1 = lt[1], t2 = lt[2];
-	const int slotF = t0.x, srcA = t0.y, srcB = t0.z, RA = t0.w, RB = t1.x, H_xm = t1.y, H_xp = t1.z, H_ym = t1.w, H_yp = t2.x, slotE = t2.y;
-	const bool hpar = t2.z;
-	const int* __restrict__ nb = rec + 28 * w + 1;
-	const int n_f = nb[slotF];
-	const RowP HA = glb_rowp(p_in, n_f, srcA);
-	const RowP HB = glb_rowp(p_in, n_f, srcB);
-	const RowP HD = glb_rowp(div, n_f, srcA);
+	c.slotF = t0.x, c.srcA = t0.y, c.srcB = t0.z, c.RA = t0.w, c.RB = t1.x, c.H_xm = t1.y, c.H_xp = t1.z, c.H_ym = t1.w, c.H_yp = t2.x, c.slotE = t2.y;
+	c.hpar = t2.z;
+	c.ew = (c.l >> 2) & 1, c.ea = (c.l >> 1) & 1, c.eb = c.l & 1;
+	c.I = 8 * (c.x + 1) + c.y;
+	c.R_xm = c.I - 8, c.R_xp = c.I + 8, c.R_ym = c.y == 0 ? 87 + 8 * c.x : c.I - 1, c.R_yp = c.y == 7 ? 96 + 8 * c.x : c.I + 1;
+	return c;
+}
+
+// issue every global load of one pair (no waits here: the values are consumed in pair_compute)
+__device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __restrict__ rec, const float* __restrict__ div,
+                                            const float* __restrict__ p_in) {
+	PairIn in;
+	// record: {leaf0, nbr27 of leaf0, leaf1, nbr27 of leaf1}; leaf1 is the +z neighbour of leaf0
+	in.leaf0 = __builtin_amdgcn_readfirstlane(rec[0]);
+	in.leaf1 = __builtin_amdgcn_readfirstlane(rec[28]);
+	const int n_zm = __builtin_amdgcn_readfirstlane(rec[1 + 12]), n_zp = __builtin_amdgcn_readfirstlane(rec[28 + 1 + 14]);
+	const int l = c.l;
+	in.P0 = glb_rowp(p_in, in.leaf0, l), in.P1 = glb_rowp(p_in, in.leaf1, l);
+	in.D0 = glb_rowp(div, in.leaf0, l), in.D1 = glb_rowp(div, in.leaf1, l);
+	in.zlo = *reinterpret_cast<const float2*>(p_in + (size_t)(n_zm < 0 ? 0 : n_zm) * 512 + l * 8 + 6);
+	in.zhi = *reinterpret_cast<const float2*>(p_in + (size_t)(n_zp < 0 ? 0 : n_zp) * 512 + l * 8);
+	if (n_zm < 0) in.zlo = make_float2(0.0f, 0.0f);
+	if (n_zp < 0) in.zhi = make_float2(0.0f, 0.0f);
+	const int n_zh = c.par ? n_zm : n_zp;  // this lane's z-halo red voxel: below leaf0 if par, else above leaf1
+	in.zh_ok = n_zh >= 0;
+	in.d_zh = div[(size_t)(n_zh < 0 ? 0 : n_zh) * 512 + l * 8 + (c.par ? 7 : 0)];
+	// halo-row duty: lanes 0..31 -> leaf0, 32..63 -> leaf1; 4 faces x 8 rows each
+	const int* __restrict__ nb = rec + 28 * c.w + 1;
+	const int n_f = nb[c.slotF];
+	in.f_ok = n_f >= 0;
+	in.HA = glb_rowp(p_in, n_f, c.srcA);
+	in.HB = glb_rowp(p_in, n_f, c.srcB);
+	in.HD = glb_rowp(div, n_f, c.srcA);
 	// the halo row's own z-neighbour outside the pair: z=-1 for the lower leaf, z=8 for the upper leaf
-	const int n_e = nb[slotE];
-	float e_val = p_in[(size_t)(n_e < 0 ? 0 : n_e) * 512 + srcA * 8 + (w ? 0 : 7)];
-	e_val = n_e < 0 ? 0.0f : e_val;
+	const int n_e = nb[c.slotE];
+	const float ev = p_in[(size_t)(n_e < 0 ? 0 : n_e) * 512 + c.srcA * 8 + (c.w ? 0 : 7)];
+	in.e_val = n_e < 0 ? 0.0f : ev;
 	// edge rows along z (lanes 0..7): tile rows (-1,-1), (-1,8), (8,-1), (8,8) of each leaf
-	const int ew = (l >> 2) & 1, ea = (l >> 1) & 1, eb = l & 1;
-	const int n_er = rec[28 * ew + 1 + (ea ? 2 : 0) * 9 + (eb ? 2 : 0) * 3 + 1];
-	RowP ER;
-	if (l < 8) ER = glb_rowp(p_in, n_er, (ea ? 0 : 7) * 8 + (eb ? 0 : 7));
+	const int n_er = rec[28 * c.ew + 1 + (c.ea ? 2 : 0) * 9 + (c.eb ? 2 : 0) * 3 + 1];
+	if (l < 8) in.ER = glb_rowp(p_in, n_er, (c.ea ? 0 : 7) * 8 + (c.eb ? 0 : 7));
+	return in;
+}
 
-	// ---- row numbers of the lane's own rows ----
-	const int I = 8 * (x + 1) + y;
-	const int R_xm = I - 8, R_xp = I + 8, R_ym = y == 0 ? 87 + 8 * x : I - 1, R_yp = y == 7 ? 96 + 8 * x : I + 1;
-
+// stage, red sweep, black sweep, store: one full iteration for one pair from registers `in`
+__device__ __forceinline__ void pair_compute(PairTile& S, const PairLaneCtx& c, const PairIn& in, float* __restrict__ p_out, const float dx2,
+                                             const float omega) {
+	const int l = c.l, w = c.w, I = c.I;
+	const bool par = c.par;
 	// ---- stage ----
-	pt_put(S, 0, I, P0);
-	pt_put(S, 1, I, P1);
-	S.ZM[I] = zlo.y;
-	S.ZP[I] = zhi.x;
-	pt_put(S, w, RA, HA);
-	pt_put(S, w, RB, HB);
-	(w ? S.ZP : S.ZM)[RA] = e_val;
-	if (l < 8) pt_put(S, ew, 81 + ea * 2 + eb, ER);
+	pt_put(S, 0, I, in.P0);
+	pt_put(S, 1, I, in.P1);
+	S.ZM[I] = in.zlo.y;
+	S.ZP[I] = in.zhi.x;
+	pt_put(S, w, c.RA, in.HA);
+	pt_put(S, w, c.RB, in.HB);
+	(w ? S.ZP : S.ZM)[c.RA] = in.e_val;
+	if (l < 8) pt_put(S, c.ew, 81 + c.ea * 2 + c.eb, in.ER);
 	__syncthreads();
 
 	// ---- phase R ----
 	RowP hnew, c0, c1;
 	float zc;
 	{
-		const RowP hxm = pt_row(S, w, H_xm), hxp = pt_row(S, w, H_xp), hym = pt_row(S, w, H_ym), hyp = pt_row(S, w, H_yp);
-		const float other_lo = S.HI[0][RA].w, other_hi = S.LO[1][RA].x;
-		const float below = w ? other_lo : e_val;  // z=-1 of this halo row
-		const float above = w ? e_val : other_hi;  // z=8
-		hnew = row_sweep(hxp, hxm, hyp, hym, HA, below, above, HD, dx2, omega, !hpar, n_f >= 0);
+		const RowP hxm = pt_row(S, w, c.H_xm), hxp = pt_row(S, w, c.H_xp), hym = pt_row(S, w, c.H_ym), hyp = pt_row(S, w, c.H_yp);
+		const float other_lo = S.HI[0][c.RA].w, other_hi = S.LO[1][c.RA].x;
+		const float below = w ? other_lo : in.e_val;  // z=-1 of this halo row
+		const float above = w ? in.e_val : other_hi;  // z=8
+		hnew = row_sweep(hxp, hxm, hyp, hym, in.HA, below, above, in.HD, dx2, omega, !c.hpar, in.f_ok);
 	}
 	{
-		const RowP xm = pt_row(S, 0, R_xm), xp = pt_row(S, 0, R_xp), ym = pt_row(S, 0, R_ym), yp = pt_row(S, 0, R_yp);
-		c0 = row_sweep(xp, xm, yp, ym, P0, zlo.y, P1.q[0].x, D0, dx2, omega, !par, true);
+		const RowP xm = pt_row(S, 0, c.R_xm), xp = pt_row(S, 0, c.R_xp), ym = pt_row(S, 0, c.R_ym), yp = pt_row(S, 0, c.R_yp);
+		c0 = row_sweep(xp, xm, yp, ym, in.P0, in.zlo.y, in.P1.q[0].x, in.D0, dx2, omega, !par, true);
 	}
 	{
-		const RowP xm = pt_row(S, 1, R_xm), xp = pt_row(S, 1, R_xp), ym = pt_row(S, 1, R_ym), yp = pt_row(S, 1, R_yp);
-		c1 = row_sweep(xp, xm, yp, ym, P1, P0.q[3].y, zhi.x, D1, dx2, omega, !par, true);
+		const RowP xm = pt_row(S, 1, c.R_xm), xp = pt_row(S, 1, c.R_xp), ym = pt_row(S, 1, c.R_ym), yp = pt_row(S, 1, c.R_yp);
+		c1 = row_sweep(xp, xm, yp, ym, in.P1, in.P0.q[3].y, in.zhi.x, in.D1, dx2, omega, !par, true);
 	}
 	{
 		// z-halo red voxel: (x,y,-1) under leaf0 when par, else (x,y,8) over leaf1
 		const float* ZA = par ? S.ZM : S.ZP;
-		zc = sor_update(ZA[R_xp], ZA[R_xm], ZA[R_yp], ZA[R_ym], par ? P0.q[0].x : zhi.y, par ? zlo.x : P1.q[3].y, d_zh, par ? zlo.y : zhi.x, dx2,
-		                omega);
+		zc = sor_update(ZA[c.R_xp], ZA[c.R_xm], ZA[c.R_yp], ZA[c.R_ym], par ? in.P0.q[0].x : in.zhi.y, par ? in.zlo.x : in.P1.q[3].y, in.d_zh,
+		                par ? in.zlo.y : in.zhi.x, dx2, omega);
 	}
 	// values just outside each row after the red sweep
-	const float below0 = (par && n_zh >= 0) ? zc : zlo.y;
-	const float above1 = (!par && n_zh >= 0) ? zc : zhi.x;
+	const float below0 = (par && in.zh_ok) ? zc : in.zlo.y;
+	const float above1 = (!par && in.zh_ok) ? zc : in.zhi.x;
 	__syncthreads();  // phase-R reads complete before the rows are overwritten
 	pt_put(S, 0, I, c0);
 	pt_put(S, 1, I, c1);
-	pt_put(S, w, RA, hnew);
+	pt_put(S, w, c.RA, hnew);
 	__syncthreads();
 
 	// ---- phase B ----
 	{
-		const RowP xm = pt_row(S, 0, R_xm), xp = pt_row(S, 0, R_xp), ym = pt_row(S, 0, R_ym), yp = pt_row(S, 0, R_yp);
-		const RowP o = row_sweep(xp, xm, yp, ym, c0, below0, c1.q[0].x, D0, dx2, omega, par, true);
-		float4* q = reinterpret_cast<float4*>(p_out + (size_t)leaf0 * 512 + l * 8);
+		const RowP xm = pt_row(S, 0, c.R_xm), xp = pt_row(S, 0, c.R_xp), ym = pt_row(S, 0, c.R_ym), yp = pt_row(S, 0, c.R_yp);
+		const RowP o = row_sweep(xp, xm, yp, ym, c0, below0, c1.q[0].x, in.D0, dx2, omega, par, true);
+		float4* q = reinterpret_cast<float4*>(p_out + (size_t)in.leaf0 * 512 + l * 8);
 		q[0] = make_float4(o.q[0].x, o.q[0].y, o.q[1].x, o.q[1].y);
 		q[1] = make_float4(o.q[2].x, o.q[2].y, o.q[3].x, o.q[3].y);
 	}
 	{
-		const RowP xm = pt_row(S, 1, R_xm), xp = pt_row(S, 1, R_xp), ym = pt_row(S, 1, R_ym), yp = pt_row(S, 1, R_yp);
-		const RowP o = row_sweep(xp, xm, yp, ym, c1, c0.q[3].y, above1, D1, dx2, omega, par, true);
-		float4* q = reinterpret_cast<float4*>(p_out + (size_t)leaf1 * 512 + l * 8);
+		const RowP xm = pt_row(S, 1, c.R_xm), xp = pt_row(S, 1, c.R_xp), ym = pt_row(S, 1, c.R_ym), yp = pt_row(S, 1, c.R_yp);
+		const RowP o = row_sweep(xp, xm, yp, ym, c1, c0.q[3].y, above1, in.D1, dx2, omega, par, true);
+		float4* q = reinterpret_cast<float4*>(p_out + (size_t)in.leaf1 * 512 + l * 8);
 		q[0] = make_float4(o.q[0].x, o.q[0].y, o.q[1].x, o.q[1].y);
 		q[1] = make_float4(o.q[2].x, o.q[2].y, o.q[3].x, o.q[3].y);
 	}
+}
+
+__global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs, const float* __restrict__ div, const float* __restrict__ p_in,
+                                                  float* __restrict__ p_out, const float dx2, const float omega) {
+	__shared__ __attribute__((aligned(16))) PairTile S;
+	const PairLaneCtx c = pair_lane_ctx();
+	const PairIn in = pair_load(c, pairs + (size_t)blockIdx.x * 56, div, p_in);
+	pair_compute(S, c, in, p_out, dx2, omega);
 }
 
 
