@@ -15,11 +15,13 @@ Exchanges sit exactly where the single-GPU code has a global kernel boundary tha
 are bit-identical to the single-GPU run:
 
     exchange(u, phi) -> advect_vector -> exchange(u*) -> divergence -> exchange(div)
-      -> iterations x [ fused red+black sweep on owned leaves -> exchange(p) ]
+      -> iterations x fused red+black sweep, exchange(p) after every 4th sweep
       -> gradient subtraction -> exchange(u) -> advect_scalars
 
-(the fused sweep recomputes the red update of the face-adjacent ghost voxels itself, so ONE exchange per iteration is
-enough, not one per colour). There is no all-reduce: the reference uses a fixed iteration count with no residual norm.
+(the fused sweep recomputes the red update of the face-adjacent ghost voxels itself, and the ghost leaves are swept
+locally between exchanges: their outer voxel layers go stale two per sweep while the owned leaves only read the two
+layers next to them, so four sweeps fit between exchanges -- 13 pressure exchanges per 50 iterations instead of the 100
+a colour-by-colour scheme needs). There is no all-reduce: the reference uses a fixed iteration count, no residual norm.
 
 The compute engine is injected: ``HipEngine`` (libhns.so through hnanosolver_amd.device) is the product; the CPU tests
 inject an engine built on the oracle to exercise partition + exchange logic under gloo.
@@ -161,6 +163,8 @@ class HipEngine:
         self.torch, self.D = torch, device
         self.grid = api.create_grid_from_leaves(local_origins, voxel_size)
         self.grid.set_active_leaves(n_owned)
+        # same leaves, ghosts updated too: used by the communication-avoiding pressure sweeps
+        self.grid_all = api.create_grid_from_leaves(local_origins, voxel_size) if n_owned < len(local_origins) else self.grid
         self.device = torch.device("cuda", torch.cuda.current_device())
 
     def set_outside_element(self, idx: int):
@@ -187,8 +191,8 @@ class HipEngine:
     def divergence(self, u, div, inv_dx):
         self.D.divergence(self.grid, u, div, inv_dx)
 
-    def rbgs_iteration(self, div, p_in, p_out, dx, omega):
-        self.D.rbgs_iterate(self.grid, div, p_in, p_out, dx, omega, 1)
+    def rbgs_iteration(self, div, p_in, p_out, dx, omega, include_ghosts=False):
+        self.D.rbgs_iterate(self.grid_all if include_ghosts else self.grid, div, p_in, p_out, dx, omega, 1)
 
     def subtract_pressure_gradient(self, u, p, out, inv_dx):
         self.D.subtract_pressure_gradient(self.grid, u, p, out, inv_dx)
@@ -310,13 +314,23 @@ class DistributedSolver:
         for k, s in enumerate(scalars):
             self.phi[k].copy_(self.e.from_numpy(s))
 
+    # A fused (red, black) sweep moves information two voxels, and a ghost layer is one leaf = 8 voxels deep. If the
+    # ghosts are swept locally as well, after k sweeps without an exchange only their outer 2k voxel layers are stale, and
+    # the sweep of the OWNED leaves reads ghosts no deeper than 2 voxels: four sweeps fit between two exchanges
+    # (2*3 = 6 stale layers before the fourth sweep, 2 valid ones left). Owned results stay bit-identical.
+    SWEEPS_PER_EXCHANGE = 4
+
     def pressure_solve(self, iterations: int) -> None:
         self.p_a.zero_()  # never warm-started (reference HNanoSolver.cu:113)
         self.p_b.zero_()
         src, dst = self.p_a, self.p_b
-        for _ in range(iterations):
-            self.e.rbgs_iteration(self.div, src, dst, self.vs, self.omega)
-            self.halo.exchange([dst])
+        k = max(1, int(self.SWEEPS_PER_EXCHANGE))
+        for it in range(iterations):
+            last_before_exchange = (it + 1) % k == 0 or it + 1 == iterations
+            # the sweep right before an exchange need not touch the ghosts: they are overwritten anyway
+            self.e.rbgs_iteration(self.div, src, dst, self.vs, self.omega, include_ghosts=not last_before_exchange)
+            if last_before_exchange:
+                self.halo.exchange([dst])
             src, dst = dst, src
         self.p = src
 
