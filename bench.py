@@ -13,9 +13,10 @@ N > 1: weak scaling -- every rank owns one such x-slab of a (256*N) x 256 x 256 
 leaves of u / p / phi over RCCL each time the reference would have a global kernel boundary that the stencil crosses
 (hnanosolver_amd/dist.py). `value` = slab-substeps/s summed over ranks = N x (global substeps/s).
 
-Rank 0 prints ONE JSON line. `roofline`: dominant kernel k_rbgs_fused, algorithmic 12 B/voxel per launch (read p, read
+Rank 0 prints ONE JSON line. `roofline`: dominant kernel k_rbgs_pair, algorithmic 12 B/voxel per launch (read p, read
 div, write p once each), launch time from hipEvents recorded on the launch stream around the pressure loop of every
-timed step. `cpu_baseline`: the oracle (C restatement of the reference kernels, OpenMP over leaves) on the host cores,
+timed step; `traffic` = PMC-derived HBM bytes per launch from the committed profile of this same command
+(profiles/pmc_latest.json; bench.py cannot run rocprofv3 on itself). `cpu_baseline`: the oracle (C restatement of the reference kernels, OpenMP over leaves) on the host cores,
 rank 0 at N=1 only, on a bounded sample.
 """
 from __future__ import annotations
@@ -202,7 +203,7 @@ def main():
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("config") == args.config and j.get("kernel") == "k_rbgs_fused":
+                if j.get("config") == args.config and j.get("kernel") == "k_rbgs_pair":
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -229,7 +230,7 @@ def main():
                 "parallelism": "single GPU" if world == 1 else f"x-slab leaf partition over {world} GPUs, RCCL halo exchange",
             },
             "roofline": {
-                "kernel": "k_rbgs_fused (one launch = one red+black SOR iteration)",
+                "kernel": "k_rbgs_pair (one launch = one full red+black SOR iteration over all leaves)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
