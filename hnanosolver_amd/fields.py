@@ -63,7 +63,7 @@ def config_leaves(name: str) -> Tuple[np.ndarray, int]:
     if name == "plume":  # ~4k leaves / ~2M voxels on a 256^3 extent
         return plume_leaves(32, 2.5, 0.22), 256
     if name == "plume1024":  # ~64k leaves on a 1024^3 extent
-        return plume_leaves(128, 4.0, 0.13), 1024
+        return plume_leaves(128, 4.0, 0.125), 1024
     raise KeyError(name)
 
 

@@ -1,0 +1,131 @@
+"""Full-size checks on the GPU at BASELINE.json's configurations: direct parity against the oracle (the GPU box has
+enough host cores for the oracle to finish these in seconds) plus size-independent properties of the path.
+
+configs[1] 128^3 dense, 50 iterations: whole Compute_Sim cook vs the oracle.
+configs[2] 256^3 dense, 50 iterations: the metric's core substep vs the oracle, and the fused SOR kernel vs the
+           independent two-launch kernel (bit-identical), linearity in the right-hand side, zero-velocity idempotence.
+configs[3] sparse plume (~3.9k leaves): whole Compute_Sim cook vs the oracle; translation invariance of the topology.
+"""
+import numpy as np
+import pytest
+
+from hnanosolver_amd import api, fields
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5  # north_star: 1e-5 relative L-inf
+
+
+def rel_linf(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def cook_data(origins, R):
+    f = fields.synthetic_fields(origins, R)
+    c = fields.leaves_to_coords(origins)
+    d = api.GridIndexedData()
+    d.allocateCoords(len(c))
+    d.pCoords()[:] = c
+    for n in ("density", "temperature", "fuel", "waste", "flame"):
+        d.addValueBlock(n, d.FLOAT)
+        d.pValues(n)[:] = f[n]
+    d.addValueBlock("vel", d.VEC3F)
+    d.pValues("vel")[:] = f["vel"]
+    return d
+
+
+@pytest.mark.parametrize("config", ["128", "plume"])
+def test_compute_sim_full_size_vs_oracle(config):
+    from oracle_lib import OracleGrid
+
+    origins, R = fields.config_leaves(config)
+    vs, dt, iters = 1.0 / R, 1.0 / 24.0, 50
+    d = cook_data(origins, R)
+    names = d.getBlocksOfType(d.FLOAT)
+    want = {n: d.pValues(n).copy() for n in names + ["vel"]}
+    params = api.CombustionParams()
+    assert OracleGrid(origins).compute_sim(want["vel"], {n: want[n] for n in names}, iters, dt, vs, params, False) == 0
+    h = api.IndexGridHandle()
+    api.CreateIndexGrid(d, h, vs)
+    api.Compute_Sim(d, h, iters, dt, vs, params, False)
+    for n in names + ["vel"]:
+        r = rel_linf(d.pValues(n), want[n])
+        assert r <= TOL, f"{config}: field {n} rel L-inf {r:.3e}"
+        assert np.array_equal(d.pValues(n), want[n]), f"{config}: field {n} not bit-identical (rel {r:.3e})"
+
+
+def test_core_substep_256_vs_oracle_and_properties():
+    import torch
+
+    from hnanosolver_amd import device as D
+    from oracle_lib import OracleGrid, oracle
+
+    origins, R = fields.config_leaves("256")
+    vs, dt, iters = 1.0 / R, 1.0 / 24.0, 50
+    f = fields.synthetic_fields(origins, R)
+    grid = api.create_grid_from_leaves(origins, vs)
+    sim = D.Sim(grid, ["density"])
+    got = {"vel": f["vel"].copy(), "density": f["density"].copy()}
+    sim.upload(got)
+    sim.core_substep(iters, dt, vs, D.current_stream())
+    sim.download(got)
+
+    G = OracleGrid(origins)
+    inv_dx = float(np.float32(1.0) / np.float32(vs))
+    omega = float(oracle().orc_omega_compute(vs))
+    adv = G.advect_vector(f["vel"], dt, inv_dx)
+    div = G.divergence(adv, inv_dx)
+    p = G.rbgs_iterations(div, float(np.float32(vs)), omega, iters)
+    u = G.subtract_pressure_gradient(adv, p, inv_dx)
+    phi = G.advect_scalars(u, [f["density"]], dt, inv_dx)[0]
+    assert rel_linf(got["vel"], u) <= TOL and rel_linf(got["density"], phi) <= TOL
+    assert np.array_equal(got["vel"], u) and np.array_equal(got["density"], phi)
+
+    # --- properties of the pressure kernel at full size ---
+    N = len(div)
+    d_div = torch.from_numpy(div).cuda()
+    p0 = torch.zeros(N, device="cuda")
+    a, b = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    fused = D.rbgs_iterate(grid, d_div, a, b, vs, omega, 5).clone()
+    for _ in range(5):  # the independent two-launch kernel, in place
+        D.rbgs_color(grid, d_div, p0, vs, omega, 0)
+        D.rbgs_color(grid, d_div, p0, vs, omega, 1)
+    assert torch.equal(fused, p0), "fused pair kernel and two-launch kernel must agree bit-for-bit"
+    # linearity: scaling the right-hand side by a power of two scales the iterate exactly
+    a.zero_()
+    b.zero_()
+    twice = D.rbgs_iterate(grid, d_div * 2.0, a, b, vs, omega, 5)
+    assert torch.equal(twice, fused * 2.0)
+    # zero velocity: advection is the identity, projection leaves zero untouched
+    zero_u = torch.zeros((N, 3), device="cuda")
+    phi_d = torch.from_numpy(f["density"]).cuda()
+    out = torch.empty(N, device="cuda")
+    D.advect_scalar(grid, zero_u, phi_d, out, dt, inv_dx)
+    assert torch.equal(out, phi_d)
+    outv = torch.ones((N, 3), device="cuda")
+    D.advect_vector(grid, zero_u, outv, dt, inv_dx)
+    assert not outv.any()
+
+
+def test_translation_invariance_of_topology():
+    """Moving every leaf by the same multiple of 8 voxels (into negative coordinates and across root tiles) changes
+    nothing: no result depends on absolute coordinates except through float(coord), which is exact here."""
+    from hnanosolver_amd import device as D
+
+    import torch
+
+    origins, R = fields.config_leaves("plume")
+    f = fields.synthetic_fields(origins, R)
+    vs, dt = 1.0 / R, 1.0 / 24.0
+    outs = []
+    for shift in ([0, 0, 0], [-4096, 8, -8192]):
+        grid = api.create_grid_from_leaves(origins + np.array(shift, dtype=np.int32), vs)
+        sim = D.Sim(grid, ["density"])
+        arr = {"vel": f["vel"].copy(), "density": f["density"].copy()}
+        sim.upload(arr)
+        sim.core_substep(10, dt, vs, D.current_stream())
+        sim.download(arr)
+        outs.append(arr)
+        torch.cuda.synchronize()
+    assert np.array_equal(outs[0]["vel"], outs[1]["vel"]) and np.array_equal(outs[0]["density"], outs[1]["density"])
