@@ -98,48 +98,41 @@ int hns_grid_upload_schedule(hns_grid* g) {
 	// z-adjacent pairs for k_rbgs_pair: walk the schedule, pair a leaf with its +z neighbour when both are active and unpaired
 	{
 		std::vector<char> used((size_t)n, 0);
-		std::vector<int32_t> pairs, singles;
-		auto put = [&](std::vector<int32_t>& v, int32_t l) {
-			v.push_back(l);
-			v.insert(v.end(), g->topo.nbr27.begin() + (size_t)l * 27, g->topo.nbr27.begin() + (size_t)l * 27 + 27);
+		std::vector<int32_t> recs;  // 56 ints per wave: {leaf0, nbr27, leaf1 or -1, nbr27}
+		recs.reserve((size_t)n * 28);
+		auto put = [&](int32_t l) {
+			recs.push_back(l);
+			if (l >= 0)
+				recs.insert(recs.end(), g->topo.nbr27.begin() + (size_t)l * 27, g->topo.nbr27.begin() + (size_t)l * 27 + 27);
+			else
+				recs.insert(recs.end(), 27, -1);
 		};
-		std::vector<int32_t> order_pairs, order_single;
+		uint64_t n_single = 0;
 		for (int64_t b = 0; b < n; ++b) {
 			const int32_t l = sched[(size_t)b];
 			if (used[(size_t)l]) continue;
 			const int32_t up = g->topo.nbr27[(size_t)l * 27 + 14];
 			const int32_t dn = g->topo.nbr27[(size_t)l * 27 + 12];
+			used[(size_t)l] = 1;
 			if (up >= 0 && up < n && !used[(size_t)up]) {
-				used[(size_t)l] = used[(size_t)up] = 1;
-				put(pairs, l);
-				put(pairs, up);
+				used[(size_t)up] = 1;
+				put(l);
+				put(up);
 			} else if (dn >= 0 && dn < n && !used[(size_t)dn]) {
-				used[(size_t)l] = used[(size_t)dn] = 1;
-				put(pairs, dn);
-				put(pairs, l);
-			} else {
-				used[(size_t)l] = 1;
-				put(singles, l);
+				used[(size_t)dn] = 1;
+				put(dn);
+				put(l);
+			} else {  // no free partner: the leaf travels alone in its wave
+				put(l);
+				put(-1);
+				++n_single;
 			}
 		}
-		g->n_pairs = pairs.size() / 56;
-		g->n_singles = singles.size() / 28;
+		g->n_pairs = recs.size() / 56;  // waves to launch
+		g->n_singles = n_single;
 		if (g->n_pairs) {
-			// re-chunk the pair list over the 8 XCDs (the schedule above interleaves leaves, pairs halve the count)
-			std::vector<int32_t> ordered;
-			ordered.reserve(pairs.size());
-			if (linear) {
-				ordered = pairs;
-			} else {
-				// pairs were emitted in schedule order, which already alternates XCD chunks block by block
-				ordered = pairs;
-			}
-			HNS_HIP(hipMalloc(&g->d_pairs, sizeof(int32_t) * ordered.size()));
-			HNS_HIP(hipMemcpy(g->d_pairs, ordered.data(), sizeof(int32_t) * ordered.size(), hipMemcpyHostToDevice));
-		}
-		if (g->n_singles) {
-			HNS_HIP(hipMalloc(&g->d_singles, sizeof(int32_t) * singles.size()));
-			HNS_HIP(hipMemcpy(g->d_singles, singles.data(), sizeof(int32_t) * singles.size(), hipMemcpyHostToDevice));
+			HNS_HIP(hipMalloc(&g->d_pairs, sizeof(int32_t) * recs.size()));
+			HNS_HIP(hipMemcpy(g->d_pairs, recs.data(), sizeof(int32_t) * recs.size(), hipMemcpyHostToDevice));
 		}
 	}
 	if (linear) return HNS_OK;

@@ -501,7 +501,7 @@ __device__ const PairLaneTab g_pair_lane_tab = make_pair_lane_tab();
 
 // everything one wave reads from global memory for one leaf pair
 struct PairIn {
-	int leaf0, leaf1;
+	int leaf0, leaf1;  // leaf1 < 0: an unpaired leaf travelling alone (its +z neighbour, if any, belongs to another wave)
 	RowP P0, P1, D0, D1;  // own rows of p and div
 	float2 zlo, zhi;      // p(x,y,-2..-1) below leaf0, p(x,y,8..9) above leaf1
 	float d_zh;           // div at this lane's z-halo red voxel
@@ -544,7 +544,10 @@ __device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __r
 	// record: {leaf0, nbr27 of leaf0, leaf1, nbr27 of leaf1}; leaf1 is the +z neighbour of leaf0
 	in.leaf0 = __builtin_amdgcn_readfirstlane(rec[0]);
 	in.leaf1 = __builtin_amdgcn_readfirstlane(rec[28]);
-	const int n_zm = __builtin_amdgcn_readfirstlane(rec[1 + 12]), n_zp = __builtin_amdgcn_readfirstlane(rec[28 + 1 + 14]);
+	const bool single = in.leaf1 < 0;
+	// below the lower leaf / above the top leaf (the top leaf is leaf0 itself when it travels alone)
+	const int n_zm = __builtin_amdgcn_readfirstlane(rec[1 + 12]);
+	const int n_zp = __builtin_amdgcn_readfirstlane(single ? rec[1 + 14] : rec[28 + 1 + 14]);
 	const int l = c.l;
 	in.P0 = glb_rowp(p_in, in.leaf0, l), in.P1 = glb_rowp(p_in, in.leaf1, l);
 	in.D0 = glb_rowp(div, in.leaf0, l), in.D1 = glb_rowp(div, in.leaf1, l);
@@ -555,9 +558,10 @@ __device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __r
 	const int n_zh = c.par ? n_zm : n_zp;  // this lane's z-halo red voxel: below leaf0 if par, else above leaf1
 	in.zh_ok = n_zh >= 0;
 	in.d_zh = div[(size_t)(n_zh < 0 ? 0 : n_zh) * 512 + l * 8 + (c.par ? 7 : 0)];
-	// halo-row duty: lanes 0..31 -> leaf0, 32..63 -> leaf1; 4 faces x 8 rows each
-	const int* __restrict__ nb = rec + 28 * c.w + 1;
-	const int n_f = nb[c.slotF];
+	// halo-row duty: lanes 0..31 -> leaf0, 32..63 -> leaf1; 4 faces x 8 rows each. For a leaf travelling alone lanes 32..63
+	// have no rows to recompute; they only fetch the z=8 neighbours of leaf0's halo rows (slotE = face neighbour one up).
+	const int* __restrict__ nb = rec + (single ? 0 : 28 * c.w) + 1;
+	const int n_f = (single && c.w) ? -1 : nb[c.slotF];
 	in.f_ok = n_f >= 0;
 	in.HA = glb_rowp(p_in, n_f, c.srcA);
 	in.HB = glb_rowp(p_in, n_f, c.srcB);
@@ -567,7 +571,7 @@ __device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __r
 	const float ev = p_in[(size_t)(n_e < 0 ? 0 : n_e) * 512 + c.srcA * 8 + (c.w ? 0 : 7)];
 	in.e_val = n_e < 0 ? 0.0f : ev;
 	// edge rows along z (lanes 0..7): tile rows (-1,-1), (-1,8), (8,-1), (8,8) of each leaf
-	const int n_er = rec[28 * c.ew + 1 + (c.ea ? 2 : 0) * 9 + (c.eb ? 2 : 0) * 3 + 1];
+	const int n_er = (single && c.ew) ? -1 : rec[28 * c.ew + 1 + (c.ea ? 2 : 0) * 9 + (c.eb ? 2 : 0) * 3 + 1];
 	if (l < 8) in.ER = glb_rowp(p_in, n_er, (c.ea ? 0 : 7) * 8 + (c.eb ? 0 : 7));
 	return in;
 }
@@ -577,6 +581,7 @@ __device__ __forceinline__ void pair_compute(PairTile& S, const PairLaneCtx& c, 
                                              const float omega) {
 	const int l = c.l, w = c.w, I = c.I;
 	const bool par = c.par;
+	const bool single = in.leaf1 < 0;  // wave-uniform
 	// ---- stage ----
 	pt_put(S, 0, I, in.P0);
 	pt_put(S, 1, I, in.P1);
@@ -593,23 +598,23 @@ __device__ __forceinline__ void pair_compute(PairTile& S, const PairLaneCtx& c, 
 	float zc;
 	{
 		const RowP hxm = pt_row(S, w, c.H_xm), hxp = pt_row(S, w, c.H_xp), hym = pt_row(S, w, c.H_ym), hyp = pt_row(S, w, c.H_yp);
-		const float other_lo = S.HI[0][c.RA].w, other_hi = S.LO[1][c.RA].x;
+		const float other_lo = S.HI[0][c.RA].w, other_hi = single ? S.ZP[c.RA] : S.LO[1][c.RA].x;
 		const float below = w ? other_lo : in.e_val;  // z=-1 of this halo row
 		const float above = w ? in.e_val : other_hi;  // z=8
 		hnew = row_sweep(hxp, hxm, hyp, hym, in.HA, below, above, in.HD, dx2, omega, !c.hpar, in.f_ok);
 	}
 	{
 		const RowP xm = pt_row(S, 0, c.R_xm), xp = pt_row(S, 0, c.R_xp), ym = pt_row(S, 0, c.R_ym), yp = pt_row(S, 0, c.R_yp);
-		c0 = row_sweep(xp, xm, yp, ym, in.P0, in.zlo.y, in.P1.q[0].x, in.D0, dx2, omega, !par, true);
+		c0 = row_sweep(xp, xm, yp, ym, in.P0, in.zlo.y, single ? in.zhi.x : in.P1.q[0].x, in.D0, dx2, omega, !par, true);
 	}
 	{
 		const RowP xm = pt_row(S, 1, c.R_xm), xp = pt_row(S, 1, c.R_xp), ym = pt_row(S, 1, c.R_ym), yp = pt_row(S, 1, c.R_yp);
-		c1 = row_sweep(xp, xm, yp, ym, in.P1, in.P0.q[3].y, in.zhi.x, in.D1, dx2, omega, !par, true);
+		c1 = row_sweep(xp, xm, yp, ym, in.P1, in.P0.q[3].y, in.zhi.x, in.D1, dx2, omega, !par, !single);
 	}
 	{
 		// z-halo red voxel: (x,y,-1) under leaf0 when par, else (x,y,8) over leaf1
 		const float* ZA = par ? S.ZM : S.ZP;
-		zc = sor_update(ZA[c.R_xp], ZA[c.R_xm], ZA[c.R_yp], ZA[c.R_ym], par ? in.P0.q[0].x : in.zhi.y, par ? in.zlo.x : in.P1.q[3].y, in.d_zh,
+		zc = sor_update(ZA[c.R_xp], ZA[c.R_xm], ZA[c.R_yp], ZA[c.R_ym], par ? in.P0.q[0].x : in.zhi.y, par ? in.zlo.x : (single ? in.P0.q[3].y : in.P1.q[3].y), in.d_zh,
 		                par ? in.zlo.y : in.zhi.x, dx2, omega);
 	}
 	// values just outside each row after the red sweep
@@ -624,12 +629,12 @@ __device__ __forceinline__ void pair_compute(PairTile& S, const PairLaneCtx& c, 
 	// ---- phase B ----
 	{
 		const RowP xm = pt_row(S, 0, c.R_xm), xp = pt_row(S, 0, c.R_xp), ym = pt_row(S, 0, c.R_ym), yp = pt_row(S, 0, c.R_yp);
-		const RowP o = row_sweep(xp, xm, yp, ym, c0, below0, c1.q[0].x, in.D0, dx2, omega, par, true);
+		const RowP o = row_sweep(xp, xm, yp, ym, c0, below0, single ? above1 : c1.q[0].x, in.D0, dx2, omega, par, true);
 		float4* q = reinterpret_cast<float4*>(p_out + (size_t)in.leaf0 * 512 + l * 8);
 		q[0] = make_float4(o.q[0].x, o.q[0].y, o.q[1].x, o.q[1].y);
 		q[1] = make_float4(o.q[2].x, o.q[2].y, o.q[3].x, o.q[3].y);
 	}
-	{
+	if (!single) {
 		const RowP xm = pt_row(S, 1, c.R_xm), xp = pt_row(S, 1, c.R_xp), ym = pt_row(S, 1, c.R_ym), yp = pt_row(S, 1, c.R_yp);
 		const RowP o = row_sweep(xp, xm, yp, ym, c1, c0.q[3].y, above1, in.D1, dx2, omega, par, true);
 		float4* q = reinterpret_cast<float4*>(p_out + (size_t)in.leaf1 * 512 + l * 8);
@@ -704,25 +709,14 @@ static void launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* d
                                   hipStream_t st, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
 	if (mode == 1) {
 		hipLaunchKernelGGL(k_rbgs_fused, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, src, dst, dx2, omega);
-	} else if (mode == 2 || !g->d_pairs) {
+	} else if (mode == 2 || !g->d_pairs || (mode == 0 && g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs)) {
+		// one leaf per wave: also the better choice for SMALL IRREGULAR grids, which are latency-bound (twice as many, shorter
+		// waves; no half-empty pair waves). Measured on the 3.9k-leaf plume: 9.0 vs 11.9 us per iteration.
 		hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_active), dim3(64), 0, st, gd, div, src, dst, dx2, omega);
 	} else {
-		// paired leaves and the unpaired remainder are disjoint, both read src and write dst: two independent launches
-		const bool par = side && g->n_pairs && g->n_singles;
-		if (par) {
-			(void)hipEventRecord(fork, st);
-			(void)hipStreamWaitEvent(side, fork, 0);
-		}
-		if (g->n_pairs) hipLaunchKernelGGL(k_rbgs_pair, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, src, dst, dx2, omega);
-		if (g->n_singles) {
-			GridDev gs = gd;
-			gs.blk = (const int*)g->d_singles;
-			hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_singles), dim3(64), 0, par ? side : st, gs, div, src, dst, dx2, omega);
-		}
-		if (par) {
-			(void)hipEventRecord(join, side);
-			(void)hipStreamWaitEvent(st, join, 0);
-		}
+		// one launch: the record list holds the z-adjacent pairs and, as {leaf, nbr27, -1, ...}, the leaves that found no partner
+		(void)side, (void)fork, (void)join;
+		hipLaunchKernelGGL(k_rbgs_pair, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, src, dst, dx2, omega);
 	}
 }
 
