@@ -95,6 +95,19 @@ class RankPlan:
     def peers(self) -> List[int]:
         return sorted(set(self.recv_ranges) | set(self.send_local))
 
+    @property
+    def mirror_only_peers(self) -> List[int]:
+        """Peers whose whole traffic with this rank is the mirror of global leaf 0 (only advect_scalars reads it)."""
+        out = []
+        for q in self.peers:
+            r0, r1 = self.recv_ranges.get(q, (0, 0))
+            recv_only_mirror = (r1 - r0 == 0) or (r1 - r0 == 1 and self.ghost_global[r0 - self.n_owned] == 0)
+            snd = self.send_local.get(q)
+            send_only_mirror = snd is None or (len(snd) == 1 and len(self.owned_global) and self.owned_global[snd[0]] == 0)
+            if recv_only_mirror and send_only_mirror:
+                out.append(q)
+        return out
+
 
 def partition_bounds(n_leaves: int, world: int) -> np.ndarray:
     return np.array([(n_leaves * r) // world for r in range(world + 1)], dtype=np.int64)
@@ -216,6 +229,7 @@ class HaloExchanger:
         self.plan, self.engine, self.group, self.dist, self.torch = plan, engine, group, dist, torch
         self.send_ids = {q: engine.ids(ids) for q, ids in plan.send_local.items()}
         self._bufs: Dict[Tuple[int, int], Tuple[object, object]] = {}
+        self._far = set(plan.mirror_only_peers)
 
     def _ncomp(self, f) -> int:
         return int(f.numel()) // (self.plan.n_local * LEAF_VOXELS)  # 1 = float field, 3 = Vec3f field
@@ -228,11 +242,14 @@ class HaloExchanger:
             self._bufs[key] = (self.engine.zeros(max(1, units * ns * LEAF_VOXELS)), self.engine.zeros(max(1, units * (r1 - r0) * LEAF_VOXELS)))
         return self._bufs[key]
 
-    def pack_sends(self, fields: Sequence) -> Dict[int, object]:
-        """Gather, per peer, the owned leaves it mirrors (all `fields` back to back) into that peer's send buffer."""
+    def pack_sends(self, fields: Sequence, mirror: bool = True) -> Dict[int, object]:
+        """Gather, per peer, the owned leaves it mirrors (all `fields` back to back) into that peer's send buffer.
+        mirror=False skips the peers that only exchange the mirror of global leaf 0."""
         comps = [self._ncomp(f) for f in fields]
         units, out = sum(comps), {}
         for q, ids in self.send_ids.items():
+            if not mirror and q in self._far:
+                continue
             sb, _ = self._buffers(q, units)
             ns, pos = len(self.plan.send_local[q]), 0
             for f, c in zip(fields, comps):
@@ -241,12 +258,14 @@ class HaloExchanger:
             out[q] = sb[:pos]
         return out
 
-    def recv_targets(self, fields: Sequence) -> Dict[int, object]:
+    def recv_targets(self, fields: Sequence, mirror: bool = True) -> Dict[int, object]:
         """Per peer, the tensor its message lands in: the ghost range itself for one field (ghosts of a peer are
         contiguous), a staging buffer for several."""
         comps = [self._ncomp(f) for f in fields]
         units, out = sum(comps), {}
         for q, (r0, r1) in self.plan.recv_ranges.items():
+            if not mirror and q in self._far:
+                continue
             if len(fields) == 1:
                 c = comps[0]
                 out[q] = fields[0].view(-1)[r0 * c * LEAF_VOXELS:r1 * c * LEAF_VOXELS]
@@ -254,28 +273,33 @@ class HaloExchanger:
                 out[q] = self._buffers(q, units)[1][: units * (r1 - r0) * LEAF_VOXELS]
         return out
 
-    def finish(self, fields: Sequence) -> None:
+    def finish(self, fields: Sequence, mirror: bool = True) -> None:
         if len(fields) == 1:
             return
         comps = [self._ncomp(f) for f in fields]
         units = sum(comps)
         for q, (r0, r1) in self.plan.recv_ranges.items():
+            if not mirror and q in self._far:
+                continue
             rb, nr, pos = self._buffers(q, units)[1], r1 - r0, 0
             for f, c in zip(fields, comps):
                 f.view(-1)[r0 * c * LEAF_VOXELS:r1 * c * LEAF_VOXELS].copy_(rb[pos:pos + c * nr * LEAF_VOXELS])
                 pos += c * nr * LEAF_VOXELS
 
-    def exchange(self, fields: Sequence) -> None:
-        """Refresh the ghost leaves of every tensor in `fields` (one message per peer carrying all of them)."""
+    def exchange(self, fields: Sequence, mirror: bool = True) -> None:
+        """Refresh the ghost leaves of every tensor in `fields` (one message per peer carrying all of them).
+        mirror=False leaves the mirror of global leaf 0 alone where that is a peer's only traffic: only advect_scalars reads
+        it, so the pressure / divergence / u* exchanges need not fan out from rank 0 to every rank."""
         if self.plan.world == 1 or not self.plan.peers:
             return
         dist = self.dist
-        sends, recvs = self.pack_sends(fields), self.recv_targets(fields)
+        sends, recvs = self.pack_sends(fields, mirror), self.recv_targets(fields, mirror)
         ops = [dist.P2POp(dist.isend, t, q, self.group) for q, t in sends.items()]
         ops += [dist.P2POp(dist.irecv, t, q, self.group) for q, t in recvs.items()]
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-        self.finish(fields)
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        self.finish(fields, mirror)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -330,17 +354,17 @@ class DistributedSolver:
             # the sweep right before an exchange need not touch the ghosts: they are overwritten anyway
             self.e.rbgs_iteration(self.div, src, dst, self.vs, self.omega, include_ghosts=not last_before_exchange)
             if last_before_exchange:
-                self.halo.exchange([dst])
+                self.halo.exchange([dst], mirror=False)
             src, dst = dst, src
         self.p = src
 
     def core_substep(self, iterations: int, dt: float) -> None:
         e, h = self.e, self.halo
-        h.exchange([self.u] + self.phi)
+        h.exchange([self.u] + self.phi)  # with the mirror of global leaf 0: advect_scalars reads phi's (and u's) element 0
         e.advect_vector(self.u, self.adv, dt, self.inv_dx)
-        h.exchange([self.adv])
+        h.exchange([self.adv], mirror=False)
         e.divergence(self.adv, self.div, self.inv_dx)
-        h.exchange([self.div])
+        h.exchange([self.div], mirror=False)
         self.pressure_solve(iterations)
         e.subtract_pressure_gradient(self.adv, self.p, self.u, self.inv_dx)
         h.exchange([self.u])
@@ -397,9 +421,9 @@ class SlabBench:
         e, h = s.e, s.halo
         h.exchange([s.u] + s.phi)
         e.advect_vector(s.u, s.adv, self.dt, s.inv_dx)
-        h.exchange([s.adv])
+        h.exchange([s.adv], mirror=False)
         e.divergence(s.adv, s.div, s.inv_dx)
-        h.exchange([s.div])
+        h.exchange([s.div], mirror=False)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         s.pressure_solve(self.iterations)

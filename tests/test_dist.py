@@ -47,6 +47,10 @@ def test_partition_properties():
                 assert np.array_equal(ghosts_from_q, sent)
             for q in p.send_local:
                 assert p.rank in plans[q].recv_ranges
+            # peers that only trade the mirror of global leaf 0: symmetric, and never a spatial neighbour
+            for q in p.mirror_only_peers:
+                assert p.rank in plans[q].mirror_only_peers
+                assert 0 in (p.rank, q)
 
 
 def test_slab_plan_matches_generic_plan():
@@ -173,7 +177,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("name,world", [("dense", 2), ("plume", 3)])
+@pytest.mark.parametrize("name,world", [("dense", 2), ("plume", 3), ("dense", 4)])
 def test_partitioned_substep_is_bit_identical_to_single_domain(tmp_path, name, world):
     import torch.multiprocessing as mp
 
