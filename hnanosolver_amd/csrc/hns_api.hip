@@ -64,8 +64,7 @@ int hns_grid_upload_schedule(hns_grid* g) {
 		g->d_blk = nullptr;
 	}
 	if (g->d_pairs) hipFree(g->d_pairs);
-	if (g->d_singles) hipFree(g->d_singles);
-	g->d_pairs = g->d_singles = nullptr;
+	g->d_pairs = nullptr;
 	g->n_pairs = g->n_singles = 0;
 	for (auto& e : g->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);  // captured launches hold the old lists
 	g->graphs.clear();
@@ -167,18 +166,14 @@ void hns_grid_free_device(hns_grid* g) {
 	for (auto& e : g->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);
 	g->graphs.clear();
 	if (g->cap_stream) (void)hipStreamDestroy((hipStream_t)g->cap_stream);
-	if (g->cap_side) (void)hipStreamDestroy((hipStream_t)g->cap_side);
-	if (g->cap_fork) (void)hipEventDestroy((hipEvent_t)g->cap_fork);
-	if (g->cap_join) (void)hipEventDestroy((hipEvent_t)g->cap_join);
-	g->cap_stream = g->cap_side = g->cap_fork = g->cap_join = nullptr;
+	g->cap_stream = nullptr;
 	if (g->d_origins) hipFree(g->d_origins);
 	if (g->d_nbr27) hipFree(g->d_nbr27);
 	if (g->d_hash) hipFree(g->d_hash);
 	if (g->d_sched) hipFree(g->d_sched);
 	if (g->d_blk) hipFree(g->d_blk);
 	if (g->d_pairs) hipFree(g->d_pairs);
-	if (g->d_singles) hipFree(g->d_singles);
-	g->d_origins = g->d_nbr27 = g->d_hash = g->d_sched = g->d_blk = g->d_pairs = g->d_singles = nullptr;
+	g->d_origins = g->d_nbr27 = g->d_hash = g->d_sched = g->d_blk = g->d_pairs = nullptr;
 	g->on_device = false;
 }
 

@@ -79,13 +79,9 @@ struct hns_grid {
 	void* d_sched = nullptr;
 	void* d_blk = nullptr;
 	void* d_pairs = nullptr;    // launch-ordered wave records {leaf0, nbr27, leaf1 or -1, nbr27} (56 ints): z-adjacent pairs and lone leaves
-	void* d_singles = nullptr;  // unused (kept for ABI of the struct)
 	uint64_t n_pairs = 0, n_singles = 0;  // waves to launch / how many of them carry a lone leaf
 	std::vector<hns::RbgsGraph> graphs;  // cached hipGraph replays of the pressure loop (dropped when the schedule changes)
-	void* cap_stream = nullptr;          // private capture streams / events
-	void* cap_side = nullptr;
-	void* cap_fork = nullptr;
-	void* cap_join = nullptr;
+	void* cap_stream = nullptr;          // private capture stream
 	hns::GridDev dev() const;
 };
 

@@ -704,9 +704,9 @@ int hns_dev_rbgs_color(hns_grid* g, const float* div, float* p, float dx, float 
 	return launch_status("hns_dev_rbgs_color");
 }
 
-// one full (red, black) iteration src -> dst; `side` (may be null) carries the unpaired leaves concurrently when capturing
+// one full (red, black) iteration src -> dst
 static void launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* div, const float* src, float* dst, float dx2, float omega, int mode,
-                                  hipStream_t st, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
+                                  hipStream_t st) {
 	if (mode == 1) {
 		hipLaunchKernelGGL(k_rbgs_fused, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, src, dst, dx2, omega);
 	} else if (mode == 2 || !g->d_pairs || (mode == 0 && g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs)) {
@@ -715,7 +715,6 @@ static void launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* d
 		hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_active), dim3(64), 0, st, gd, div, src, dst, dx2, omega);
 	} else {
 		// one launch: the record list holds the z-adjacent pairs and, as {leaf, nbr27, -1, ...}, the leaves that found no partner
-		(void)side, (void)fork, (void)join;
 		hipLaunchKernelGGL(k_rbgs_pair, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, src, dst, dx2, omega);
 	}
 }
@@ -741,19 +740,14 @@ int hns_dev_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, 
 		for (auto& e : g->graphs)
 			if (e.div == div && e.p_a == p_a && e.p_b == p_b && e.dx2 == dx2 && e.omega == omega && e.iterations == iterations && e.mode == mode) hit = &e;
 		if (!hit) {
-			if (!g->cap_stream) {
-				HNS_HIP(hipStreamCreateWithFlags((hipStream_t*)&g->cap_stream, hipStreamNonBlocking));
-				HNS_HIP(hipStreamCreateWithFlags((hipStream_t*)&g->cap_side, hipStreamNonBlocking));
-				HNS_HIP(hipEventCreateWithFlags((hipEvent_t*)&g->cap_fork, hipEventDisableTiming));
-				HNS_HIP(hipEventCreateWithFlags((hipEvent_t*)&g->cap_join, hipEventDisableTiming));
-			}
+			if (!g->cap_stream) HNS_HIP(hipStreamCreateWithFlags((hipStream_t*)&g->cap_stream, hipStreamNonBlocking));
 			hipStream_t cs = (hipStream_t)g->cap_stream;
 			hipGraph_t graph = nullptr;
 			HNS_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
 			float* src = p_a;
 			float* dst = p_b;
 			for (int it = 0; it < iterations; ++it) {
-				launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode, cs, (hipStream_t)g->cap_side, (hipEvent_t)g->cap_fork, (hipEvent_t)g->cap_join);
+				launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode, cs);
 				float* tmp = src;
 				src = dst;
 				dst = tmp;
@@ -780,7 +774,7 @@ int hns_dev_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, 
 	float* src = p_a;
 	float* dst = p_b;
 	for (int it = 0; it < iterations; ++it) {
-		launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode, (hipStream_t)stream, nullptr, nullptr, nullptr);
+		launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode, (hipStream_t)stream);
 		float* tmp = src;
 		src = dst;
 		dst = tmp;
