@@ -559,16 +559,30 @@ __device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __r
 	in.zh_ok = n_zh >= 0;
 	in.d_zh = div[(size_t)(n_zh < 0 ? 0 : n_zh) * 512 + l * 8 + (c.par ? 7 : 0)];
 	// halo-row duty: lanes 0..31 -> leaf0, 32..63 -> leaf1; 4 faces x 8 rows each. For a leaf travelling alone lanes 32..63
-	// have no rows to recompute; they only fetch the z=8 neighbours of leaf0's halo rows (slotE = face neighbour one up).
-	const int* __restrict__ nb = rec + (single ? 0 : 28 * c.w) + 1;
-	const int n_f = (single && c.w) ? -1 : nb[c.slotF];
+	// have no rows to recompute; they only fetch the z=8 neighbours of leaf0's halo rows (the face neighbour one leaf up).
+	// The neighbour ids are wave-uniform: they come from scalar loads of the record and are picked per lane with selects,
+	// so that no vector load sits between the record and the halo loads (one dependent memory level instead of three).
+	const int f = (l >> 3) & 3, i = l & 7;
+	const int* __restrict__ r0 = rec + 1;                      // neighbour table of leaf0
+	const int* __restrict__ r1 = rec + (single ? 1 : 29);      // ... of the leaf whose halo rows lanes 32..63 serve
+	const int a0 = r0[4], a1 = r0[22], a2 = r0[10], a3 = r0[16];    // faces -x,+x,-y,+y of leaf0
+	const int b0 = r1[4], b1 = r1[22], b2 = r1[10], b3 = r1[16];
+	const int c0 = r0[3], c1 = r0[21], c2 = r0[9], c3 = r0[15];     // the same faces one leaf down (dz = -1)
+	const int d0 = r1[5], d1 = r1[23], d2 = r1[11], d3 = r1[17];    // ... one leaf up (dz = +1)
+	const int nf0 = f == 0 ? a0 : (f == 1 ? a1 : (f == 2 ? a2 : a3));
+	const int nf1 = f == 0 ? b0 : (f == 1 ? b1 : (f == 2 ? b2 : b3));
+	const int ne0 = f == 0 ? c0 : (f == 1 ? c1 : (f == 2 ? c2 : c3));
+	const int ne1 = f == 0 ? d0 : (f == 1 ? d1 : (f == 2 ? d2 : d3));
+	const int n_f = c.w ? (single ? -1 : nf1) : nf0;
+	const int srcA = f == 0 ? 56 + i : (f == 1 ? i : (f == 2 ? i * 8 + 7 : i * 8));
+	const int srcB = f == 0 ? 48 + i : (f == 1 ? 8 + i : (f == 2 ? i * 8 + 6 : i * 8 + 1));
 	in.f_ok = n_f >= 0;
-	in.HA = glb_rowp(p_in, n_f, c.srcA);
-	in.HB = glb_rowp(p_in, n_f, c.srcB);
-	in.HD = glb_rowp(div, n_f, c.srcA);
+	in.HA = glb_rowp(p_in, n_f, srcA);
+	in.HB = glb_rowp(p_in, n_f, srcB);
+	in.HD = glb_rowp(div, n_f, srcA);
 	// the halo row's own z-neighbour outside the pair: z=-1 for the lower leaf, z=8 for the upper leaf
-	const int n_e = nb[c.slotE];
-	const float ev = p_in[(size_t)(n_e < 0 ? 0 : n_e) * 512 + c.srcA * 8 + (c.w ? 0 : 7)];
+	const int n_e = c.w ? ne1 : ne0;
+	const float ev = p_in[(size_t)(n_e < 0 ? 0 : n_e) * 512 + srcA * 8 + (c.w ? 0 : 7)];
 	in.e_val = n_e < 0 ? 0.0f : ev;
 	// edge rows along z (lanes 0..7): tile rows (-1,-1), (-1,8), (8,-1), (8,8) of each leaf
 	const int n_er = (single && c.ew) ? -1 : rec[28 * c.ew + 1 + (c.ea ? 2 : 0) * 9 + (c.eb ? 2 : 0) * 3 + 1];
