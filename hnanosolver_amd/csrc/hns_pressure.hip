@@ -471,29 +471,24 @@ __device__ __forceinline__ RowP row_sweep(const RowP& xp, const RowP& xm, const 
 
 // Per-lane constants of k_rbgs_pair (halo-row duty of lane l), generated at compile time so that the kernel reads them
 // with two 16-byte loads instead of ~100 instructions of lane-dependent index arithmetic.
-struct PairLane {
-	int slotF, srcA, srcB, RA, RB, H_xm, H_xp, H_ym, H_yp, slotE, hpar, pad;
-};
+// LDS row numbers of lane l's halo-row duty, packed 8 bits each into two dwords (one 8-byte load per lane):
+//   lo = RA | RB<<8 | H_xm<<16 | H_xp<<24,   hi = H_ym | H_yp<<8 | hpar<<16
 struct PairLaneTab {
-	PairLane t[64];
+	unsigned t[64][2];
 };
 constexpr PairLaneTab make_pair_lane_tab() {
 	PairLaneTab T{};
 	for (int l = 0; l < 64; ++l) {
-		const int w = l >> 5, h = l & 31, f = h >> 3, i = h & 7;
-		PairLane& e = T.t[l];
-		e.slotF = f == 0 ? 4 : (f == 1 ? 22 : (f == 2 ? 10 : 16));
-		e.srcA = f == 0 ? 56 + i : (f == 1 ? i : (f == 2 ? i * 8 + 7 : i * 8));
-		e.srcB = f == 0 ? 48 + i : (f == 1 ? 8 + i : (f == 2 ? i * 8 + 6 : i * 8 + 1));
-		e.RA = f == 0 ? i : (f == 1 ? 72 + i : (f == 2 ? 87 + 8 * i : 96 + 8 * i));
-		e.RB = 89 + 8 * (h / 6) + (h % 6);
-		e.H_xm = f == 0 ? e.RB : (f == 1 ? 64 + i : (i == 0 ? (f == 2 ? 81 : 82) : (f == 2 ? 87 + 8 * (i - 1) : 96 + 8 * (i - 1))));
-		e.H_xp = f == 1 ? e.RB : (f == 0 ? 8 + i : (i == 7 ? (f == 2 ? 83 : 84) : (f == 2 ? 87 + 8 * (i + 1) : 96 + 8 * (i + 1))));
-		e.H_ym = f == 2 ? e.RB : (f == 3 ? 8 * (i + 1) + 7 : (i == 0 ? (f == 0 ? 81 : 83) : (f == 0 ? i - 1 : 72 + i - 1)));
-		e.H_yp = f == 3 ? e.RB : (f == 2 ? 8 * (i + 1) : (i == 7 ? (f == 0 ? 82 : 84) : (f == 0 ? i + 1 : 72 + i + 1)));
-		e.slotE = e.slotF + (w ? 1 : -1);              // the face neighbour one leaf further along -z (lower leaf) / +z (upper leaf)
-		e.hpar = (i + ((f & 1) ? 0 : 1)) & 1;          // parity of the halo row's x+y: faces -x,-y sit at coordinate -1
-		e.pad = 0;
+		const int h = l & 31, f = h >> 3, i = h & 7;
+		const int RA = f == 0 ? i : (f == 1 ? 72 + i : (f == 2 ? 87 + 8 * i : 96 + 8 * i));
+		const int RB = 89 + 8 * (h / 6) + (h % 6);
+		const int H_xm = f == 0 ? RB : (f == 1 ? 64 + i : (i == 0 ? (f == 2 ? 81 : 82) : (f == 2 ? 87 + 8 * (i - 1) : 96 + 8 * (i - 1))));
+		const int H_xp = f == 1 ? RB : (f == 0 ? 8 + i : (i == 7 ? (f == 2 ? 83 : 84) : (f == 2 ? 87 + 8 * (i + 1) : 96 + 8 * (i + 1))));
+		const int H_ym = f == 2 ? RB : (f == 3 ? 8 * (i + 1) + 7 : (i == 0 ? (f == 0 ? 81 : 83) : (f == 0 ? i - 1 : 72 + i - 1)));
+		const int H_yp = f == 3 ? RB : (f == 2 ? 8 * (i + 1) : (i == 7 ? (f == 0 ? 82 : 84) : (f == 0 ? i + 1 : 72 + i + 1)));
+		const int hpar = (i + ((f & 1) ? 0 : 1)) & 1;  // parity of the halo row's x+y: faces -x,-y sit at coordinate -1
+		T.t[l][0] = (unsigned)RA | ((unsigned)RB << 8) | ((unsigned)H_xm << 16) | ((unsigned)H_xp << 24);
+		T.t[l][1] = (unsigned)H_ym | ((unsigned)H_yp << 8) | ((unsigned)hpar << 16);
 	}
 	return T;
 }
@@ -516,7 +511,7 @@ struct PairIn {
 struct PairLaneCtx {
 	int l, x, y, w, I, R_xm, R_xp, R_ym, R_yp;
 	bool par;
-	int slotF, srcA, srcB, RA, RB, H_xm, H_xp, H_ym, H_yp, slotE;
+	int RA, RB, H_xm, H_xp, H_ym, H_yp;
 	bool hpar;
 	int ew, ea, eb;
 };
@@ -527,10 +522,10 @@ __device__ __forceinline__ PairLaneCtx pair_lane_ctx() {
 	c.x = c.l >> 3, c.y = c.l & 7;
 	c.par = (c.x + c.y) & 1;  // false: even z red, true: odd z red (both leaves: their z origins differ by 8)
 	c.w = c.l >> 5;
-	const int4* __restrict__ lt = reinterpret_cast<const int4*>(&g_pair_lane_tab.t[c.l]);
-	const int4 t0 = lt[0], t1 = lt[1], t2 = lt[2];
-	c.slotF = t0.x, c.srcA = t0.y, c.srcB = t0.z, c.RA = t0.w, c.RB = t1.x, c.H_xm = t1.y, c.H_xp = t1.z, c.H_ym = t1.w, c.H_yp = t2.x, c.slotE = t2.y;
-	c.hpar = t2.z;
+	const uint2 lt = *reinterpret_cast<const uint2*>(&g_pair_lane_tab.t[c.l][0]);
+	c.RA = lt.x & 255, c.RB = (lt.x >> 8) & 255, c.H_xm = (lt.x >> 16) & 255, c.H_xp = lt.x >> 24;
+	c.H_ym = lt.y & 255, c.H_yp = (lt.y >> 8) & 255;
+	c.hpar = (lt.y >> 16) & 1;
 	c.ew = (c.l >> 2) & 1, c.ea = (c.l >> 1) & 1, c.eb = c.l & 1;
 	c.I = 8 * (c.x + 1) + c.y;
 	c.R_xm = c.I - 8, c.R_xp = c.I + 8, c.R_ym = c.y == 0 ? 87 + 8 * c.x : c.I - 1, c.R_yp = c.y == 7 ? 96 + 8 * c.x : c.I + 1;
