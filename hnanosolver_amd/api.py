@@ -172,6 +172,18 @@ class IndexGridHandle:
     def set_active_leaves(self, n: int) -> None:
         _raise(lib.hns_grid_set_active_leaves(self._ptr, int(n)))
 
+    def active_leaves(self) -> int:
+        return int(lib.hns_grid_active_leaves(self._ptr)) if self._ptr else 0
+
+    def launch_tables(self):
+        """(sched, wave_records, n_lone): copies of the device-built launch order (inspection / tests)."""
+        nw, nl = C.c_uint64(0), C.c_uint64(0)
+        _raise(lib.hns_grid_launch_tables(self._ptr, None, None, C.byref(nw), C.byref(nl)))
+        sched = np.zeros((self.active_leaves(),), dtype=np.int32)
+        recs = np.zeros((nw.value, 56), dtype=np.int32)
+        _raise(lib.hns_grid_launch_tables(self._ptr, sched.ctypes.data, recs.ctypes.data, None, None))
+        return sched, recs, int(nl.value)
+
     def set_outside_element(self, element_index: int) -> None:
         _raise(lib.hns_grid_set_outside_element(self._ptr, int(element_index)))
 

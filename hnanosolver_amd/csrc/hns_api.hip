@@ -1,4 +1,4 @@
-// hns_api.hip -- device upload of the index grid, the device-resident simulation state, and the drop-in operators of
+// hns_api.hip -- the device-resident simulation state and the drop-in operators of
 // include/hns.h. The launch orders follow the reference's host drivers (reference src/Cuda/HNanoSolver.cu:150-356,
 // src/Cuda/PressureProjection.cu:43-66, src/Cuda/Advection.cu:76-91,148-155); what differs is that fields can stay
 // resident across substeps and that nothing is allocated inside a substep.
@@ -48,133 +48,6 @@ extern "C" int hns_device_count(void) {
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
 	return n;
-}
-
-// Block -> leaf order. The dispatcher places workgroup b on XCD b % 8 (observed, not contractual), each XCD has a
-// private 4 MiB L2, and a leaf's halo is its neighbours' payload: give every XCD one contiguous chunk of the leaf
-// list so that halo reads hit the L2 that already holds (or will shortly hold) those leaves. Speed only; any order is
-// correct. HNS_SCHEDULE=linear disables it.
-int hns_grid_upload_schedule(hns_grid* g) {
-	if (g->d_sched) {
-		hipFree(g->d_sched);
-		g->d_sched = nullptr;
-	}
-	if (g->d_blk) {
-		hipFree(g->d_blk);
-		g->d_blk = nullptr;
-	}
-	if (g->d_pairs) hipFree(g->d_pairs);
-	g->d_pairs = nullptr;
-	g->n_pairs = g->n_singles = 0;
-	for (auto& e : g->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);  // captured launches hold the old lists
-	g->graphs.clear();
-	const int64_t n = (int64_t)g->n_active;
-	if (n == 0) return HNS_OK;
-	const char* mode = getenv("HNS_SCHEDULE");
-	const bool linear = mode && strcmp(mode, "linear") == 0;
-	const int nx = 8;
-	const int64_t chunk = (n + nx - 1) / nx;
-	std::vector<int32_t> sched;
-	sched.reserve((size_t)n);
-	if (linear) {
-		for (int64_t l = 0; l < n; ++l) sched.push_back((int32_t)l);
-	} else {
-		for (int64_t i = 0; i < chunk; ++i)
-			for (int x = 0; x < nx; ++x) {
-				const int64_t l = x * chunk + i;
-				if (l < n) sched.push_back((int32_t)l);
-			}
-	}
-	// launch-ordered records {leaf, nbr27}: the one-wave-per-leaf SOR kernel reads its whole topology with one fetch
-	std::vector<int32_t> blk((size_t)n * 28);
-	for (int64_t b = 0; b < n; ++b) {
-		const int32_t l = sched[(size_t)b];
-		blk[(size_t)b * 28] = l;
-		memcpy(&blk[(size_t)b * 28 + 1], &g->topo.nbr27[(size_t)l * 27], 27 * sizeof(int32_t));
-	}
-	HNS_HIP(hipMalloc(&g->d_blk, sizeof(int32_t) * blk.size()));
-	HNS_HIP(hipMemcpy(g->d_blk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
-	// z-adjacent pairs for k_rbgs_pair: walk the schedule, pair a leaf with its +z neighbour when both are active and unpaired
-	{
-		std::vector<char> used((size_t)n, 0);
-		std::vector<int32_t> recs;  // 56 ints per wave: {leaf0, nbr27, leaf1 or -1, nbr27}
-		recs.reserve((size_t)n * 28);
-		auto put = [&](int32_t l) {
-			recs.push_back(l);
-			if (l >= 0)
-				recs.insert(recs.end(), g->topo.nbr27.begin() + (size_t)l * 27, g->topo.nbr27.begin() + (size_t)l * 27 + 27);
-			else
-				recs.insert(recs.end(), 27, -1);
-		};
-		uint64_t n_single = 0;
-		for (int64_t b = 0; b < n; ++b) {
-			const int32_t l = sched[(size_t)b];
-			if (used[(size_t)l]) continue;
-			const int32_t up = g->topo.nbr27[(size_t)l * 27 + 14];
-			const int32_t dn = g->topo.nbr27[(size_t)l * 27 + 12];
-			used[(size_t)l] = 1;
-			if (up >= 0 && up < n && !used[(size_t)up]) {
-				used[(size_t)up] = 1;
-				put(l);
-				put(up);
-			} else if (dn >= 0 && dn < n && !used[(size_t)dn]) {
-				used[(size_t)dn] = 1;
-				put(dn);
-				put(l);
-			} else {  // no free partner: the leaf travels alone in its wave
-				put(l);
-				put(-1);
-				++n_single;
-			}
-		}
-		g->n_pairs = recs.size() / 56;  // waves to launch
-		g->n_singles = n_single;
-		if (g->n_pairs) {
-			HNS_HIP(hipMalloc(&g->d_pairs, sizeof(int32_t) * recs.size()));
-			HNS_HIP(hipMemcpy(g->d_pairs, recs.data(), sizeof(int32_t) * recs.size(), hipMemcpyHostToDevice));
-		}
-	}
-	if (linear) return HNS_OK;
-	HNS_HIP(hipMalloc(&g->d_sched, sizeof(int32_t) * (size_t)n));
-	HNS_HIP(hipMemcpy(g->d_sched, sched.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
-	return HNS_OK;
-}
-
-int hns_grid_upload(hns_grid* g) {
-	int ndev = 0;
-	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-		set_error("hns_grid: no HIP device available (libhns has no CPU fallback; pass HNS_GRID_HOST_ONLY for topology-only use)");
-		return HNS_ERR_NO_DEVICE;
-	}
-	HNS_HIP(hipGetDevice(&g->device));
-	const Topology& t = g->topo;
-	const size_t nl = (size_t)(t.n_leaves > 0 ? t.n_leaves : 1);
-	HNS_HIP(hipMalloc(&g->d_origins, sizeof(int32_t) * 4 * nl));
-	HNS_HIP(hipMalloc(&g->d_nbr27, sizeof(int32_t) * 27 * nl));
-	HNS_HIP(hipMalloc(&g->d_hash, sizeof(int32_t) * t.hash.size()));
-	if (t.n_leaves > 0) {
-		HNS_HIP(hipMemcpy(g->d_origins, t.origins.data(), sizeof(int32_t) * 4 * nl, hipMemcpyHostToDevice));
-		HNS_HIP(hipMemcpy(g->d_nbr27, t.nbr27.data(), sizeof(int32_t) * 27 * nl, hipMemcpyHostToDevice));
-	}
-	HNS_HIP(hipMemcpy(g->d_hash, t.hash.data(), sizeof(int32_t) * t.hash.size(), hipMemcpyHostToDevice));
-	g->on_device = true;
-	return hns_grid_upload_schedule(g);
-}
-
-void hns_grid_free_device(hns_grid* g) {
-	if (!g) return;
-	for (auto& e : g->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);
-	g->graphs.clear();
-	if (g->cap_stream) (void)hipStreamDestroy((hipStream_t)g->cap_stream);
-	g->cap_stream = nullptr;
-	if (g->d_origins) hipFree(g->d_origins);
-	if (g->d_nbr27) hipFree(g->d_nbr27);
-	if (g->d_hash) hipFree(g->d_hash);
-	if (g->d_sched) hipFree(g->d_sched);
-	if (g->d_blk) hipFree(g->d_blk);
-	if (g->d_pairs) hipFree(g->d_pairs);
-	g->d_origins = g->d_nbr27 = g->d_hash = g->d_sched = g->d_blk = g->d_pairs = nullptr;
-	g->on_device = false;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,322 @@
+// hns_gridbuild.hip -- index-grid construction on the device.
+//
+// The reference rebuilds its NanoGrid<ValueOnIndex> on the GPU every cook (create_index_grid, reference
+// src/Cuda/HNanoSolver.cu:375-384 -> externals/nanovdb/tools/cuda/PointsToGrid.cuh:511-1064: ~25 launches and 8 CUB
+// sorts/scans over all N voxel coordinates). Here only the leaf origins (one coordinate in 512) cross PCIe; the origin
+// hash, the 27-neighbour table and the launch-ordered wave records the kernels read are built by five small kernels
+// over the leaves. Integer work only; tests/test_gridbuild_gpu.py checks every table against the host builder of
+// hns_topology.cpp.
+#include <cstdlib>
+#include <cstring>
+
+#include "hns_device.hpp"
+
+namespace hns {
+
+// ---------------------------------------------------------------------------------------------------------------
+// origin hash + neighbour table
+// ---------------------------------------------------------------------------------------------------------------
+
+// One thread per leaf: linear-probe insert with compare-and-swap. Entries are never removed, so a probe that meets
+// an occupied slot can compare origins safely. status[0] receives the smallest leaf index that found its origin
+// already present (INT_MAX when none).
+__global__ __launch_bounds__(256) void k_hash_insert(const int4* __restrict__ origins, int n, int* __restrict__ hash, uint32_t mask, int* __restrict__ status) {
+	const int l = blockIdx.x * 256 + threadIdx.x;
+	if (l >= n) return;
+	const int4 o = origins[l];
+	uint32_t s = d_hash_origin(o.x, o.y, o.z) & mask;
+	for (;;) {
+		int cur = hash[s];
+		if (cur < 0) {
+			cur = atomicCAS(&hash[s], -1, l);
+			if (cur < 0) return;  // slot was empty and is now ours
+		}
+		const int4 q = origins[cur];
+		if (q.x == o.x && q.y == o.y && q.z == o.z) {
+			atomicMin(status, l > cur ? l : cur);
+			return;
+		}
+		s = (s + 1) & mask;
+	}
+}
+
+// One thread per (leaf, neighbour slot). 64-bit arithmetic so that origins at the int32 edge cannot wrap into a
+// valid neighbour (same guard as Topology::build_tables).
+__global__ __launch_bounds__(256) void k_build_nbr27(GridDev g, int* __restrict__ nbr27) {
+	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (t >= (int64_t)g.n_leaves * 27) return;
+	const int l = (int)(t / 27), j = (int)(t % 27);
+	const int4 o = g.origins[l];
+	const int64_t nx = (int64_t)o.x + 8 * (j / 9 - 1), ny = (int64_t)o.y + 8 * ((j / 3) % 3 - 1), nz = (int64_t)o.z + 8 * (j % 3 - 1);
+	int nb = -1;
+	if (nx >= INT32_MIN && nx <= INT32_MAX && ny >= INT32_MIN && ny <= INT32_MAX && nz >= INT32_MIN && nz <= INT32_MAX)
+		nb = d_find_leaf(g, (int)nx, (int)ny, (int)nz);
+	nbr27[t] = nb;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launch order
+// ---------------------------------------------------------------------------------------------------------------
+
+// Block -> leaf order. The dispatcher places workgroup b on XCD b % 8 (observed, not contractual), each XCD has a
+// private 4 MiB L2, and a leaf's halo is its neighbours' payload: every XCD gets one contiguous chunk of the leaf
+// list (sizes differ by at most one leaf), so halo reads hit the L2 that already holds those leaves. Speed only; any
+// order is correct. HNS_SCHEDULE=linear disables it.
+__host__ __device__ inline int sched_leaf(int b, int n, bool linear) {
+	if (linear) return b;
+	const int base = n >> 3, rem = n & 7;
+	const int x = b & 7, i = b >> 3;  // rows i < base hold all eight XCDs; the last row only x < rem, and b - 8*base == x there
+	return x * base + (x < rem ? x : rem) + i;
+}
+
+// {leaf, nbr27[27]} per block in launch order: the kernels that work one leaf per workgroup read their whole
+// topology with one fetch.
+__global__ __launch_bounds__(256) void k_build_blk(const int* __restrict__ nbr27, int n_active, int linear, int* __restrict__ sched, int* __restrict__ blk) {
+	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (t >= (int64_t)n_active * 28) return;
+	const int b = (int)(t / 28), j = (int)(t % 28);
+	const int l = sched_leaf(b, n_active, linear != 0);
+	if (j == 0) {
+		blk[t] = l;
+		if (sched) sched[b] = l;
+	} else {
+		blk[t] = nbr27[(size_t)l * 27 + (j - 1)];
+	}
+}
+
+// z-adjacent pairs for the one-wave-per-pair SOR kernel. A z-run is a maximal chain of active leaves linked through
+// their -z/+z neighbours; counting from the bottom of its run, an even leaf heads a wave and takes the leaf above it
+// as partner (none: the leaf travels alone), an odd leaf is that partner. The rule needs no ordering between leaves,
+// leaves the fewest possible lone leaves, and reproduces the aligned (0,1),(2,3).. pairs on a dense grid.
+__device__ __forceinline__ int pair_partner(const int* __restrict__ nbr27, int n_active, int l) {
+	int steps = 0;
+	for (int m = l;;) {
+		const int dn = nbr27[(size_t)m * 27 + 12];
+		if (dn < 0 || dn >= n_active) break;
+		m = dn;
+		++steps;
+	}
+	if (steps & 1) return -2;  // not a head
+	const int up = nbr27[(size_t)l * 27 + 14];
+	return (up >= 0 && up < n_active) ? up : -1;
+}
+
+// pass 1: partner[b] for schedule position b, and the number of wave heads / lone leaves per 256-position block
+__global__ __launch_bounds__(256) void k_pair_heads(const int* __restrict__ nbr27, int n_active, int linear, int* __restrict__ partner, int* __restrict__ block_heads,
+                                                    int* __restrict__ totals) {
+	__shared__ int s_cnt[2];
+	if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	const int b = blockIdx.x * 256 + threadIdx.x;
+	int p = -2;
+	if (b < n_active) {
+		p = pair_partner(nbr27, n_active, sched_leaf(b, n_active, linear != 0));
+		partner[b] = p;
+	}
+	const unsigned long long heads = __ballot(p != -2), lone = __ballot(p == -1);
+	if ((threadIdx.x & 63) == 0) {
+		atomicAdd(&s_cnt[0], __popcll(heads));
+		atomicAdd(&s_cnt[1], __popcll(lone));
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		block_heads[blockIdx.x] = s_cnt[0];
+		atomicAdd(&totals[0], s_cnt[0]);
+		atomicAdd(&totals[1], s_cnt[1]);
+	}
+}
+
+// pass 2: exclusive scan of the per-block head counts (one workgroup; at most 2^22 / 256 = 16384 entries)
+__global__ __launch_bounds__(1024) void k_scan_blocks(int* __restrict__ block_heads, int n_blocks) {
+	__shared__ int s_part[1024];
+	const int per = (n_blocks + 1023) / 1024;
+	const int lo = threadIdx.x * per, hi = min(n_blocks, lo + per);
+	int sum = 0;
+	for (int i = lo; i < hi; ++i) sum += block_heads[i];
+	s_part[threadIdx.x] = sum;
+	__syncthreads();
+	for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+		const int v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+		__syncthreads();
+		s_part[threadIdx.x] += v;
+		__syncthreads();
+	}
+	int run = s_part[threadIdx.x] - sum;
+	for (int i = lo; i < hi; ++i) {
+		const int c = block_heads[i];
+		block_heads[i] = run;
+		run += c;
+	}
+}
+
+// pass 3: wave records {leaf0, nbr27, leaf1 or -1, nbr27} (56 ints) in schedule order of their head leaf
+__global__ __launch_bounds__(256) void k_write_pairs(const int* __restrict__ nbr27, int n_active, int linear, const int* __restrict__ partner,
+                                                     const int* __restrict__ block_base, int* __restrict__ recs) {
+	__shared__ int s_wave[4];
+	const int b = blockIdx.x * 256 + threadIdx.x;
+	const int p = b < n_active ? partner[b] : -2;
+	const unsigned long long heads = __ballot(p != -2);
+	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	if (lane == 0) s_wave[w] = __popcll(heads);
+	__syncthreads();
+	int pos = block_base[blockIdx.x] + __popcll(heads & ((1ull << lane) - 1ull));
+	for (int i = 0; i < w; ++i) pos += s_wave[i];
+	if (p == -2) return;
+	const int l = sched_leaf(b, n_active, linear != 0);
+	int* r = recs + (size_t)pos * 56;
+	r[0] = l;
+	r[28] = p;
+	for (int j = 0; j < 27; ++j) {
+		r[1 + j] = nbr27[(size_t)l * 27 + j];
+		r[29 + j] = p < 0 ? -1 : nbr27[(size_t)p * 27 + j];
+	}
+}
+
+}  // namespace hns
+
+using namespace hns;
+
+static void free_ptr(void*& p) {
+	if (p) (void)hipFree(p);
+	p = nullptr;
+}
+
+// Launch order tables for the current n_active: d_sched, d_blk, d_pairs, n_pairs, n_singles. Called at build time and
+// whenever hns_grid_set_active_leaves changes the active prefix.
+int hns_grid_upload_schedule(hns_grid* g) {
+	free_ptr(g->d_sched);
+	free_ptr(g->d_blk);
+	free_ptr(g->d_pairs);
+	g->n_pairs = g->n_singles = 0;
+	for (auto& e : g->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);  // captured launches hold the old lists
+	g->graphs.clear();
+	const int n = (int)g->n_active;
+	if (n == 0) return HNS_OK;
+	const char* mode = getenv("HNS_SCHEDULE");
+	const int linear = mode && strcmp(mode, "linear") == 0;
+	const int* nbr27 = (const int*)g->d_nbr27;
+	const int n_blocks = (n + 255) / 256;
+	int *partner = nullptr, *block_heads = nullptr, *totals = nullptr;
+	HNS_HIP(hipMalloc(&g->d_blk, sizeof(int) * 28 * (size_t)n));
+	if (!linear) HNS_HIP(hipMalloc(&g->d_sched, sizeof(int) * (size_t)n));
+	// one scratch allocation: partner[n] | block_heads[n_blocks] | totals[2]
+	HNS_HIP(hipMalloc(&partner, sizeof(int) * ((size_t)n + n_blocks + 2)));
+	block_heads = partner + n;
+	totals = block_heads + n_blocks;
+	int rc = HNS_OK;
+	int h_totals[2] = {0, 0};
+	do {
+		hipError_t e = hipMemsetAsync(totals, 0, 2 * sizeof(int), 0);
+		if (e != hipSuccess) break;
+		k_build_blk<<<(unsigned)(((int64_t)n * 28 + 255) / 256), 256, 0, 0>>>(nbr27, n, linear, (int*)g->d_sched, (int*)g->d_blk);
+		k_pair_heads<<<n_blocks, 256, 0, 0>>>(nbr27, n, linear, partner, block_heads, totals);
+		k_scan_blocks<<<1, 1024, 0, 0>>>(block_heads, n_blocks);
+		e = hipMemcpy(h_totals, totals, sizeof(h_totals), hipMemcpyDeviceToHost);  // also the sync point for the launches above
+		if (e != hipSuccess) {
+			set_error("hns_grid: schedule build failed: %s", hipGetErrorString(e));
+			rc = HNS_ERR_HIP;
+			break;
+		}
+		g->n_pairs = (uint64_t)h_totals[0];
+		g->n_singles = (uint64_t)h_totals[1];
+		e = hipMalloc(&g->d_pairs, sizeof(int) * 56 * (size_t)h_totals[0]);
+		if (e != hipSuccess) {
+			set_error("hns_grid: hipMalloc of the wave records failed: %s", hipGetErrorString(e));
+			rc = HNS_ERR_HIP;
+			break;
+		}
+		k_write_pairs<<<n_blocks, 256, 0, 0>>>(nbr27, n, linear, partner, block_heads, (int*)g->d_pairs);
+		e = hipDeviceSynchronize();
+		if (e != hipSuccess) {
+			set_error("hns_grid: schedule build failed: %s", hipGetErrorString(e));
+			rc = HNS_ERR_HIP;
+		}
+	} while (0);
+	(void)hipFree(partner);
+	return rc;
+}
+
+// Device tables from the host origin list (g->topo.origins / hash_mask prepared by Topology::prepare).
+int hns_grid_upload(hns_grid* g) {
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+		set_error("hns_grid: no HIP device available (libhns has no CPU fallback; pass HNS_GRID_HOST_ONLY for topology-only use)");
+		return HNS_ERR_NO_DEVICE;
+	}
+	HNS_HIP(hipGetDevice(&g->device));
+	Topology& t = g->topo;
+	const size_t nl = (size_t)(t.n_leaves > 0 ? t.n_leaves : 1);
+	const size_t hash_size = (size_t)t.hash_mask + 1;
+	int* status = nullptr;
+	HNS_HIP(hipMalloc(&g->d_origins, sizeof(int32_t) * 4 * nl));
+	HNS_HIP(hipMalloc(&g->d_nbr27, sizeof(int32_t) * 27 * nl));
+	HNS_HIP(hipMalloc(&g->d_hash, sizeof(int32_t) * (hash_size + 1)));  // +1: the duplicate-origin status word
+	status = (int*)g->d_hash + hash_size;
+	g->on_device = true;
+	HNS_HIP(hipMemsetAsync(g->d_hash, 0xFF, sizeof(int32_t) * hash_size, 0));
+	if (t.n_leaves > 0) {
+		const int n = (int)t.n_leaves;
+		const int int_max = INT32_MAX;
+		HNS_HIP(hipMemcpy(g->d_origins, t.origins.data(), sizeof(int32_t) * 4 * nl, hipMemcpyHostToDevice));
+		HNS_HIP(hipMemcpy(status, &int_max, sizeof(int), hipMemcpyHostToDevice));
+		k_hash_insert<<<(n + 255) / 256, 256, 0, 0>>>((const int4*)g->d_origins, n, (int*)g->d_hash, t.hash_mask, status);
+		int dup = 0;
+		HNS_HIP(hipMemcpy(&dup, status, sizeof(int), hipMemcpyDeviceToHost));
+		if (dup != INT32_MAX) {
+			// error path only: the host builder walks the leaves in order and words the message (which two leaves collide)
+			const int rc = t.build_tables();
+			if (rc != HNS_OK) return rc;
+			set_error("hns_grid: duplicate leaf origin reported by the device build near leaf %d", dup);
+			return HNS_ERR_TOPOLOGY;
+		}
+		k_build_nbr27<<<(unsigned)(((int64_t)n * 27 + 255) / 256), 256, 0, 0>>>(g->dev(), (int*)g->d_nbr27);
+		HNS_HIP(hipGetLastError());
+	}
+	return hns_grid_upload_schedule(g);
+}
+
+// Host copies of the device-built tables, fetched the first time a host query needs them.
+int hns_grid_host_tables(const hns_grid* cg) {
+	hns_grid* g = const_cast<hns_grid*>(cg);
+	std::lock_guard<std::mutex> lock(g->host_mutex);
+	Topology& t = g->topo;
+	if (t.have_tables) return HNS_OK;
+	if (!g->on_device) return t.build_tables();
+	t.nbr27.resize((size_t)t.n_leaves * 27);
+	t.hash.resize((size_t)t.hash_mask + 1);
+	if (t.n_leaves > 0) HNS_HIP(hipMemcpy(t.nbr27.data(), g->d_nbr27, sizeof(int32_t) * t.nbr27.size(), hipMemcpyDeviceToHost));
+	HNS_HIP(hipMemcpy(t.hash.data(), g->d_hash, sizeof(int32_t) * t.hash.size(), hipMemcpyDeviceToHost));
+	t.have_tables = true;
+	return HNS_OK;
+}
+
+void hns_grid_free_device(hns_grid* g) {
+	if (!g) return;
+	for (auto& e : g->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);
+	g->graphs.clear();
+	if (g->cap_stream) (void)hipStreamDestroy((hipStream_t)g->cap_stream);
+	g->cap_stream = nullptr;
+	free_ptr(g->d_origins);
+	free_ptr(g->d_nbr27);
+	free_ptr(g->d_hash);
+	free_ptr(g->d_sched);
+	free_ptr(g->d_blk);
+	free_ptr(g->d_pairs);
+	g->on_device = false;
+}
+
+// Debug/test access: copies of the launch-order tables (sched: n_active ints, may be null pointers to skip).
+extern "C" int hns_grid_launch_tables(const hns_grid* g, int32_t* sched, int32_t* wave_records, uint64_t* n_waves, uint64_t* n_lone) {
+	if (!g) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_launch_tables: null grid");
+	if (!g->on_device) return fail(HNS_ERR_NO_DEVICE, "hns_grid_launch_tables: grid has no device tables (HNS_GRID_HOST_ONLY)");
+	if (n_waves) *n_waves = g->n_pairs;
+	if (n_lone) *n_lone = g->n_singles;
+	if (sched && g->n_active) {
+		if (g->d_sched)
+			HNS_HIP(hipMemcpy(sched, g->d_sched, sizeof(int32_t) * g->n_active, hipMemcpyDeviceToHost));
+		else
+			for (uint64_t b = 0; b < g->n_active; ++b) sched[b] = (int32_t)b;
+	}
+	if (wave_records && g->n_pairs) HNS_HIP(hipMemcpy(wave_records, g->d_pairs, sizeof(int32_t) * 56 * g->n_pairs, hipMemcpyDeviceToHost));
+	return HNS_OK;
+}

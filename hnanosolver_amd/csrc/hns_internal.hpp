@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -31,9 +32,11 @@ struct Topology {
 	std::vector<int32_t> hash;     // table_size entries, -1 = empty
 	uint32_t hash_mask = 0;
 	int64_t n_leaves = 0;
+	bool have_tables = false;  // nbr27 / hash present on the host (device-built grids fetch them on first host query)
 
-	// Returns HNS_OK or HNS_ERR_TOPOLOGY (message set).
-	int build(const int32_t* leaf_origins_xyz, int64_t n_leaves);
+	// Both return HNS_OK or HNS_ERR_TOPOLOGY (message set).
+	int prepare(const int32_t* leaf_origins_xyz, int64_t n_leaves);  // origins + hash size; checks alignment and the leaf limit
+	int build_tables();                                             // host build of hash + nbr27; detects duplicate origins
 	int64_t find_leaf(int32_t ox, int32_t oy, int32_t oz) const;
 	uint64_t offset(int32_t i, int32_t j, int32_t k) const;  // 1-based, 0 = outside
 };
@@ -82,10 +85,12 @@ struct hns_grid {
 	uint64_t n_pairs = 0, n_singles = 0;  // waves to launch / how many of them carry a lone leaf
 	std::vector<hns::RbgsGraph> graphs;  // cached hipGraph replays of the pressure loop (dropped when the schedule changes)
 	void* cap_stream = nullptr;          // private capture stream
+	std::mutex host_mutex;               // guards the lazy host copy of the device-built tables
 	hns::GridDev dev() const;
 };
 
-// implemented in hns_api.hip
-int hns_grid_upload(hns_grid* g);
+// implemented in hns_gridbuild.hip
+int hns_grid_upload(hns_grid* g);           // device build of every table from topo.origins
 void hns_grid_free_device(hns_grid* g);
-int hns_grid_upload_schedule(hns_grid* g);
+int hns_grid_upload_schedule(hns_grid* g);  // launch-order tables for the current n_active
+int hns_grid_host_tables(const hns_grid* g);  // make topo.nbr27 / topo.hash valid on the host

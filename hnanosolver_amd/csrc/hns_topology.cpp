@@ -7,6 +7,7 @@
 // which order". This file keeps exactly that: a leaf-origin table in the caller's order, a 27-neighbour table per
 // leaf and an origin hash, so a tap costs one table read instead of three dependent node loads.
 #include <cstring>
+#include <thread>
 
 #include "hns_internal.hpp"
 
@@ -52,17 +53,17 @@ uint64_t Topology::offset(int32_t i, int32_t j, int32_t k) const {
 	return (uint64_t)l * 512u + (uint64_t)(((i & 7) << 6) | ((j & 7) << 3) | (k & 7)) + 1u;
 }
 
-int Topology::build(const int32_t* leaf_origins_xyz, int64_t n) {
+int Topology::prepare(const int32_t* leaf_origins_xyz, int64_t n) {
 	if (n < 0 || n > (int64_t(1) << 22)) {
 		set_error("hns_grid: %lld leaves exceeds the 2^22-leaf (2^31-voxel) limit of 32-bit voxel indices", (long long)n);
 		return HNS_ERR_TOPOLOGY;
 	}
 	n_leaves = n;
+	have_tables = false;
 	origins.assign((size_t)n * 4, 0);
 	uint32_t size = 16;
 	while ((int64_t)size < 2 * n + 2) size <<= 1;
 	hash_mask = size - 1;
-	hash.assign(size, -1);
 	for (int64_t l = 0; l < n; ++l) {
 		const int32_t ox = leaf_origins_xyz[3 * l], oy = leaf_origins_xyz[3 * l + 1], oz = leaf_origins_xyz[3 * l + 2];
 		if ((ox & 7) || (oy & 7) || (oz & 7)) {
@@ -72,6 +73,15 @@ int Topology::build(const int32_t* leaf_origins_xyz, int64_t n) {
 		origins[4 * l] = ox;
 		origins[4 * l + 1] = oy;
 		origins[4 * l + 2] = oz;
+	}
+	return HNS_OK;
+}
+
+int Topology::build_tables() {
+	const int64_t n = n_leaves;
+	hash.assign((size_t)hash_mask + 1, -1);
+	for (int64_t l = 0; l < n; ++l) {
+		const int32_t ox = origins[4 * l], oy = origins[4 * l + 1], oz = origins[4 * l + 2];
 		uint32_t s = hash_origin(ox, oy, oz) & hash_mask;
 		while (hash[s] >= 0) {
 			const int32_t* o = &origins[4 * (size_t)hash[s]];
@@ -97,6 +107,7 @@ int Topology::build(const int32_t* leaf_origins_xyz, int64_t n) {
 					nbr27[(size_t)l * 27 + (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)] = (int32_t)nb;
 				}
 	}
+	have_tables = true;
 	return HNS_OK;
 }
 
@@ -113,10 +124,10 @@ static hns_grid* grid_from_origins(const int32_t* origins, uint64_t n_leaves, fl
 	int rc = HNS_OK;
 	hns_grid* g = new hns_grid;
 	g->voxel_size = voxel_size;
-	rc = g->topo.build(origins, (int64_t)n_leaves);
+	rc = g->topo.prepare(origins, (int64_t)n_leaves);
 	if (rc == HNS_OK) {
 		g->n_active = n_leaves;
-		if (!(flags & HNS_GRID_HOST_ONLY)) rc = hns_grid_upload(g);
+		rc = (flags & HNS_GRID_HOST_ONLY) ? g->topo.build_tables() : hns_grid_upload(g);
 	}
 	if (rc != HNS_OK) {
 		hns_grid_free_device(g);
@@ -147,21 +158,50 @@ hns_grid* hns_grid_create(const int32_t* coords, uint64_t n_voxels, float voxel_
 	}
 	const uint64_t n_leaves = n_voxels / 512u;
 	std::vector<int32_t> origins((size_t)n_leaves * 3);
-	for (uint64_t l = 0; l < n_leaves; ++l) {
-		const int32_t* c = coords + 3 * 512 * l;
-		origins[3 * l] = c[0];
-		origins[3 * l + 1] = c[1];
-		origins[3 * l + 2] = c[2];
-		if (flags & HNS_GRID_SKIP_VALIDATE) continue;
-		for (int n = 1; n < 512; ++n) {
-			const int32_t* v = c + 3 * n;
-			if (v[0] != c[0] + (n >> 6) || v[1] != c[1] + ((n >> 3) & 7) || v[2] != c[2] + (n & 7)) {
-				set_error("hns_grid_create: coordinate %llu = (%d,%d,%d) breaks the leaf-dense x<<6|y<<3|z order of leaf %llu",
-				          (unsigned long long)(512 * l + n), v[0], v[1], v[2], (unsigned long long)l);
-				if (err) *err = HNS_ERR_TOPOLOGY;
-				return nullptr;
+	// Leaf-density check of all N coordinates on the host, where they already are: shipping them to the device would
+	// cost more than reading them once. Threads take contiguous leaf ranges; the lowest offending coordinate is
+	// reported, as a serial scan would.
+	const bool validate = !(flags & HNS_GRID_SKIP_VALIDATE);
+	unsigned n_threads = 1;
+	if (validate && n_leaves >= 2048) {
+		n_threads = std::thread::hardware_concurrency();
+		if (n_threads == 0) n_threads = 1;
+		if (n_threads > 16) n_threads = 16;
+	}
+	std::vector<uint64_t> first_bad(n_threads, UINT64_MAX);
+	auto scan = [&](unsigned t) {
+		const uint64_t l0 = n_leaves * t / n_threads, l1 = n_leaves * (t + 1) / n_threads;
+		for (uint64_t l = l0; l < l1; ++l) {
+			const int32_t* c = coords + 3 * 512 * l;
+			origins[3 * l] = c[0];
+			origins[3 * l + 1] = c[1];
+			origins[3 * l + 2] = c[2];
+			if (!validate || first_bad[t] != UINT64_MAX) continue;
+			for (int n = 1; n < 512; ++n) {
+				const int32_t* v = c + 3 * n;
+				if (v[0] != c[0] + (n >> 6) || v[1] != c[1] + ((n >> 3) & 7) || v[2] != c[2] + (n & 7)) {
+					first_bad[t] = 512 * l + n;
+					break;
+				}
 			}
 		}
+	};
+	if (n_threads == 1) {
+		scan(0);
+	} else {
+		std::vector<std::thread> pool;
+		for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(scan, t);
+		scan(0);
+		for (auto& th : pool) th.join();
+	}
+	for (unsigned t = 0; t < n_threads; ++t) {
+		if (first_bad[t] == UINT64_MAX) continue;
+		const uint64_t i = first_bad[t];
+		const int32_t* v = coords + 3 * i;
+		set_error("hns_grid_create: coordinate %llu = (%d,%d,%d) breaks the leaf-dense x<<6|y<<3|z order of leaf %llu", (unsigned long long)i, v[0], v[1], v[2],
+		          (unsigned long long)(i / 512));
+		if (err) *err = HNS_ERR_TOPOLOGY;
+		return nullptr;
 	}
 	return grid_from_origins(origins.data(), n_leaves, voxel_size, flags, err);
 }
@@ -194,12 +234,14 @@ int hns_grid_set_outside_element(hns_grid* g, uint64_t element_index) {
 
 int hns_grid_offsets(const hns_grid* g, const int32_t* ijk, uint64_t n, uint64_t* out) {
 	if (!g || (!ijk && n) || (!out && n)) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_offsets: null argument");
+	if (int rc = hns_grid_host_tables(g)) return rc;
 	for (uint64_t t = 0; t < n; ++t) out[t] = g->topo.offset(ijk[3 * t], ijk[3 * t + 1], ijk[3 * t + 2]);
 	return HNS_OK;
 }
 
 int hns_grid_neighbor_table(const hns_grid* g, int32_t* out) {
 	if (!g || !out) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_neighbor_table: null argument");
+	if (int rc = hns_grid_host_tables(g)) return rc;
 	memcpy(out, g->topo.nbr27.data(), g->topo.nbr27.size() * sizeof(int32_t));
 	return HNS_OK;
 }

@@ -84,6 +84,9 @@ int hns_grid_offsets(const hns_grid*, const int32_t* ijk, uint64_t n, uint64_t* 
 int hns_grid_neighbor_table(const hns_grid*, int32_t* out);
 /* Writes the n_voxels x 3 coordinate array the grid represents (what the reference keeps as d_coords). */
 int hns_grid_coords(const hns_grid*, int32_t* out_xyz);
+/* Copies of the device-built launch tables (inspection / tests; any argument may be NULL): sched = n_active leaf ids in
+ * workgroup order; wave_records = n_waves x 56 int32 {leaf0, nbr27[27], leaf1 or -1, nbr27[27]} read by the SOR kernel. */
+int hns_grid_launch_tables(const hns_grid*, int32_t* sched, int32_t* wave_records, uint64_t* n_waves, uint64_t* n_lone);
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Drop-in operators (host pointers in, results in place, synchronous)                                           */
