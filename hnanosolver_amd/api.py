@@ -172,6 +172,10 @@ class IndexGridHandle:
     def set_active_leaves(self, n: int) -> None:
         _raise(lib.hns_grid_set_active_leaves(self._ptr, int(n)))
 
+    def release_cache(self) -> None:
+        """Free the device buffers operator calls keep with the grid between cooks."""
+        _raise(lib.hns_grid_release_cache(self._ptr))
+
     def active_leaves(self) -> int:
         return int(lib.hns_grid_active_leaves(self._ptr)) if self._ptr else 0
 
@@ -220,11 +224,22 @@ def create_grid_from_leaves(leaf_origins: np.ndarray, voxel_size: float = 1.0, f
 
 
 def CreateIndexGrid(data: GridIndexedData, handle: IndexGridHandle, voxelSize: float, flags: int = _lib.HNS_GRID_DEFAULT) -> None:
-    """Build the index grid for ``data.pCoords()`` into ``handle`` (reference HNanoSolver.cu:375-390)."""
+    """Build the index grid for ``data.pCoords()`` into ``handle`` (reference HNanoSolver.cu:375-390).
+
+    Persistent state across cooks: a handle that already holds a grid for exactly these leaves, in
+    this order and at this voxel size, is kept -- with the device buffers the operators left with it -- instead of
+    being rebuilt; the coordinates are validated either way."""
     coords = data.pCoords()
     if coords is None:
         raise RuntimeError("Host coordinate data pointer is null.")
     coords = np.ascontiguousarray(coords, dtype=np.int32)
+    if not handle.isEmpty() and float(lib.hns_grid_voxel_size(handle.ptr)) == float(np.float32(voxelSize)) \
+            and not (flags & _lib.HNS_GRID_HOST_ONLY):
+        same = lib.hns_grid_matches(handle.ptr, coords.ctypes.data, coords.shape[0], flags)
+        if same < 0:
+            _raise(same)
+        if same == 1:
+            return
     err = C.c_int(0)
     ptr = lib.hns_grid_create(coords.ctypes.data, coords.shape[0], float(voxelSize), flags, C.byref(err))
     if not ptr and err.value < 0:

@@ -72,6 +72,9 @@ struct hns_sim {
 	std::vector<hipEvent_t> ev;  // start/stop pairs
 	size_t ev_used = 0;
 	long long timed_launches = 0;
+	hipStream_t xfer = nullptr;  // transfer stream + hand-off events of the pipelined operator path (compute_sim_pipelined)
+	hipEvent_t xev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+	bool cached = false, in_use = false;  // owned by the grid's cook cache / currently lent to an operator call
 	int find(const char* name) const {
 		for (size_t i = 0; i < names.size(); ++i)
 			if (names[i] == name) return (int)i;
@@ -96,7 +99,32 @@ extern "C" void hns_sim_destroy(hns_sim* s) {
 	hipFree(s->p_a);
 	hipFree(s->p_b);
 	for (hipEvent_t e : s->ev) hipEventDestroy(e);
+	for (hipEvent_t e : s->xev)
+		if (e) hipEventDestroy(e);
+	if (s->xfer) hipStreamDestroy(s->xfer);
 	delete s;
+}
+
+// Frees the device-resident state operator calls left with the grid (see make_sim below).
+extern "C" int hns_grid_release_cache(hns_grid* g) {
+	if (!g) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_release_cache: null grid");
+	std::vector<hns_sim*> drop;
+	{
+		std::lock_guard<std::mutex> lock(g->host_mutex);
+		for (size_t i = 0; i < g->sim_cache.size();) {
+			if (g->sim_cache[i]->in_use) {
+				++i;
+				continue;
+			}
+			drop.push_back(g->sim_cache[i]);
+			g->sim_cache.erase(g->sim_cache.begin() + (long)i);
+		}
+	}
+	for (hns_sim* s : drop) {
+		s->cached = false;
+		hns_sim_destroy(s);
+	}
+	return HNS_OK;
 }
 
 extern "C" hns_sim* hns_sim_create(hns_grid* g, const char* const* float_names, int n_float, int* err) {
@@ -278,46 +306,81 @@ static int sim_advect_scalars(hns_sim* s, const float* sdf, bool coll, float dt,
 	return HNS_OK;
 }
 
+// One substep in the order of reference HNanoSolver.cu:150-356, cut at the two points where it starts to need more input
+// fields, so that the operator path can enqueue each part as soon as its inputs are on the device:
+//   part A  needs velocity (+ collision_sdf)      collision, advect_vector, vorticity, divergence
+//   part B  needs fuel/waste/temperature/flame     combustion, buoyancy, pressure solve, gradient subtraction, collision
+//   part C  needs every advected float field       advect_scalars
+struct Substep {
+	hns_sim* s;
+	int iterations;
+	float dt, voxel_size, inv_dx;
+	const hns_combustion_params* params;
+	int ci[4];
+	bool coll;
+	const float* sdf;
+	void* stream;
+
+	int prepare(hns_sim* sim, int iters, float dt_, float vs, const hns_combustion_params* prm, int has_collision, void* st) {
+		s = sim;
+		iterations = iters;
+		dt = dt_;
+		voxel_size = vs;
+		inv_dx = 1.0f / vs;
+		params = prm;
+		stream = st;
+		if (s->names.empty()) return fail(HNS_ERR_RUNTIME, "No float blocks found in input data.");  // :61-63
+		const char* required[4] = {"fuel", "waste", "temperature", "flame"};                          // :193-201
+		for (int c = 0; c < 4; ++c) {
+			ci[c] = s->find(required[c]);
+			if (ci[c] < 0) {
+				set_error("Missing required input field for combustion: %s", required[c]);
+				return HNS_ERR_RUNTIME;
+			}
+		}
+		const int i_sdf = has_collision ? s->find("collision_sdf") : -1;  // :66-75
+		coll = i_sdf >= 0;
+		sdf = coll ? s->cur[i_sdf] : nullptr;
+		return HNS_OK;
+	}
+	int part_a() {
+		hns_grid* g = s->grid;
+		if (coll) HNS_TRY(hns_dev_enforce_collision_boundaries(g, s->vel, sdf, voxel_size, stream));  // :153-157
+		HNS_TRY(hns_dev_advect_vector(g, s->vel, s->adv, sdf, coll, dt, inv_dx, stream));  // :162-170
+		if ((int)params->factorScale != 0) {  // :172-176. With (int)factorScale == 0 every vorticity-magnitude tap collapses onto the centre, the
+			// gradient is 0, N = 0/(0+1e-5) = 0 and the kernel writes u + dt*(scale*0) = u: a bit-exact copy, skipped.
+			HNS_TRY(hns_dev_vorticity_confinement(g, s->adv, s->tmp, dt, inv_dx,
+			                                      params->vorticityScale, params->factorScale, stream));
+			std::swap(s->adv, s->tmp);
+		}
+		return hns_dev_divergence(g, s->adv, s->div, inv_dx, stream);  // :181-188
+	}
+	int part_b() {
+		hns_grid* g = s->grid;
+		HNS_TRY(hns_dev_combustion_oxygen(s->cur[ci[0]], s->cur[ci[1]], s->cur[ci[2]], s->div, s->cur[ci[3]], s->nxt[ci[0]], s->nxt[ci[1]],
+		                                  s->nxt[ci[2]], s->nxt[ci[3]], params->temperatureRelease, params->expansionRate, s->n, stream));  // :211-221
+		HNS_TRY(hns_dev_temperature_buoyancy(s->adv, s->nxt[ci[2]], s->adv, dt, params->ambientTemp, params->buoyancyStrength, s->n,
+		                                     stream));  // :226-234 (temperature AFTER combustion)
+		for (int c = 0; c < 4; ++c) std::swap(s->cur[ci[c]], s->nxt[ci[c]]);  // :239-246
+		HNS_TRY(sim_pressure(s, iterations, voxel_size, omega_compute(voxel_size), stream));  // :256-272
+		HNS_TRY(hns_dev_subtract_pressure_gradient(g, s->adv, s->p_result, s->vel, sdf, coll,
+		                                           inv_dx, stream));  // :278-289
+		if (coll) HNS_TRY(hns_dev_enforce_collision_boundaries(g, s->vel, sdf, voxel_size, stream));  // :292-296
+		return HNS_OK;
+	}
+	int part_c() { return sim_advect_scalars(s, sdf, coll, dt, inv_dx, stream); }  // :321-356
+};
+
 extern "C" int hns_sim_substep(hns_sim* s, int iterations, float dt, float voxel_size, const hns_combustion_params* params, int has_collision,
                                void* stream) {
 	if (!s || !params) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_sim_substep: null argument");
 	HNS_TRY(validate_step(voxel_size, dt, iterations, true));
 	if (s->n == 0) return HNS_OK;  // HNanoSolver.cu:26-28
-	if (s->names.empty()) return fail(HNS_ERR_RUNTIME, "No float blocks found in input data.");  // :61-63
-	const char* required[4] = {"fuel", "waste", "temperature", "flame"};                          // :193-201
-	int ci[4];
-	for (int c = 0; c < 4; ++c) {
-		ci[c] = s->find(required[c]);
-		if (ci[c] < 0) {
-			set_error("Missing required input field for combustion: %s", required[c]);
-			return HNS_ERR_RUNTIME;
-		}
-	}
-	const int i_sdf = has_collision ? s->find("collision_sdf") : -1;  // :66-75
-	const bool coll = i_sdf >= 0;
-	const float* sdf = coll ? s->cur[i_sdf] : nullptr;
-	const float inv_dx = 1.0f / voxel_size;
-	hns_grid* g = s->grid;
-
-	if (coll) HNS_TRY(hns_dev_enforce_collision_boundaries(g, s->vel, sdf, voxel_size, stream));  // :153-157
-	HNS_TRY(hns_dev_advect_vector(g, s->vel, s->adv, sdf, coll, dt, inv_dx, stream));  // :162-170
-	if ((int)params->factorScale != 0) {  // :172-176. With (int)factorScale == 0 every vorticity-magnitude tap collapses onto the centre, the
-		// gradient is 0, N = 0/(0+1e-5) = 0 and the kernel writes u + dt*(scale*0) = u: a bit-exact copy, skipped.
-		HNS_TRY(hns_dev_vorticity_confinement(g, s->adv, s->tmp, dt, inv_dx,
-		                                      params->vorticityScale, params->factorScale, stream));
-		std::swap(s->adv, s->tmp);
-	}
-	HNS_TRY(hns_dev_divergence(g, s->adv, s->div, inv_dx, stream));  // :181-188
-	HNS_TRY(hns_dev_combustion_oxygen(s->cur[ci[0]], s->cur[ci[1]], s->cur[ci[2]], s->div, s->cur[ci[3]], s->nxt[ci[0]], s->nxt[ci[1]],
-	                                  s->nxt[ci[2]], s->nxt[ci[3]], params->temperatureRelease, params->expansionRate, s->n, stream));  // :211-221
-	HNS_TRY(hns_dev_temperature_buoyancy(s->adv, s->nxt[ci[2]], s->adv, dt, params->ambientTemp, params->buoyancyStrength, s->n,
-	                                     stream));  // :226-234 (temperature AFTER combustion)
-	for (int c = 0; c < 4; ++c) std::swap(s->cur[ci[c]], s->nxt[ci[c]]);  // :239-246
-	HNS_TRY(sim_pressure(s, iterations, voxel_size, omega_compute(voxel_size), stream));  // :256-272
-	HNS_TRY(hns_dev_subtract_pressure_gradient(g, s->adv, s->p_result, s->vel, sdf, coll,
-	                                           inv_dx, stream));  // :278-289
-	if (coll) HNS_TRY(hns_dev_enforce_collision_boundaries(g, s->vel, sdf, voxel_size, stream));  // :292-296
-	return sim_advect_scalars(s, sdf, coll, dt, inv_dx, stream);  // :321-356
+	Substep step;
+	HNS_TRY(step.prepare(s, iterations, dt, voxel_size, params, has_collision, stream));
+	HNS_TRY(step.part_a());
+	HNS_TRY(step.part_b());
+	return step.part_c();
 }
 
 extern "C" int hns_sim_core_substep(hns_sim* s, int iterations, float dt, float voxel_size, void* stream) {
@@ -368,19 +431,133 @@ int split_fields(hns_field* fields, int n_fields, FieldSplit& out, const char* w
 	return HNS_OK;
 }
 
+// Persistent state across cooks (the reference's cook cache is an empty struct, SOP_HNanoSolver.hpp:60-64,
+// and every cook pays cudaMallocAsync x 15+ and the matching frees, HNanoSolver.cu:87-133). An operator call borrows a
+// device-resident hns_sim for its field-name list from the grid and returns it afterwards; the buffers live until the
+// grid is destroyed or hns_grid_release_cache() is called. Two entries cover the usual "full solver + one single-field
+// operator" pattern; a call that finds its entry lent out (concurrent cooks on one grid) works on a private sim.
+// HNS_COOK_CACHE=0 disables the cache.
 struct SimGuard {
 	hns_sim* s = nullptr;
-	~SimGuard() { hns_sim_destroy(s); }
+	~SimGuard() {
+		if (!s) return;
+		if (!s->cached) {
+			hns_sim_destroy(s);
+			return;
+		}
+		std::lock_guard<std::mutex> lock(s->grid->host_mutex);
+		s->in_use = false;
+	}
 };
 
-int make_sim(hns_grid* g, const FieldSplit& fs, SimGuard& guard) {
+int make_sim(hns_grid* g, const FieldSplit& fs, SimGuard& guard, void* stream) {
 	std::vector<const char*> names;
 	for (hns_field* f : fs.floats) names.push_back(f->name);
+	const char* env = getenv("HNS_COOK_CACHE");
+	const bool use_cache = !(env && strcmp(env, "0") == 0);
+	if (use_cache) {
+		std::lock_guard<std::mutex> lock(g->host_mutex);
+		for (hns_sim* c : g->sim_cache) {
+			if (c->in_use || c->names.size() != names.size()) continue;
+			bool same = true;
+			for (size_t i = 0; i < names.size() && same; ++i) same = c->names[i] == names[i];
+			if (!same) continue;
+			c->in_use = true;
+			guard.s = c;
+			break;
+		}
+	}
+	if (guard.s) {
+		// A fresh sim starts zeroed and a substep only writes the active leaves; with an active prefix
+		// (hns_grid_set_active_leaves) restore that guarantee for everything a kernel may read across a leaf face.
+		if (g->n_active != (uint64_t)g->topo.n_leaves) {
+			hns_sim* s = guard.s;
+			const size_t bytes = sizeof(float) * (size_t)s->n;
+			hipStream_t st = (hipStream_t)stream;
+			HNS_HIP(hipMemsetAsync(s->div, 0, bytes, st));
+			HNS_HIP(hipMemsetAsync(s->p_b, 0, bytes, st));
+			HNS_HIP(hipMemsetAsync(s->adv, 0, 3 * bytes, st));
+			HNS_HIP(hipMemsetAsync(s->tmp, 0, 3 * bytes, st));
+			for (float* q : s->nxt) HNS_HIP(hipMemsetAsync(q, 0, bytes, st));
+		}
+		return HNS_OK;
+	}
 	int err = HNS_OK;
 	guard.s = hns_sim_create(g, names.data(), (int)names.size(), &err);
-	return err;
+	if (err != HNS_OK || !use_cache) return err;
+	std::lock_guard<std::mutex> lock(g->host_mutex);
+	if (g->sim_cache.size() >= 2) {  // evict the oldest entry that is not lent out
+		for (size_t i = 0; i < g->sim_cache.size(); ++i)
+			if (!g->sim_cache[i]->in_use) {
+				g->sim_cache[i]->cached = false;
+				hns_sim_destroy(g->sim_cache[i]);
+				g->sim_cache.erase(g->sim_cache.begin() + (long)i);
+				break;
+			}
+	}
+	if (g->sim_cache.size() < 2) {
+		guard.s->cached = guard.s->in_use = true;
+		g->sim_cache.push_back(guard.s);
+	}
+	return HNS_OK;
 }
 }  // namespace
+
+// hns_compute_sim's data movement. The reference uploads everything, runs, downloads everything (HNanoSolver.cu:87-133,
+// 361-371). Here the fields go up in the order the substep consumes them, on a transfer stream of the sim's own, and each
+// part of the substep is enqueued on the caller's stream as soon as its inputs are queued: advect_vector + divergence
+// run under the upload of the combustion fields, the remaining fields arrive under the pressure solve, and
+// advect_scalars runs under the download of the final velocity. Same kernels, same order per buffer; only the overlap
+// differs. HNS_COOK_PIPELINE=0 falls back to upload-all / run / download-all.
+static int compute_sim_pipelined(hns_sim* s, FieldSplit& fs, int iterations, float dt, float voxel_size, const hns_combustion_params* params,
+                                 int has_collision, void* stream) {
+	const char* env = getenv("HNS_COOK_PIPELINE");
+	Substep step;
+	if (env && strcmp(env, "0") == 0) {
+		std::vector<hns_field> all;
+		all.push_back(*fs.velocity);
+		for (hns_field* f : fs.floats) all.push_back(*f);
+		HNS_TRY(hns_sim_upload(s, all.data(), (int)all.size(), stream));
+		HNS_TRY(hns_sim_substep(s, iterations, dt, voxel_size, params, has_collision, stream));
+		return hns_sim_download(s, all.data(), (int)all.size(), stream);
+	}
+	if (!s->xfer) {
+		HNS_HIP(hipStreamCreateWithFlags(&s->xfer, hipStreamNonBlocking));
+		for (hipEvent_t& e : s->xev) HNS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	}
+	hipStream_t st = (hipStream_t)stream, xf = s->xfer;
+	HNS_TRY(step.prepare(s, iterations, dt, voxel_size, params, has_collision, stream));
+	auto is_combustion = [](const char* n) { return !strcmp(n, "fuel") || !strcmp(n, "waste") || !strcmp(n, "temperature") || !strcmp(n, "flame"); };
+	auto handoff = [&](hipEvent_t e, hipStream_t from, hipStream_t to) -> int {
+		HNS_HIP(hipEventRecord(e, from));
+		HNS_HIP(hipStreamWaitEvent(to, e, 0));
+		return HNS_OK;
+	};
+	HNS_TRY(handoff(s->xev[0], st, xf));  // transfers start after whatever the caller's stream holds
+	if (step.coll)
+		for (hns_field* f : fs.floats)
+			if (!strcmp(f->name, "collision_sdf")) HNS_TRY(hns_sim_upload(s, f, 1, xf));
+	HNS_TRY(hns_sim_upload(s, fs.velocity, 1, xf));
+	HNS_TRY(handoff(s->xev[1], xf, st));
+	HNS_TRY(step.part_a());
+	for (hns_field* f : fs.floats)
+		if (is_combustion(f->name)) HNS_TRY(hns_sim_upload(s, f, 1, xf));
+	HNS_TRY(handoff(s->xev[2], xf, st));
+	HNS_TRY(step.part_b());
+	HNS_HIP(hipEventRecord(s->xev[3], st));  // s->vel is final here
+	for (hns_field* f : fs.floats)
+		if (!is_combustion(f->name) && !(step.coll && !strcmp(f->name, "collision_sdf"))) HNS_TRY(hns_sim_upload(s, f, 1, xf));
+	HNS_TRY(handoff(s->xev[4], xf, st));
+	HNS_TRY(step.part_c());
+	HNS_HIP(hipStreamWaitEvent(xf, s->xev[3], 0));
+	HNS_HIP(hipMemcpyAsync(fs.velocity->host, s->vel, sizeof(float) * 3 * (size_t)s->n, hipMemcpyDeviceToHost, xf));
+	HNS_TRY(handoff(s->xev[0], st, xf));
+	std::vector<hns_field> outs;
+	for (hns_field* f : fs.floats) outs.push_back(*f);
+	HNS_TRY(hns_sim_download(s, outs.data(), (int)outs.size(), xf));  // synchronises xf
+	HNS_HIP(hipStreamSynchronize(st));
+	return HNS_OK;
+}
 
 extern "C" int hns_compute_sim(hns_grid* g, hns_field* fields, int n_fields, int iterations, float dt, float voxel_size,
                                const hns_combustion_params* params, int has_collision, void* stream) {
@@ -403,10 +580,8 @@ extern "C" int hns_compute_sim(hns_grid* g, hns_field* fields, int n_fields, int
 		}
 	if (!g->on_device) return fail(HNS_ERR_NO_DEVICE, "hns_compute_sim: grid has no device tables (there is no CPU fallback)");
 	SimGuard guard;
-	HNS_TRY(make_sim(g, fs, guard));
-	HNS_TRY(hns_sim_upload(guard.s, fields, n_fields, stream));
-	HNS_TRY(hns_sim_substep(guard.s, iterations, dt, voxel_size, params, has_collision, stream));
-	HNS_TRY(hns_sim_download(guard.s, fields, n_fields, stream));
+	HNS_TRY(make_sim(g, fs, guard, stream));
+	HNS_TRY(compute_sim_pipelined(guard.s, fs, iterations, dt, voxel_size, params, has_collision, stream));
 	// The reference copies every float block back from its OUTPUT buffer; "collision_sdf" is never advected, so its
 	// output buffer is still the memset zeros and the caller's SDF array comes back zeroed (HNanoSolver.cu:115-117,327,364-369).
 	for (hns_field* f : fs.floats)
@@ -429,7 +604,7 @@ extern "C" int hns_advect_index_grid(hns_grid* g, hns_field* fields, int n_field
 	if (hns_grid_voxel_count(g) == 0) return HNS_OK;
 	if (!g->on_device) return fail(HNS_ERR_NO_DEVICE, "hns_advect_index_grid: grid has no device tables (there is no CPU fallback)");
 	SimGuard guard;
-	HNS_TRY(make_sim(g, fs, guard));
+	HNS_TRY(make_sim(g, fs, guard, stream));
 	hns_sim* s = guard.s;
 	HNS_TRY(hns_sim_upload(s, fields, n_fields, stream));
 	const float inv_dx = 1.0f / voxel_size;
@@ -454,7 +629,7 @@ extern "C" int hns_advect_index_grid_velocity(hns_grid* g, hns_field* fields, in
 	FieldSplit only_vel;
 	only_vel.velocity = fs.velocity;
 	only_vel.n_vec3 = 1;
-	HNS_TRY(make_sim(g, only_vel, guard));
+	HNS_TRY(make_sim(g, only_vel, guard, stream));
 	hns_sim* s = guard.s;
 	HNS_TRY(hns_sim_upload(s, fs.velocity, 1, stream));
 	HNS_TRY(hns_dev_advect_vector(g, s->vel, s->adv, nullptr, 0, dt, 1.0f / voxel_size, stream));
@@ -476,7 +651,7 @@ extern "C" int hns_project_non_divergent(hns_grid* g, hns_field* fields, int n_f
 	FieldSplit only_vel;
 	only_vel.velocity = fs.velocity;
 	only_vel.n_vec3 = 1;
-	HNS_TRY(make_sim(g, only_vel, guard));
+	HNS_TRY(make_sim(g, only_vel, guard, stream));
 	hns_sim* s = guard.s;
 	HNS_TRY(hns_sim_upload(s, fs.velocity, 1, stream));
 	const float inv_dx = 1.0f / voxel_size;
@@ -504,7 +679,7 @@ extern "C" int hns_divergence(hns_grid* g, hns_field* fields, int n_fields, floa
 	FieldSplit only_vel;
 	only_vel.velocity = fs.velocity;
 	only_vel.n_vec3 = 1;
-	HNS_TRY(make_sim(g, only_vel, guard));
+	HNS_TRY(make_sim(g, only_vel, guard, stream));
 	hns_sim* s = guard.s;
 	HNS_TRY(hns_sim_upload(s, fs.velocity, 1, stream));
 	HNS_TRY(hns_dev_divergence(g, s->vel, s->div, 1.0f / voxel_size, stream));

@@ -292,6 +292,7 @@ int hns_grid_host_tables(const hns_grid* cg) {
 
 void hns_grid_free_device(hns_grid* g) {
 	if (!g) return;
+	(void)hns_grid_release_cache(g);
 	for (auto& e : g->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);
 	g->graphs.clear();
 	if (g->cap_stream) (void)hipStreamDestroy((hipStream_t)g->cap_stream);

@@ -146,21 +146,20 @@ hns_grid* hns_grid_create_from_leaves(const int32_t* leaf_origins_xyz, uint64_t 
 	return grid_from_origins(leaf_origins_xyz, n_leaves, voxel_size, flags, err);
 }
 
-hns_grid* hns_grid_create(const int32_t* coords, uint64_t n_voxels, float voxel_size, unsigned flags, int* err) {
+// Leaf-density check of all N coordinates on the host, where they already are: shipping them to the device would cost
+// more than reading them once. Threads take contiguous leaf ranges; the lowest offending coordinate is reported, as a
+// serial scan would. Writes the leaf origins (every 512th coordinate) to `origins` (n_leaves x 3).
+static int scan_coords(const char* who, const int32_t* coords, uint64_t n_voxels, unsigned flags, std::vector<int32_t>& origins) {
 	if (!coords && n_voxels) {
-		if (err) *err = fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_create: null coordinate array");
-		return nullptr;
+		set_error("%s: null coordinate array", who);
+		return HNS_ERR_INVALID_ARGUMENT;
 	}
 	if (n_voxels % 512u) {
-		set_error("hns_grid_create: %llu coordinates is not a multiple of 512: the domain must be leaf-dense", (unsigned long long)n_voxels);
-		if (err) *err = HNS_ERR_TOPOLOGY;
-		return nullptr;
+		set_error("%s: %llu coordinates is not a multiple of 512: the domain must be leaf-dense", who, (unsigned long long)n_voxels);
+		return HNS_ERR_TOPOLOGY;
 	}
 	const uint64_t n_leaves = n_voxels / 512u;
-	std::vector<int32_t> origins((size_t)n_leaves * 3);
-	// Leaf-density check of all N coordinates on the host, where they already are: shipping them to the device would
-	// cost more than reading them once. Threads take contiguous leaf ranges; the lowest offending coordinate is
-	// reported, as a serial scan would.
+	origins.resize((size_t)n_leaves * 3);
 	const bool validate = !(flags & HNS_GRID_SKIP_VALIDATE);
 	unsigned n_threads = 1;
 	if (validate && n_leaves >= 2048) {
@@ -198,12 +197,38 @@ hns_grid* hns_grid_create(const int32_t* coords, uint64_t n_voxels, float voxel_
 		if (first_bad[t] == UINT64_MAX) continue;
 		const uint64_t i = first_bad[t];
 		const int32_t* v = coords + 3 * i;
-		set_error("hns_grid_create: coordinate %llu = (%d,%d,%d) breaks the leaf-dense x<<6|y<<3|z order of leaf %llu", (unsigned long long)i, v[0], v[1], v[2],
+		set_error("%s: coordinate %llu = (%d,%d,%d) breaks the leaf-dense x<<6|y<<3|z order of leaf %llu", who, (unsigned long long)i, v[0], v[1], v[2],
 		          (unsigned long long)(i / 512));
-		if (err) *err = HNS_ERR_TOPOLOGY;
+		return HNS_ERR_TOPOLOGY;
+	}
+	return HNS_OK;
+}
+
+hns_grid* hns_grid_create(const int32_t* coords, uint64_t n_voxels, float voxel_size, unsigned flags, int* err) {
+	std::vector<int32_t> origins;
+	const int rc = scan_coords("hns_grid_create", coords, n_voxels, flags, origins);
+	if (rc != HNS_OK) {
+		if (err) *err = rc;
 		return nullptr;
 	}
-	return grid_from_origins(origins.data(), n_leaves, voxel_size, flags, err);
+	return grid_from_origins(origins.data(), n_voxels / 512u, voxel_size, flags, err);
+}
+
+// 1 when `coords` describes exactly the leaves of `g` in the same order (so every table, and any device state kept with
+// the grid, is still valid), 0 when it does not, < 0 when the coordinates are not leaf-dense. The caller decides
+// whether to keep the grid or build a new one: this is the "topology unchanged" test of a cook.
+int hns_grid_matches(const hns_grid* g, const int32_t* coords, uint64_t n_voxels, unsigned flags) {
+	if (!g) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_matches: null grid");
+	std::vector<int32_t> origins;
+	const int rc = scan_coords("hns_grid_matches", coords, n_voxels, flags, origins);
+	if (rc != HNS_OK) return rc;
+	const uint64_t n_leaves = n_voxels / 512u;
+	if (n_leaves != (uint64_t)g->topo.n_leaves) return 0;
+	for (uint64_t l = 0; l < n_leaves; ++l) {
+		const int32_t* o = &g->topo.origins[4 * (size_t)l];
+		if (o[0] != origins[3 * l] || o[1] != origins[3 * l + 1] || o[2] != origins[3 * l + 2]) return 0;
+	}
+	return 1;
 }
 
 void hns_grid_destroy(hns_grid* g) {

@@ -172,7 +172,14 @@ inline void check(int rc) {
 	if (rc == HNS_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);  // reference HNanoSolver.cu:12-23
 	throw std::runtime_error(msg);                                         // reference Utils.cuh:10-18, HNanoSolver.cu:44,62,196
 }
+// A handle that already holds the grid of exactly these leaves (same order, same voxel size) is kept, together with the
+// device buffers earlier operator calls left with it: the "topology unchanged" cook allocates and builds nothing.
 inline void gridFor(GridIndexedData& data, float voxelSize, IndexGridHandle& h, unsigned flags = HNS_GRID_DEFAULT) {
+	if (h.get() && !(flags & HNS_GRID_HOST_ONLY) && hns_grid_voxel_size(h.get()) == voxelSize) {
+		const int same = hns_grid_matches(h.get(), reinterpret_cast<const int32_t*>(data.pCoords()), data.size(), flags);
+		if (same < 0) check(same);
+		if (same == 1) return;
+	}
 	int err = HNS_OK;
 	hns_grid* g = hns_grid_create(reinterpret_cast<const int32_t*>(data.pCoords()), data.size(), voxelSize, flags, &err);
 	if (!g) check(err < 0 ? err : HNS_ERR_RUNTIME);

@@ -84,6 +84,12 @@ int hns_grid_offsets(const hns_grid*, const int32_t* ijk, uint64_t n, uint64_t* 
 int hns_grid_neighbor_table(const hns_grid*, int32_t* out);
 /* Writes the n_voxels x 3 coordinate array the grid represents (what the reference keeps as d_coords). */
 int hns_grid_coords(const hns_grid*, int32_t* out_xyz);
+/* 1 if `coords_xyz` lists exactly this grid's leaves in the same order (the grid, and the device state kept with it, can
+ * serve the next cook), 0 if not, < 0 if the coordinates are not leaf-dense (same checks and flags as hns_grid_create). */
+int hns_grid_matches(const hns_grid*, const int32_t* coords_xyz, uint64_t n_voxels, unsigned flags);
+/* Operator calls (hns_compute_sim ... hns_divergence) keep their device buffers with the grid between calls, so a cook on
+ * an unchanged topology allocates nothing; this frees them early (hns_grid_destroy does it too). */
+int hns_grid_release_cache(hns_grid*);
 /* Copies of the device-built launch tables (inspection / tests; any argument may be NULL): sched = n_active leaf ids in
  * workgroup order; wave_records = n_waves x 56 int32 {leaf0, nbr27[27], leaf1 or -1, nbr27[27]} read by the SOR kernel. */
 int hns_grid_launch_tables(const hns_grid*, int32_t* sched, int32_t* wave_records, uint64_t* n_waves, uint64_t* n_lone);

@@ -93,6 +93,32 @@ def test_create_index_grid_validates_leaf_density():
     assert h.leaf_count() == 8 and np.array_equal(h.coords(), c)
 
 
+def test_grid_matches_detects_topology_changes():
+    o = fields.plume_leaves(8, 1.0, 0.3)
+    c = fields.leaves_to_coords(o)
+    g = api.create_grid_from_leaves(o, 0.1, _lib.HNS_GRID_HOST_ONLY)
+
+    def matches(coords, flags=0):
+        coords = np.ascontiguousarray(coords, dtype=np.int32)
+        return _lib.lib.hns_grid_matches(g.ptr, coords.ctypes.data, len(coords), flags)
+
+    assert matches(c) == 1
+    assert matches(c[:-512]) == 0                                   # one leaf fewer
+    moved = c.copy()
+    moved[512 * 5:512 * 6] += np.array([0, 0, 800], dtype=np.int32)  # same count, one leaf elsewhere
+    assert matches(moved) == 0
+    swapped = c.copy()
+    swapped[:512], swapped[512:1024] = c[512:1024], c[:512]          # same leaves, different order = different layout
+    assert matches(swapped) == 0
+    bad = c.copy()
+    bad[1000, 1] += 1
+    assert matches(bad) == _lib.HNS_ERR_TOPOLOGY
+    assert b"breaks the leaf-dense" in _lib.lib.hns_last_error()
+    assert matches(bad, _lib.HNS_GRID_SKIP_VALIDATE) == 1           # only every 512th coordinate is read
+    assert matches(c[:700]) == _lib.HNS_ERR_TOPOLOGY
+    g.reset()
+
+
 def test_grid_indexed_data_mirrors_reference_container():
     """reference Tests/IndexGrid.cpp:473-539 (GridIndexedData alloc/add/clear)"""
     d = api.GridIndexedData()

@@ -207,3 +207,78 @@ def test_device_resident_substeps_match_repeated_cooks():
     api.Compute_Sim(d, h, iters, dt, vs, p, False)
     for n in names + ["vel"]:
         assert np.array_equal(arrays[n], d.pValues(n)), n
+
+
+def test_cook_cache_is_invisible():
+    """Operator calls keep their device buffers with the grid between cooks. Results must not depend on
+    whether a call found warm buffers, on what the previous call left in them, or on the cache being disabled."""
+    origins, R = fields.plume_leaves(8, 1.0, 0.3), 64
+    vs, dt, iters = 1.0 / R, 1.0 / 24.0, 12
+    p = api.CombustionParams(factorScale=1.0)
+
+    def cook(handle, amplitude):
+        d = build_data(origins, R, with_sdf=True, amplitude=amplitude)
+        api.Compute_Sim(d, handle, iters, dt, vs, p, True)
+        return snapshot(d)
+
+    h = api.IndexGridHandle()
+    api.CreateIndexGrid(build_data(origins, R), h, vs)
+    cold = cook(h, 96.0)            # allocates the entry
+    other = cook(h, 250.0)          # different data through the warm buffers
+    warm = cook(h, 96.0)            # same inputs again, warm and dirty buffers
+    for n in cold:
+        assert np.array_equal(cold[n], warm[n]), n
+    assert any(not np.array_equal(cold[n], other[n]) for n in cold)
+    # a second field list (single-field operators) shares the grid with the solver entry
+    d = build_data(origins, R)
+    vel_only = api.GridIndexedData()
+    vel_only.allocateCoords(d.size())
+    vel_only.pCoords()[:] = d.pCoords()
+    vel_only.addValueBlock("vel", vel_only.VEC3F)
+    vel_only.pValues("vel")[:] = d.pValues("vel")
+    api.ProjectNonDivergent(vel_only, 10, vs, handle=h)
+    first = vel_only.pValues("vel").copy()
+    vel_only.pValues("vel")[:] = d.pValues("vel")
+    api.ProjectNonDivergent(vel_only, 10, vs, handle=h)
+    assert np.array_equal(first, vel_only.pValues("vel"))
+    again = cook(h, 96.0)
+    h.release_cache()
+    released = cook(h, 96.0)
+    for n in cold:
+        assert np.array_equal(cold[n], again[n]) and np.array_equal(cold[n], released[n]), n
+    h.reset()
+
+
+def test_cook_cache_disabled_matches(monkeypatch):
+    origins, R = fields.dense_leaves(32), 32
+    vs = 1.0 / R
+    p = api.CombustionParams()
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("HNS_COOK_CACHE", flag)
+        h = api.IndexGridHandle()
+        d = build_data(origins, R)
+        api.CreateIndexGrid(d, h, vs)
+        api.Compute_Sim(d, h, 8, 1.0 / 24.0, vs, p, False)
+        api.Compute_Sim(d, h, 8, 1.0 / 24.0, vs, p, False)  # second cook feeds on the first one's output
+        outs.append(snapshot(d))
+        h.reset()
+    for n in outs[0]:
+        assert np.array_equal(outs[0][n], outs[1][n]), n
+
+
+def test_create_index_grid_keeps_a_matching_handle():
+    origins, R = fields.plume_leaves(8, 1.0, 0.3), 64
+    d = build_data(origins, R)
+    h = api.IndexGridHandle()
+    api.CreateIndexGrid(d, h, 1.0 / R)
+    first = h.ptr
+    api.CreateIndexGrid(d, h, 1.0 / R)
+    assert h.ptr == first                      # topology unchanged: same grid, nothing rebuilt
+    api.CreateIndexGrid(d, h, 2.0 / R)
+    assert h.ptr != first                      # voxel size changed
+    second = h.ptr
+    d2 = build_data(origins[:-3], R)
+    api.CreateIndexGrid(d2, h, 2.0 / R)
+    assert h.ptr != second and h.leaf_count() == len(origins) - 3
+    h.reset()
