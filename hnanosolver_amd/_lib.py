@@ -59,6 +59,7 @@ SIGNATURES = {
     "hns_grid_coords": (_i, [_vp, _vp]),
     "hns_grid_release_cache": (_i, [_vp]),
     "hns_grid_matches": (_i, [_vp, _vp, _u64, C.c_uint]),
+    "hns_grid_export_nanovdb": (_i, [_vp, _vp, _u64, _vp]),
     "hns_grid_launch_tables": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "hns_compute_sim": (_i, [_vp, C.POINTER(hns_field), _i, _i, _f, _f, C.POINTER(hns_combustion_params), _i, _vp]),
     "hns_advect_index_grid": (_i, [_vp, C.POINTER(hns_field), _i, _f, _f, _vp]),

@@ -172,6 +172,17 @@ class IndexGridHandle:
     def set_active_leaves(self, n: int) -> None:
         _raise(lib.hns_grid_set_active_leaves(self._ptr, int(n)))
 
+    def export_nanovdb(self) -> np.ndarray:
+        """The grid as a NanoVDB ``NanoGrid<ValueOnIndex>`` buffer (uint8 array, 32-byte aligned), the reference's own
+        index-grid format (HNanoSolver.cu:375-384)."""
+        size = C.c_uint64(0)
+        _raise(lib.hns_grid_export_nanovdb(self._ptr, None, 0, C.byref(size)))
+        raw = np.zeros(size.value + 32, dtype=np.uint8)
+        shift = (-raw.ctypes.data) % 32
+        buf = raw[shift:shift + size.value]
+        _raise(lib.hns_grid_export_nanovdb(self._ptr, buf.ctypes.data, size.value, C.byref(size)))
+        return buf
+
     def release_cache(self) -> None:
         """Free the device buffers operator calls keep with the grid between cooks."""
         _raise(lib.hns_grid_release_cache(self._ptr))

@@ -198,6 +198,25 @@ struct CombustionParams {  // reference src/Cuda/Kernels.cuh:6-13
 };
 static_assert(sizeof(CombustionParams) == sizeof(hns_combustion_params), "CombustionParams must match the C ABI struct");
 
+// The grid as a NanoVDB NanoGrid<ValueOnIndex> buffer -- the reference's own handle contents (HNanoSolver.cu:375-384) --
+// for code that still wants a nanovdb accessor. The returned storage is over-allocated; `data` points at the 32-byte
+// aligned start of the `size`-byte grid inside it.
+namespace HNS {
+struct NanoVDBBuffer {
+	std::vector<uint8_t> storage;
+	uint8_t* data = nullptr;
+	uint64_t size = 0;
+};
+}  // namespace HNS
+inline HNS::NanoVDBBuffer ExportNanoVDB(const HNS::IndexGridHandle& handle) {
+	HNS::NanoVDBBuffer b;
+	HNS::detail::check(hns_grid_export_nanovdb(handle.get(), nullptr, 0, &b.size));
+	b.storage.resize(b.size + 32);
+	b.data = b.storage.data() + ((32 - (reinterpret_cast<uintptr_t>(b.storage.data()) & 31u)) & 31u);
+	HNS::detail::check(hns_grid_export_nanovdb(handle.get(), b.data, b.size, &b.size));
+	return b;
+}
+
 inline void CreateIndexGrid(HNS::GridIndexedData& data, HNS::IndexGridHandle& handle, const float voxelSize) {
 	HNS::detail::gridFor(data, voxelSize, handle);
 }

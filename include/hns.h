@@ -90,6 +90,11 @@ int hns_grid_matches(const hns_grid*, const int32_t* coords_xyz, uint64_t n_voxe
 /* Operator calls (hns_compute_sim ... hns_divergence) keep their device buffers with the grid between calls, so a cook on
  * an unchanged topology allocates nothing; this frees them early (hns_grid_destroy does it too). */
 int hns_grid_release_cache(hns_grid*);
+/* Serialises the grid as a NanoVDB NanoGrid<ValueOnIndex> buffer (32.7.0 layout), the format the reference keeps its index
+ * grid in (create_index_grid, HNanoSolver.cu:375-384 -> nanovdb voxelsToGrid): same header, tree, node and leaf contents,
+ * so NanoVDB accessors return offset(ijk) = hns_grid_offsets(ijk). *size_out receives the byte size; pass buffer = NULL
+ * to query it. `buffer` must be 32-byte aligned host memory. Works on HOST_ONLY grids. */
+int hns_grid_export_nanovdb(const hns_grid*, void* buffer, uint64_t capacity, uint64_t* size_out);
 /* Copies of the device-built launch tables (inspection / tests; any argument may be NULL): sched = n_active leaf ids in
  * workgroup order; wave_records = n_waves x 56 int32 {leaf0, nbr27[27], leaf1 or -1, nbr27[27]} read by the SOR kernel. */
 int hns_grid_launch_tables(const hns_grid*, int32_t* sched, int32_t* wave_records, uint64_t* n_waves, uint64_t* n_lone);

@@ -42,6 +42,15 @@ static int cpu_checks() {
 	const int32_t q[6] = {1, 2, 3, 8, 2, 3};
 	uint64_t off[2];
 	REQUIRE(hns_grid_offsets(h.get(), q, 2, off) == HNS_OK && off[0] == 1 + 64 + 16 + 3 && off[1] == 512 + 1 + 16 + 3);
+	// the grid in the reference's own handle format (NanoGrid<ValueOnIndex>): header, tree, 1 upper, 1 lower, 2 leaves
+	HNS::NanoVDBBuffer nb = ExportNanoVDB(h);
+	REQUIRE(nb.size == 672 + 64 + 96 + 32 + 270400 + 33856 + 2 * 96 && (reinterpret_cast<uintptr_t>(nb.data) & 31u) == 0);
+	REQUIRE(std::memcmp(nb.data, "NanoVDB0", 8) == 0);
+	uint64_t value_count = 0;
+	std::memcpy(&value_count, nb.data + 656, 8);
+	REQUIRE(value_count == 1 + 2 * 512);
+	REQUIRE(hns_grid_matches(h.get(), reinterpret_cast<const int32_t*>(d.pCoords()), d.size(), HNS_GRID_DEFAULT) == 1);
+	REQUIRE(hns_grid_matches(h.get(), reinterpret_cast<const int32_t*>(d.pCoords()), 512, HNS_GRID_DEFAULT) == 0);
 	// exception mapping: invalid_argument for bad scalars (reference HNanoSolver.cu:12-23)
 	CombustionParams p{0.1f, 0.5f, 1.0f, 23.0f, 1.0f, 0.5f};
 	bool caught = false;

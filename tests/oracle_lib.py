@@ -93,6 +93,11 @@ def reference_samplers():
         "ref_sample_nearest_f": (None, [_vp, _vp, _vp, _i64, _vp]),
         "ref_sample_trilinear_f": (None, [_vp, _vp, _vp, _i64, _vp]),
         "ref_sample_trilinear_v": (None, [_vp, _vp, _vp, _i64, _vp]),
+        "ref_nanovdb_check": (C.c_int, [_vp, _vp, C.c_int]),
+        "ref_nanovdb_query": (None, [_vp, _vp, _i64, _vp, _vp]),
+        "ref_nanovdb_info": (None, [_vp, _vp, _vp, _vp]),
+        "ref_nanovdb_leaves": (_i64, [_vp, _vp, _vp, _vp, _vp]),
+        "ref_nanovdb_host_build": (C.c_uint64, [_vp, _i64, C.c_double, _vp, C.c_uint64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
