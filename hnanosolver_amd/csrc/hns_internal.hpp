@@ -87,6 +87,7 @@ struct hns_grid {
 	uint64_t n_pairs = 0, n_singles = 0;  // waves to launch / how many of them carry a lone leaf
 	std::vector<hns::RbgsGraph> graphs;  // cached hipGraph replays of the pressure loop (dropped when the schedule changes)
 	void* cap_stream = nullptr;          // private capture stream
+	std::mutex graph_mutex;              // guards graphs / cap_stream
 	std::mutex host_mutex;               // guards the lazy host copy of the device-built tables and sim_cache
 	std::vector<hns_sim*> sim_cache;     // device-resident state kept between operator calls (hns_api.hip: make_sim)
 	hns::GridDev dev() const;

@@ -840,39 +840,49 @@ int hns_dev_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, 
 	// is captured once per (buffers, parameters) on a private stream and cached in the grid; the caller's stream only
 	// sees one hipGraphLaunch.
 	if (use_graph && iterations >= 4) {
+		std::lock_guard<std::mutex> lock(g->graph_mutex);  // cooks from several threads may share one grid
 		hns::RbgsGraph* hit = nullptr;
 		for (auto& e : g->graphs)
 			if (e.div == div && e.p_a == p_a && e.p_b == p_b && e.dx2 == dx2 && e.omega == omega && e.iterations == iterations && e.mode == mode) hit = &e;
 		if (!hit) {
-			if (!g->cap_stream) HNS_HIP(hipStreamCreateWithFlags((hipStream_t*)&g->cap_stream, hipStreamNonBlocking));
-			hipStream_t cs = (hipStream_t)g->cap_stream;
-			hipGraph_t graph = nullptr;
-			HNS_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-			float* src = p_a;
-			float* dst = p_b;
-			for (int it = 0; it < iterations; ++it) {
-				launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode, cs);
-				float* tmp = src;
-				src = dst;
-				dst = tmp;
-			}
-			HNS_HIP(hipStreamEndCapture(cs, &graph));
+			// Capture can fail through no fault of this call: on this runtime a synchronising HIP call made by ANOTHER host
+			// thread (a cook on a different grid) invalidates a thread-local capture. Any failure here drops the capture
+			// stream and falls through to the eager loop below; the next call tries again.
 			hipGraphExec_t exec = nullptr;
-			hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-			(void)hipGraphDestroy(graph);
-			if (ie != hipSuccess) {
-				set_error("hns_dev_rbgs_iterate: hipGraphInstantiate failed: %s", hipGetErrorString(ie));
-				return HNS_ERR_HIP;
+			bool ok = g->cap_stream || hipStreamCreateWithFlags((hipStream_t*)&g->cap_stream, hipStreamNonBlocking) == hipSuccess;
+			hipStream_t cs = (hipStream_t)g->cap_stream;
+			if (ok) ok = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess;
+			if (ok) {
+				float* src = p_a;
+				float* dst = p_b;
+				for (int it = 0; it < iterations; ++it) {
+					launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode, cs);
+					float* tmp = src;
+					src = dst;
+					dst = tmp;
+				}
+				hipGraph_t graph = nullptr;
+				ok = hipStreamEndCapture(cs, &graph) == hipSuccess && graph;
+				if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+				if (graph) (void)hipGraphDestroy(graph);
 			}
-			if (g->graphs.size() >= 8) {  // small cache: drop the oldest
-				(void)hipGraphExecDestroy((hipGraphExec_t)g->graphs.front().exec);
-				g->graphs.erase(g->graphs.begin());
+			if (ok) {
+				if (g->graphs.size() >= 8) {  // small cache: drop the oldest
+					(void)hipGraphExecDestroy((hipGraphExec_t)g->graphs.front().exec);
+					g->graphs.erase(g->graphs.begin());
+				}
+				g->graphs.push_back(hns::RbgsGraph{div, p_a, p_b, dx2, omega, iterations, mode, (void*)exec});
+				hit = &g->graphs.back();
+			} else {
+				(void)hipGetLastError();
+				if (g->cap_stream) (void)hipStreamDestroy((hipStream_t)g->cap_stream);
+				g->cap_stream = nullptr;
 			}
-			g->graphs.push_back(hns::RbgsGraph{div, p_a, p_b, dx2, omega, iterations, mode, (void*)exec});
-			hit = &g->graphs.back();
 		}
-		HNS_HIP(hipGraphLaunch((hipGraphExec_t)hit->exec, (hipStream_t)stream));
-		return HNS_OK;
+		if (hit) {
+			HNS_HIP(hipGraphLaunch((hipGraphExec_t)hit->exec, (hipStream_t)stream));
+			return HNS_OK;
+		}
 	}
 
 	float* src = p_a;

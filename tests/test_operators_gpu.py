@@ -282,3 +282,42 @@ def test_create_index_grid_keeps_a_matching_handle():
     api.CreateIndexGrid(d2, h, 2.0 / R)
     assert h.ptr != second and h.leaf_count() == len(origins) - 3
     h.reset()
+
+
+def test_concurrent_cooks_on_one_grid():
+    """Houdini may cook from several threads. Two threads sharing one grid handle: one borrows the cached device
+    buffers, the other works on private ones; both must get the serial answer."""
+    import threading
+
+    origins, R = fields.dense_leaves(32), 32
+    vs = 1.0 / R
+    p = api.CombustionParams()
+    h = api.IndexGridHandle()
+    api.CreateIndexGrid(build_data(origins, R), h, vs)
+    amps = [60.0, 96.0, 140.0, 200.0]
+    serial = []
+    for a in amps:
+        d = build_data(origins, R, amplitude=a)
+        api.Compute_Sim(d, h, 10, 1.0 / 24.0, vs, p, False)
+        serial.append(snapshot(d))
+    results, errors = [None] * len(amps), []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                d = build_data(origins, R, amplitude=amps[i])
+                api.Compute_Sim(d, h, 10, 1.0 / 24.0, vs, p, False)
+                results[i] = snapshot(d)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(amps))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(len(amps)):
+        for n in serial[i]:
+            assert np.array_equal(serial[i][n], results[i][n]), (i, n)
+    h.reset()
