@@ -400,12 +400,16 @@ __global__ __launch_bounds__(64) void k_rbgs_wave(const GridDev g, const float* 
 // LDS rows are kept as separate 16-byte halves LO (z 0..3) / HI (z 4..7) indexed by a row number chosen so that the
 // lateral-neighbour reads of the 64 lanes are linear in the lane id (conflict-free ds_read_b128):
 //   (x', y') x' in -1..8, y' in 0..7 -> 8*(x'+1) + y'          (x'=-1 / 8 are the -x / +x face rows)
-//   (x', -1) -> 87 + 8*x'      (== row (x',0) - 1   mod 16)
-//   (x',  8) -> 96 + 8*x'      (== row (x',7) + 1   mod 16)
+//   (x', -1) -> 87 + 8*x'      (== row (x',0) - 1   mod 16), except x' = 7 -> 86 (see below)
+//   (x',  8) -> 80 + 8*x'      (== row (x',7) + 1   mod 16)
 //   edge rows (-1,-1) (-1,8) (8,-1) (8,8) -> 81..84; depth-2 rows of halo lane h -> 89 + 8*(h/6) + h%6
 // ZM / ZP hold the z=-1 values of the lower tile and the z=8 values of the upper tile (core rows and face rows).
+// 137 rows = 9,864 bytes per wave: 16 waves per CU fit in the 160 KB of LDS (a 153-row numbering that kept row (7,-1)
+// conflict-free too needed 11,016 bytes = 14 waves, i.e. 4.6 rounds of waves per launch at 256^3 instead of 4.0).
 
-#define PR_ROWS 153
+#define PR_ROWS 137
+__host__ __device__ constexpr int pr_row_ym(int x) { return x == 7 ? 86 : 87 + 8 * x; }  // tile row (x, -1)
+__host__ __device__ constexpr int pr_row_yp(int x) { return 80 + 8 * x; }                 // tile row (x, 8)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -480,10 +484,10 @@ constexpr PairLaneTab make_pair_lane_tab() {
 	PairLaneTab T{};
 	for (int l = 0; l < 64; ++l) {
 		const int h = l & 31, f = h >> 3, i = h & 7;
-		const int RA = f == 0 ? i : (f == 1 ? 72 + i : (f == 2 ? 87 + 8 * i : 96 + 8 * i));
+		const int RA = f == 0 ? i : (f == 1 ? 72 + i : (f == 2 ? pr_row_ym(i) : pr_row_yp(i)));
 		const int RB = 89 + 8 * (h / 6) + (h % 6);
-		const int H_xm = f == 0 ? RB : (f == 1 ? 64 + i : (i == 0 ? (f == 2 ? 81 : 82) : (f == 2 ? 87 + 8 * (i - 1) : 96 + 8 * (i - 1))));
-		const int H_xp = f == 1 ? RB : (f == 0 ? 8 + i : (i == 7 ? (f == 2 ? 83 : 84) : (f == 2 ? 87 + 8 * (i + 1) : 96 + 8 * (i + 1))));
+		const int H_xm = f == 0 ? RB : (f == 1 ? 64 + i : (i == 0 ? (f == 2 ? 81 : 82) : (f == 2 ? pr_row_ym(i - 1) : pr_row_yp(i - 1))));
+		const int H_xp = f == 1 ? RB : (f == 0 ? 8 + i : (i == 7 ? (f == 2 ? 83 : 84) : (f == 2 ? pr_row_ym(i + 1) : pr_row_yp(i + 1))));
 		const int H_ym = f == 2 ? RB : (f == 3 ? 8 * (i + 1) + 7 : (i == 0 ? (f == 0 ? 81 : 83) : (f == 0 ? i - 1 : 72 + i - 1)));
 		const int H_yp = f == 3 ? RB : (f == 2 ? 8 * (i + 1) : (i == 7 ? (f == 0 ? 82 : 84) : (f == 0 ? i + 1 : 72 + i + 1)));
 		const int hpar = (i + ((f & 1) ? 0 : 1)) & 1;  // parity of the halo row's x+y: faces -x,-y sit at coordinate -1
@@ -528,7 +532,7 @@ __device__ __forceinline__ PairLaneCtx pair_lane_ctx() {
 	c.hpar = (lt.y >> 16) & 1;
 	c.ew = (c.l >> 2) & 1, c.ea = (c.l >> 1) & 1, c.eb = c.l & 1;
 	c.I = 8 * (c.x + 1) + c.y;
-	c.R_xm = c.I - 8, c.R_xp = c.I + 8, c.R_ym = c.y == 0 ? 87 + 8 * c.x : c.I - 1, c.R_yp = c.y == 7 ? 96 + 8 * c.x : c.I + 1;
+	c.R_xm = c.I - 8, c.R_xp = c.I + 8, c.R_ym = c.y == 0 ? pr_row_ym(c.x) : c.I - 1, c.R_yp = c.y == 7 ? pr_row_yp(c.x) : c.I + 1;
 	return c;
 }
 
