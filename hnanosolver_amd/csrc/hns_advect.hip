@@ -20,8 +20,41 @@ struct Taps {
 	float fx, fy, fz;
 };
 
-// stage nbr27 (for the generic path) and the neighbours' base indices leaf*512 (-1 = absent)
-__device__ __forceinline__ LeafCtx stage_leaf_base(const GridDev& g, int* s_nbr, int* s_base, int block) {
+// ---- 32-bit addressed field access ---------------------------------------------------------------------------------
+// The advection kernels issue ~590 vector ALU instructions per voxel against 23 loads and are bound by VALU issue, not by
+// memory; a large share of those instructions only guards and addresses the taps: a 64-bit multiply-add per address,
+// an index clamp and three "value or 0" selects per out-of-domain-capable tap (IndexSampler<T,0>, Stencils.hpp:83,88).
+// While a field is below 4 GiB all of that is a property of the load instead: a buffer descriptor over the whole field
+// takes a 32-bit byte offset, and the hardware returns 0 for offsets past the end. Taps are therefore carried as the
+// byte offset of the voxel in a float field (voxel * 4; a Vec3f tap is at three times that), and a tap outside the
+// domain is any offset >= kOutside: absent neighbour leaves get kOutside as their base, so no select is needed at all.
+typedef float v3f __attribute__((ext_vector_type(3)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+// raw buffer loads through the LLVM intrinsics (this toolchain's __builtin_amdgcn_raw_buffer_load_b96 returns one dword)
+__device__ v3f hns_buffer_load_v3f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v3f32");
+__device__ float hns_buffer_load_f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+
+constexpr unsigned kOutside = 0xFFFFE000u;        // float-field byte offsets at or above this read as 0 (and 3x it still lies past a Vec3f field)
+constexpr uint64_t kNarrowBytes = 0xFFFF0000ull;  // largest Vec3f field the 32-bit path accepts
+
+__device__ __forceinline__ v4i field_rsrc(const float* p, unsigned bytes) {
+	const unsigned long long a = (unsigned long long)p;
+	v4i r;
+	r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+	r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));  // stride 0: raw buffer
+	r.z = __builtin_amdgcn_readfirstlane((int)bytes);                            // num_records in bytes
+	r.w = 0x00020000;                                                            // 32-bit float data format
+	return r;
+}
+__device__ __forceinline__ f3 ldv(const v4i& r, unsigned o4) {  // Vec3f of the voxel at float-offset o4; 0 outside
+	const v3f v = hns_buffer_load_v3f32(r, (int)(o4 + (o4 << 1)), 0, 0);
+	return f3{v.x, v.y, v.z};
+}
+__device__ __forceinline__ float lds1(const v4i& r, unsigned o4) { return hns_buffer_load_f32(r, (int)o4, 0, 0); }
+
+// stage nbr27 (for the generic path), the neighbours' base indices leaf*512 (-1 = absent) and, for the 32-bit path, their
+// base byte offsets in a float field (kOutside = absent)
+__device__ __forceinline__ LeafCtx stage_leaf_base(const GridDev& g, int* s_nbr, int* s_base, int block, unsigned* s_b4 = nullptr) {
 	LeafCtx c;
 	c.leaf = g.sched ? g.sched[block] : block;
 	c.org = g.origins[c.leaf];
@@ -29,10 +62,16 @@ __device__ __forceinline__ LeafCtx stage_leaf_base(const GridDev& g, int* s_nbr,
 		const int nb = g.nbr27[c.leaf * 27 + threadIdx.x];
 		s_nbr[threadIdx.x] = nb;
 		s_base[threadIdx.x] = nb < 0 ? -1 : nb * 512;
+		if (s_b4) s_b4[threadIdx.x] = nb < 0 ? kOutside : (unsigned)nb * 2048u;
 	}
 	__syncthreads();
 	return c;
 }
+
+struct TapsB {
+	unsigned o[8];  // float-field byte offset of corner (di,dj,dk) at o[di*4+dj*2+dk]; >= kOutside: outside the domain
+	float fx, fy, fz;
+};
 
 // Floor (Stencils.hpp:25-43) + the eight corner indices of TrilinearSampler::stencil (Stencils.hpp:104-114)
 __device__ __forceinline__ Taps make_taps(const GridDev& g, const int* s_nbr, const int* s_base, const int4 org, float x, float y, float z) {
@@ -57,8 +96,39 @@ __device__ __forceinline__ Taps make_taps(const GridDev& g, const int* s_nbr, co
 			T.t[c] = b < 0 ? -1 : b + (lx[di] | ly[dj] | lz[dk]);
 		}
 	} else {
-#pragma unroll 1
-		for (int c = 0; c < 8; ++c) T.t[c] = tap_index(g, s_nbr, org, i + (c >> 2), j + ((c >> 1) & 1), k + (c & 1));
+#pragma unroll
+		for (int c = 0; c < 8; ++c) T.t[c] = tap_index(g, s_nbr, org, i + (c >> 2), j + ((c >> 1) & 1), k + (c & 1));  // unrolled: see make_taps_b
+	}
+	return T;
+}
+
+// the same for the 32-bit path: byte offsets, and an absent leaf needs no test (its base is kOutside)
+__device__ __forceinline__ TapsB make_taps_b(const GridDev& g, const int* s_nbr, const unsigned* s_b4, const int4 org, float x, float y, float z) {
+	TapsB T;
+	const int i = __float2int_rd(x), j = __float2int_rd(y), k = __float2int_rd(z);
+	T.fx = x - (float)i;
+	T.fy = y - (float)j;
+	T.fz = z - (float)k;
+	const int ax0 = (i >> 3) - (org.x >> 3) + 1, ax1 = ((i + 1) >> 3) - (org.x >> 3) + 1;
+	const int ay0 = (j >> 3) - (org.y >> 3) + 1, ay1 = ((j + 1) >> 3) - (org.y >> 3) + 1;
+	const int az0 = (k >> 3) - (org.z >> 3) + 1, az1 = ((k + 1) >> 3) - (org.z >> 3) + 1;
+	const bool near = ((unsigned)ax0 <= 2u) & ((unsigned)ax1 <= 2u) & ((unsigned)ay0 <= 2u) & ((unsigned)ay1 <= 2u) & ((unsigned)az0 <= 2u) &
+	                  ((unsigned)az1 <= 2u);
+	if (near) {
+		const int sx[2] = {ax0 * 9, ax1 * 9}, sy[2] = {ay0 * 3, ay1 * 3}, sz[2] = {az0, az1};
+		const unsigned lx[2] = {(unsigned)(i & 7) << 8, (unsigned)((i + 1) & 7) << 8}, ly[2] = {(unsigned)(j & 7) << 5, (unsigned)((j + 1) & 7) << 5},
+		               lz[2] = {(unsigned)(k & 7) << 2, (unsigned)((k + 1) & 7) << 2};
+#pragma unroll
+		for (int c = 0; c < 8; ++c) {
+			const int di = c >> 2, dj = (c >> 1) & 1, dk = c & 1;
+			T.o[c] = s_b4[sx[di] + sy[dj] + sz[dk]] + (lx[di] | ly[dj] | lz[dk]);
+		}
+	} else {
+#pragma unroll
+		for (int c = 0; c < 8; ++c) {  // unrolled: a rolled loop would index T.o dynamically and push the whole array into LDS
+			const int t = tap_index(g, s_nbr, org, i + (c >> 2), j + ((c >> 1) & 1), k + (c & 1));
+			T.o[c] = t < 0 ? kOutside : (unsigned)t << 2;
+		}
 	}
 	return T;
 }
@@ -81,7 +151,8 @@ __device__ __forceinline__ float tri_f_t(const float* __restrict__ f, const Taps
 }
 
 // IndexSampler<Vec3f,1> on the device branch: per component fmaf(w, b-a, a) (Stencils.hpp:131-135); eight 12-byte taps
-__device__ __forceinline__ float tri_c8(float c0, float c1, float c2, float c3, float c4, float c5, float c6, float c7, const Taps& T) {
+template <class TapsT>
+__device__ __forceinline__ float tri_c8(float c0, float c1, float c2, float c3, float c4, float c5, float c6, float c7, const TapsT& T) {
 	const float z0 = lerp_c(c0, c1, T.fz);
 	const float z1 = lerp_c(c2, c3, T.fz);
 	const float z2 = lerp_c(c4, c5, T.fz);
@@ -100,6 +171,46 @@ __device__ __forceinline__ f3 tri_v_t(const float* __restrict__ u, const Taps& T
 	r.y = tri_c8(c[0].y, c[1].y, c[2].y, c[3].y, c[4].y, c[5].y, c[6].y, c[7].y, T);
 	r.z = tri_c8(c[0].z, c[1].z, c[2].z, c[3].z, c[4].z, c[5].z, c[6].z, c[7].z, T);
 	return r;
+}
+
+__device__ __forceinline__ f3 tri_v_b(const v4i& ru, const TapsB& T) {
+	f3 c[8];
+#pragma unroll
+	for (int q = 0; q < 8; ++q) c[q] = ldv(ru, T.o[q]);
+	f3 r;
+	r.x = tri_c8(c[0].x, c[1].x, c[2].x, c[3].x, c[4].x, c[5].x, c[6].x, c[7].x, T);
+	r.y = tri_c8(c[0].y, c[1].y, c[2].y, c[3].y, c[4].y, c[5].y, c[6].y, c[7].y, T);
+	r.z = tri_c8(c[0].z, c[1].z, c[2].z, c[3].z, c[4].z, c[5].z, c[6].z, c[7].z, T);
+	return r;
+}
+
+__device__ __forceinline__ float tri_f_b(const v4i& rf, const TapsB& T) {
+	const float z0 = lerp_f(lds1(rf, T.o[0]), lds1(rf, T.o[1]), T.fz);
+	const float z1 = lerp_f(lds1(rf, T.o[2]), lds1(rf, T.o[3]), T.fz);
+	const float z2 = lerp_f(lds1(rf, T.o[4]), lds1(rf, T.o[5]), T.fz);
+	const float z3 = lerp_f(lds1(rf, T.o[6]), lds1(rf, T.o[7]), T.fz);
+	const float y0 = lerp_f(z0, z1, T.fy);
+	const float y1 = lerp_f(z2, z3, T.fy);
+	return lerp_f(y0, y1, T.fx);
+}
+
+// float-field byte offset of the face neighbour of own voxel n along AXIS/DIR (>= kOutside where that leaf is absent)
+template <int AXIS, int DIR>
+__device__ __forceinline__ unsigned nbr_off(const unsigned* s_b4, unsigned own, int n) {
+	constexpr int shift = AXIS == 0 ? 6 : (AXIS == 1 ? 3 : 0);
+	constexpr int stride = 1 << shift;
+	constexpr int dslot = AXIS == 0 ? 9 : (AXIS == 1 ? 3 : 1);
+	const int c = (n >> shift) & 7;
+	const bool inside = DIR > 0 ? c != 7 : c != 0;
+	return inside ? own + (unsigned)(DIR * stride * 4) : s_b4[13 + DIR * dslot] + (unsigned)((n - DIR * 7 * stride) << 2);
+}
+__device__ __forceinline__ void nbr6_b(const unsigned* s_b4, unsigned own, int n, unsigned (&o)[6]) {
+	o[0] = nbr_off<0, -1>(s_b4, own, n);
+	o[1] = nbr_off<0, 1>(s_b4, own, n);
+	o[2] = nbr_off<1, -1>(s_b4, own, n);
+	o[3] = nbr_off<1, 1>(s_b4, own, n);
+	o[4] = nbr_off<2, -1>(s_b4, own, n);
+	o[5] = nbr_off<2, 1>(s_b4, own, n);
 }
 
 // flat index of the face neighbour of voxel n of the workgroup's leaf along AXIS in direction DIR, -1 = outside
@@ -129,6 +240,58 @@ __device__ __forceinline__ void nbr6(const int* s_base, int leaf, int n, int (&t
 // ---------------------------------------------------------------------------------------------------------------
 // advect_vector (reference Kernel.cu:354-453): BFECC self-advection of the velocity, clamped
 // ---------------------------------------------------------------------------------------------------------------
+
+// 32-bit addressed form (no collision field): same loads and arithmetic as the generic kernel below
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_advect_vector_n(const GridDev g, const float* __restrict__ u, float* __restrict__ out, const float scaled_dt) {
+	__shared__ int s_nbr[27];
+	__shared__ int s_base[27];
+	__shared__ unsigned s_b4[27];
+	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4);
+	const int n = threadIdx.x;
+	const int idx = L.leaf * 512 + n;
+	const float px = (float)(L.org.x + (n >> 6)), py = (float)(L.org.y + ((n >> 3) & 7)), pz = (float)(L.org.z + (n & 7));
+	const v4i ru = field_rsrc(u, (unsigned)g.n_leaves * 6144u);
+	const unsigned own = (unsigned)idx << 2;
+
+	const f3 vo = ldv(ru, own);
+	float sx = px - scaled_dt * vo.x, sy = py - scaled_dt * vo.y, sz = pz - scaled_dt * vo.z;  // backPos (Kernel.cu:374)
+	f3 vf = {0.0f, 0.0f, 0.0f}, vb = {0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+	for (int pass = 0; pass < 2; ++pass) {
+		const TapsB T = make_taps_b(g, s_nbr, s_b4, L.org, sx, sy, sz);
+		const f3 v = tri_v_b(ru, T);
+		if (pass == 0) {
+			vf = v;
+			sx = sx + scaled_dt * v.x, sy = sy + scaled_dt * v.y, sz = sz + scaled_dt * v.z;  // Kernel.cu:387
+		} else {
+			vb = v;
+		}
+	}
+	f3 vc = {vf.x + 0.5f * (vo.x - vb.x), vf.y + 0.5f * (vo.y - vb.y), vf.z + 0.5f * (vo.z - vb.z)};
+	unsigned nb[6];
+	nbr6_b(s_b4, own, n, nb);
+	f3 mn = vo, mx = vo;
+#pragma unroll
+	for (int d = 0; d < 6; ++d) {
+		const f3 nv = ldv(ru, nb[d]);
+		mn.x = fminf(mn.x, nv.x);
+		mx.x = fmaxf(mx.x, nv.x);
+		mn.y = fminf(mn.y, nv.y);
+		mx.y = fmaxf(mx.y, nv.y);
+		mn.z = fminf(mn.z, nv.z);
+		mx.z = fmaxf(mx.z, nv.z);
+	}
+	mn.x = fminf(mn.x, vf.x);
+	mx.x = fmaxf(mx.x, vf.x);
+	mn.y = fminf(mn.y, vf.y);
+	mx.y = fmaxf(mx.y, vf.y);
+	mn.z = fminf(mn.z, vf.z);
+	mx.z = fmaxf(mx.z, vf.z);
+	vc.x = fmaxf(mn.x, fminf(vc.x, mx.x));
+	vc.y = fmaxf(mn.y, fminf(vc.y, mx.y));
+	vc.z = fmaxf(mn.z, fminf(vc.z, mx.z));
+	st3(out, idx, vc);
+}
 
 template <bool COLL>
 __global__ __launch_bounds__(512) void k_advect_vector(const GridDev g, const float* __restrict__ u, float* __restrict__ out,
@@ -287,6 +450,76 @@ __device__ __forceinline__ void interp_from_taps(const Taps& T, int oob, int (&i
 	for (int q = 0; q < 8; ++q) ix[q] = T.t[perm[q]] < 0 ? oob : T.t[perm[q]];
 }
 
+// 32-bit addressed form (no collision field). Out-of-domain taps read element g.oob, as in the generic kernel.
+__global__ __launch_bounds__(512) void k_advect_scalars_n(const GridDev g, const float* __restrict__ u, const ScalarPtrs P, const float scaled_dt) {
+	__shared__ int s_nbr[27];
+	__shared__ int s_base[27];
+	__shared__ unsigned s_b4[27];
+	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4);
+	const int n = threadIdx.x;
+	const int idx = L.leaf * 512 + n;
+	const float px = (float)(L.org.x + (n >> 6)), py = (float)(L.org.y + ((n >> 3) & 7)), pz = (float)(L.org.z + (n & 7));
+	const unsigned bytes1 = (unsigned)g.n_leaves * 2048u;
+	const v4i ru = field_rsrc(u, bytes1 * 3u);
+	const unsigned own = (unsigned)idx << 2, oob4 = (unsigned)g.oob << 2;
+
+	const f3 vc = ldv(ru, own);
+	const float bx = px - scaled_dt * vc.x, by = py - scaled_dt * vc.y, bz = pz - scaled_dt * vc.z;
+	unsigned bo[8], fo[8];
+	float bw[8], fw[8];
+	const int perm[8] = {0, 4, 2, 6, 1, 5, 3, 7};  // setupInterpolation's order 000,100,010,110,001,... of (x,y,z) (Kernel.cu:163-196)
+	{
+		const TapsB T = make_taps_b(g, s_nbr, s_b4, L.org, bx, by, bz);
+		const float tx = T.fx, ty = T.fy, tz = T.fz, itx = 1.0f - tx, ity = 1.0f - ty, itz = 1.0f - tz;
+		const float w00 = itx * ity, w10 = tx * ity, w01 = itx * ty, w11 = tx * ty;
+		bw[0] = w00 * itz, bw[1] = w10 * itz, bw[2] = w01 * itz, bw[3] = w11 * itz, bw[4] = w00 * tz, bw[5] = w10 * tz, bw[6] = w01 * tz, bw[7] = w11 * tz;
+#pragma unroll
+		for (int q = 0; q < 8; ++q) bo[q] = T.o[perm[q]] >= kOutside ? oob4 : T.o[perm[q]];
+	}
+	f3 vf = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+	for (int q = 0; q < 8; ++q) {  // velF = velF + v * w (Kernel.cu:201-206), unfused
+		const f3 v = ldv(ru, bo[q]);
+		vf.x = vf.x + bw[q] * v.x;
+		vf.y = vf.y + bw[q] * v.y;
+		vf.z = vf.z + bw[q] * v.z;
+	}
+	{
+		const TapsB T = make_taps_b(g, s_nbr, s_b4, L.org, bx + scaled_dt * vf.x, by + scaled_dt * vf.y, bz + scaled_dt * vf.z);
+		const float tx = T.fx, ty = T.fy, tz = T.fz, itx = 1.0f - tx, ity = 1.0f - ty, itz = 1.0f - tz;
+		const float w00 = itx * ity, w10 = tx * ity, w01 = itx * ty, w11 = tx * ty;
+		fw[0] = w00 * itz, fw[1] = w10 * itz, fw[2] = w01 * itz, fw[3] = w11 * itz, fw[4] = w00 * tz, fw[5] = w10 * tz, fw[6] = w01 * tz, fw[7] = w11 * tz;
+#pragma unroll
+		for (int q = 0; q < 8; ++q) fo[q] = T.o[perm[q]] >= kOutside ? oob4 : T.o[perm[q]];
+	}
+	unsigned nb[6];
+	nbr6_b(s_b4, own, n, nb);
+#pragma unroll
+	for (int d = 0; d < 6; ++d) nb[d] = nb[d] >= kOutside ? oob4 : nb[d];
+	for (int s = 0; s < P.n; ++s) {
+		const v4i rf = field_rsrc(P.in[s], bytes1);
+		const float phiOrig = lds1(rf, own);
+		float phiF = 0.0f, phiB = 0.0f;
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			phiF = __fmaf_rn(lds1(rf, bo[q]), bw[q], phiF);
+			phiB = __fmaf_rn(lds1(rf, fo[q]), fw[q], phiB);
+		}
+		const float error = phiOrig - phiB;
+		const float phiCorr = __fmaf_rn(0.5f, error, phiF);
+		float mn = phiOrig, mx = phiOrig;
+#pragma unroll
+		for (int d = 0; d < 6; ++d) {
+			const float v = lds1(rf, nb[d]);
+			mn = fminf(mn, v);
+			mx = fmaxf(mx, v);
+		}
+		mn = fminf(mn, phiF);
+		mx = fmaxf(mx, phiF);
+		P.out[s][idx] = fmaxf(mn, fminf(phiCorr, mx));
+	}
+}
+
 template <bool COLL>
 __global__ __launch_bounds__(512) void k_advect_scalars(const GridDev g, const float* __restrict__ u, const ScalarPtrs P,
                                                         const float* __restrict__ sdf, const float scaled_dt) {
@@ -360,6 +593,12 @@ __global__ __launch_bounds__(512) void k_advect_scalars(const GridDev g, const f
 
 using namespace hns;
 
+// the 32-bit addressed kernels apply while a Vec3f field stays below kNarrowBytes; HNS_ADVECT=generic forces the 64-bit ones (A/B, tests)
+static bool narrow_fields(const hns_grid* g) {
+	static const bool generic = getenv("HNS_ADVECT") && strcmp(getenv("HNS_ADVECT"), "generic") == 0;
+	return !generic && (uint64_t)g->topo.n_leaves * 6144u <= hns::kNarrowBytes;
+}
+
 extern "C" {
 
 int hns_dev_advect_vector(hns_grid* g, const float* vel3, float* out3, const float* sdf, int has_collision, float dt, float inv_dx, void* stream) {
@@ -371,6 +610,8 @@ int hns_dev_advect_vector(hns_grid* g, const float* vel3, float* out3, const flo
 	const dim3 grid((unsigned)g->n_active), block(512);
 	if (has_collision && sdf)
 		hipLaunchKernelGGL(k_advect_vector<true>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, out3, sdf, scaled_dt, inv_dx);
+	else if (narrow_fields(g))
+		hipLaunchKernelGGL(k_advect_vector_n, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, out3, scaled_dt);
 	else
 		hipLaunchKernelGGL(k_advect_vector<false>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, out3, sdf, scaled_dt, inv_dx);
 	return launch_status("hns_dev_advect_vector");
@@ -411,6 +652,8 @@ int hns_dev_advect_scalars(hns_grid* g, const float* vel3, const float* const* i
 		}
 		if (has_collision && sdf)
 			hipLaunchKernelGGL(k_advect_scalars<true>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, P, sdf, scaled_dt);
+		else if (narrow_fields(g))
+			hipLaunchKernelGGL(k_advect_scalars_n, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, P, scaled_dt);
 		else
 			hipLaunchKernelGGL(k_advect_scalars<false>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, P, sdf, scaled_dt);
 	}
