@@ -93,6 +93,10 @@ struct hns_grid {
 	hns::GridDev dev() const;
 };
 
+// implemented in hns_pressure.hip: hns_dev_rbgs_iterate with the option of starting from p = 0 without reading (or clearing) p_a
+extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int* result_in_b,
+                                void* stream, bool from_zero);
+
 // implemented in hns_gridbuild.hip
 int hns_grid_upload(hns_grid* g);           // device build of every table from topo.origins
 void hns_grid_free_device(hns_grid* g);

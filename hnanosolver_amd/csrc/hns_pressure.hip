@@ -536,7 +536,10 @@ __device__ __forceinline__ PairLaneCtx pair_lane_ctx() {
 	return c;
 }
 
-// issue every global load of one pair (no waits here: the values are consumed in pair_compute)
+// issue every global load of one pair (no waits here: the values are consumed in pair_compute).
+// ZERO: p_in is known to be 0 everywhere (first iteration of a solve, which is never warm-started: HNanoSolver.cu:113),
+// so none of it is read; only div is.
+template <bool ZERO>
 __device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __restrict__ rec, const float* __restrict__ div,
                                             const float* __restrict__ p_in) {
 	PairIn in;
@@ -548,12 +551,18 @@ __device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __r
 	const int n_zm = __builtin_amdgcn_readfirstlane(rec[1 + 12]);
 	const int n_zp = __builtin_amdgcn_readfirstlane(single ? rec[1 + 14] : rec[28 + 1 + 14]);
 	const int l = c.l;
-	in.P0 = glb_rowp(p_in, in.leaf0, l), in.P1 = glb_rowp(p_in, in.leaf1, l);
+	const RowP zero_row = {{v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}}};
 	in.D0 = glb_rowp(div, in.leaf0, l), in.D1 = glb_rowp(div, in.leaf1, l);
-	in.zlo = *reinterpret_cast<const float2*>(p_in + (size_t)(n_zm < 0 ? 0 : n_zm) * 512 + l * 8 + 6);
-	in.zhi = *reinterpret_cast<const float2*>(p_in + (size_t)(n_zp < 0 ? 0 : n_zp) * 512 + l * 8);
-	if (n_zm < 0) in.zlo = make_float2(0.0f, 0.0f);
-	if (n_zp < 0) in.zhi = make_float2(0.0f, 0.0f);
+	if (ZERO) {
+		in.P0 = in.P1 = zero_row;
+		in.zlo = in.zhi = make_float2(0.0f, 0.0f);
+	} else {
+		in.P0 = glb_rowp(p_in, in.leaf0, l), in.P1 = glb_rowp(p_in, in.leaf1, l);
+		in.zlo = *reinterpret_cast<const float2*>(p_in + (size_t)(n_zm < 0 ? 0 : n_zm) * 512 + l * 8 + 6);
+		in.zhi = *reinterpret_cast<const float2*>(p_in + (size_t)(n_zp < 0 ? 0 : n_zp) * 512 + l * 8);
+		if (n_zm < 0) in.zlo = make_float2(0.0f, 0.0f);
+		if (n_zp < 0) in.zhi = make_float2(0.0f, 0.0f);
+	}
 	const int n_zh = c.par ? n_zm : n_zp;  // this lane's z-halo red voxel: below leaf0 if par, else above leaf1
 	in.zh_ok = n_zh >= 0;
 	in.d_zh = div[(size_t)(n_zh < 0 ? 0 : n_zh) * 512 + l * 8 + (c.par ? 7 : 0)];
@@ -576,9 +585,14 @@ __device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __r
 	const int srcA = f == 0 ? 56 + i : (f == 1 ? i : (f == 2 ? i * 8 + 7 : i * 8));
 	const int srcB = f == 0 ? 48 + i : (f == 1 ? 8 + i : (f == 2 ? i * 8 + 6 : i * 8 + 1));
 	in.f_ok = n_f >= 0;
+	in.HD = glb_rowp(div, n_f, srcA);
+	if (ZERO) {
+		in.HA = in.HB = in.ER = zero_row;
+		in.e_val = 0.0f;
+		return in;
+	}
 	in.HA = glb_rowp(p_in, n_f, srcA);
 	in.HB = glb_rowp(p_in, n_f, srcB);
-	in.HD = glb_rowp(div, n_f, srcA);
 	// the halo row's own z-neighbour outside the pair: z=-1 for the lower leaf, z=8 for the upper leaf
 	const int n_e = c.w ? ne1 : ne0;
 	const float ev = p_in[(size_t)(n_e < 0 ? 0 : n_e) * 512 + srcA * 8 + (c.w ? 0 : 7)];
@@ -656,11 +670,12 @@ __device__ __forceinline__ void pair_compute(PairTile& S, const PairLaneCtx& c, 
 	}
 }
 
+template <bool ZERO>
 __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs, const float* __restrict__ div, const float* __restrict__ p_in,
                                                   float* __restrict__ p_out, const float dx2, const float omega) {
 	__shared__ __attribute__((aligned(16))) PairTile S;
 	const PairLaneCtx c = pair_lane_ctx();
-	const PairIn in = pair_load(c, pairs + (size_t)blockIdx.x * 56, div, p_in);
+	const PairIn in = pair_load<ZERO>(c, pairs + (size_t)blockIdx.x * 56, div, p_in);
 	pair_compute(S, c, in, p_out, dx2, omega);
 }
 
@@ -812,9 +827,16 @@ int hns_dev_rbgs_color(hns_grid* g, const float* div, float* p, float dx, float 
 	return launch_status("hns_dev_rbgs_color");
 }
 
-// one full (red, black) iteration src -> dst
-static void launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* div, const float* src, float* dst, float dx2, float omega, int mode,
-                                  hipStream_t st) {
+// one full (red, black) iteration src -> dst. src_is_zero: the caller vouches that src is 0 on every leaf (first
+// iteration of a solve): the pair kernel then skips reading it; the other forms get an explicit clear.
+static void launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* div, float* src, float* dst, float dx2, float omega, int mode,
+                                  hipStream_t st, bool src_is_zero = false) {
+	const bool pair_form = !(mode == 1 || mode == 2 || !g->d_pairs || (mode == 0 && g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs));
+	if (src_is_zero && pair_form) {
+		hipLaunchKernelGGL(k_rbgs_pair<true>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, (const float*)src, dst, dx2, omega);
+		return;
+	}
+	if (src_is_zero) (void)hipMemsetAsync(src, 0, sizeof(float) * 512 * (size_t)g->topo.n_leaves, st);
 	if (mode == 1) {
 		hipLaunchKernelGGL(k_rbgs_fused, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, src, dst, dx2, omega);
 	} else if (mode == 2 || !g->d_pairs || (mode == 0 && g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs)) {
@@ -823,21 +845,32 @@ static void launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* d
 		hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_active), dim3(64), 0, st, gd, div, src, dst, dx2, omega);
 	} else {
 		// one launch: the record list holds the z-adjacent pairs and, as {leaf, nbr27, -1, ...}, the leaves that found no partner
-		hipLaunchKernelGGL(k_rbgs_pair, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, src, dst, dx2, omega);
+		hipLaunchKernelGGL(k_rbgs_pair<false>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, (const float*)src, dst, dx2, omega);
 	}
 }
 
 int hns_dev_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int* result_in_b,
                          void* stream) {
+	return hns_rbgs_iterate(g, div, p_a, p_b, dx, omega, iterations, result_in_b, stream, false);
+}
+
+// from_zero: the solve starts from p = 0 (the reference never warm-starts, HNanoSolver.cu:113 / PressureProjection.cu:35) and
+// p_a's content is irrelevant: the first sweep does not read it, so the caller need not clear it either.
+int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int* result_in_b, void* stream,
+                     bool from_zero) {
 	if (int rc = check_grid(g, "hns_dev_rbgs_iterate")) return rc;
 	NULLCHK(!div || !p_a || !p_b, "hns_dev_rbgs_iterate");
 	if (p_a == p_b) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dev_rbgs_iterate: p_a and p_b must be distinct buffers");
 	if (iterations < 0) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dev_rbgs_iterate: negative iteration count");
 	if (result_in_b) *result_in_b = iterations & 1;
-	if (g->n_active == 0 || iterations == 0) return HNS_OK;
+	if (g->n_active == 0 || iterations == 0) {
+		if (from_zero) HNS_HIP(hipMemsetAsync(p_a, 0, sizeof(float) * 512 * (size_t)g->topo.n_leaves, (hipStream_t)stream));  // the result is p_a = 0
+		return HNS_OK;
+	}
 	const float dx2 = dx * dx;  // Kernel.cu:608
 	const GridDev gd = g->dev();
-	static const int mode = !getenv("HNS_RBGS") ? 0 : (strcmp(getenv("HNS_RBGS"), "block") == 0 ? 1 : (strcmp(getenv("HNS_RBGS"), "wave") == 0 ? 2 : 0));
+	static const int mode_env = !getenv("HNS_RBGS") ? 0 : (strcmp(getenv("HNS_RBGS"), "block") == 0 ? 1 : (strcmp(getenv("HNS_RBGS"), "wave") == 0 ? 2 : 0));
+	const int mode = mode_env | (from_zero ? 256 : 0);  // graph-cache key: kernel form + whether the first sweep skips p_a
 	static const bool use_graph = !(getenv("HNS_GRAPH") && strcmp(getenv("HNS_GRAPH"), "0") == 0);
 
 	// The loop is launch-bound on small grids (a 128^3 sweep is a few microseconds): replay it as one hipGraph. The graph
@@ -860,7 +893,7 @@ int hns_dev_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, 
 				float* src = p_a;
 				float* dst = p_b;
 				for (int it = 0; it < iterations; ++it) {
-					launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode, cs);
+					launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode_env, cs, from_zero && it == 0);
 					float* tmp = src;
 					src = dst;
 					dst = tmp;
@@ -892,7 +925,7 @@ int hns_dev_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, 
 	float* src = p_a;
 	float* dst = p_b;
 	for (int it = 0; it < iterations; ++it) {
-		launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode, (hipStream_t)stream);
+		launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode_env, (hipStream_t)stream, from_zero && it == 0);
 		float* tmp = src;
 		src = dst;
 		dst = tmp;
