@@ -827,25 +827,26 @@ int hns_dev_rbgs_color(hns_grid* g, const float* div, float* p, float dx, float 
 	return launch_status("hns_dev_rbgs_color");
 }
 
-// one full (red, black) iteration src -> dst. src_is_zero: the caller vouches that src is 0 on every leaf (first
-// iteration of a solve): the pair kernel then skips reading it; the other forms get an explicit clear.
-static void launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* div, float* src, float* dst, float dx2, float omega, int mode,
+// which form sweeps this grid: the pair kernel, unless a debug mode or the shape of the grid says otherwise
+static bool uses_pair_form(const hns_grid* g, int mode) {
+	// one leaf per wave is also the better choice for SMALL IRREGULAR grids, which are latency-bound (twice as many, shorter
+	// waves; no half-empty pair waves). Measured on the 3.9k-leaf plume: 9.0 vs 11.9 us per iteration.
+	return !(mode == 1 || mode == 2 || !g->d_pairs || (mode == 0 && g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs));
+}
+
+// one full (red, black) iteration src -> dst. src_is_zero (pair form only): the caller vouches that src is 0 on every
+// leaf (first iteration of a solve) and the kernel skips reading it.
+static void launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* div, const float* src, float* dst, float dx2, float omega, int mode,
                                   hipStream_t st, bool src_is_zero = false) {
-	const bool pair_form = !(mode == 1 || mode == 2 || !g->d_pairs || (mode == 0 && g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs));
-	if (src_is_zero && pair_form) {
-		hipLaunchKernelGGL(k_rbgs_pair<true>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, (const float*)src, dst, dx2, omega);
-		return;
-	}
-	if (src_is_zero) (void)hipMemsetAsync(src, 0, sizeof(float) * 512 * (size_t)g->topo.n_leaves, st);
 	if (mode == 1) {
 		hipLaunchKernelGGL(k_rbgs_fused, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, src, dst, dx2, omega);
-	} else if (mode == 2 || !g->d_pairs || (mode == 0 && g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs)) {
-		// one leaf per wave: also the better choice for SMALL IRREGULAR grids, which are latency-bound (twice as many, shorter
-		// waves; no half-empty pair waves). Measured on the 3.9k-leaf plume: 9.0 vs 11.9 us per iteration.
+	} else if (!uses_pair_form(g, mode)) {
 		hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_active), dim3(64), 0, st, gd, div, src, dst, dx2, omega);
+	} else if (src_is_zero) {
+		hipLaunchKernelGGL(k_rbgs_pair<true>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, src, dst, dx2, omega);
 	} else {
 		// one launch: the record list holds the z-adjacent pairs and, as {leaf, nbr27, -1, ...}, the leaves that found no partner
-		hipLaunchKernelGGL(k_rbgs_pair<false>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, (const float*)src, dst, dx2, omega);
+		hipLaunchKernelGGL(k_rbgs_pair<false>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, src, dst, dx2, omega);
 	}
 }
 
@@ -870,12 +871,17 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 	const float dx2 = dx * dx;  // Kernel.cu:608
 	const GridDev gd = g->dev();
 	static const int mode_env = !getenv("HNS_RBGS") ? 0 : (strcmp(getenv("HNS_RBGS"), "block") == 0 ? 1 : (strcmp(getenv("HNS_RBGS"), "wave") == 0 ? 2 : 0));
+	if (from_zero && !uses_pair_form(g, mode_env)) {  // the other forms read their input: give them the zeros
+		HNS_HIP(hipMemsetAsync(p_a, 0, sizeof(float) * 512 * (size_t)g->topo.n_leaves, (hipStream_t)stream));
+		from_zero = false;
+	}
 	const int mode = mode_env | (from_zero ? 256 : 0);  // graph-cache key: kernel form + whether the first sweep skips p_a
-	static const bool use_graph = !(getenv("HNS_GRAPH") && strcmp(getenv("HNS_GRAPH"), "0") == 0);
+	static const bool use_graph = getenv("HNS_GRAPH") && strcmp(getenv("HNS_GRAPH"), "1") == 0;
 
-	// The loop is launch-bound on small grids (a 128^3 sweep is a few microseconds): replay it as one hipGraph. The graph
-	// is captured once per (buffers, parameters) on a private stream and cached in the grid; the caller's stream only
-	// sees one hipGraphLaunch.
+	// Optional (HNS_GRAPH=1): replay the loop as one hipGraph, captured once per (buffers, parameters) on a private stream
+	// and cached in the grid. Off by default: measured on MI355X the eager loop is never launch-bound (64^3: 4.11 vs
+	// 4.14 us per sweep, 128^3: 8.3 vs 8.2, 256^3: 39.2 vs 39.1 with / without the graph), and stream capture is
+	// fragile when several host threads cook at once (a legacy-stream call in another thread fails while a capture is open).
 	if (use_graph && iterations >= 4) {
 		std::lock_guard<std::mutex> lock(g->graph_mutex);  // cooks from several threads may share one grid
 		hns::RbgsGraph* hit = nullptr;

@@ -28,7 +28,7 @@ python3 - "$out" <<'PY'
 import json, sys
 out = sys.argv[1]
 p = json.load(open(out + "/pmc.json"))
-k = p["hns::k_rbgs_pair"]
+k = p.get("hns::k_rbgs_pair<false>") or p["hns::k_rbgs_pair"]
 fetch_kb, write_kb = k["FETCH_SIZE"]["mean"], k["WRITE_SIZE"]["mean"]
 j = {"config": "256", "kernel": "k_rbgs_pair", "hbm_bytes_per_launch": 1024.0 * (2.0 * fetch_kb + write_kb), "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
      "correction": "FETCH_SIZE x2 (gfx950: reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported (= 4 B/voxel exactly)",
