@@ -33,6 +33,8 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // raw buffer loads through the LLVM intrinsics (this toolchain's __builtin_amdgcn_raw_buffer_load_b96 returns one dword)
 __device__ v3f hns_buffer_load_v3f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v3f32");
 __device__ float hns_buffer_load_f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+typedef float v2f32 __attribute__((ext_vector_type(2)));
+__device__ v2f32 hns_buffer_load_v2f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
 
 constexpr unsigned kOutside = 0xFFFFE000u;        // float-field byte offsets at or above this read as 0 (and 3x it still lies past a Vec3f field)
 constexpr uint64_t kNarrowBytes = 0xFFFF0000ull;  // largest Vec3f field the 32-bit path accepts
@@ -51,6 +53,18 @@ __device__ __forceinline__ f3 ldv(const v4i& r, unsigned o4) {  // Vec3f of the 
 	return f3{v.x, v.y, v.z};
 }
 __device__ __forceinline__ float lds1(const v4i& r, unsigned o4) { return hns_buffer_load_f32(r, (int)o4, 0, 0); }
+
+// The two z-corners of a trilinear column, float field: when they are neighbours in memory (same leaf, k & 7 != 7) one
+// 8-byte load fetches both; otherwise the second comes from its own load, which only the few lanes whose column
+// straddles a leaf face execute. A load instruction costs the L1 the same 16 cycles per wave whatever its width, and
+// the scalar gathers are what bounds advect_scalars, so halving them is the point. Reading 4 bytes past `lo` is safe:
+// the descriptor's bounds check covers the end of the field.
+__device__ __forceinline__ void ld_zpair(const v4i& r, unsigned lo, unsigned hi, float& a, float& b) {
+	const v2f32 v = hns_buffer_load_v2f32(r, (int)lo, 0, 0);
+	a = v.x;
+	b = v.y;
+	if (hi != lo + 4u) b = lds1(r, hi);
+}
 
 // stage nbr27 (for the generic path), the neighbours' base indices leaf*512 (-1 = absent) and, for the 32-bit path, their
 // base byte offsets in a float field (kOutside = absent)
@@ -499,11 +513,17 @@ __global__ __launch_bounds__(512) void k_advect_scalars_n(const GridDev g, const
 	for (int s = 0; s < P.n; ++s) {
 		const v4i rf = field_rsrc(P.in[s], bytes1);
 		const float phiOrig = lds1(rf, own);
+		float vb[8], vf8[8];  // corner q and q+4 of the interpolation order differ only in z
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			ld_zpair(rf, bo[q], bo[q + 4], vb[q], vb[q + 4]);
+			ld_zpair(rf, fo[q], fo[q + 4], vf8[q], vf8[q + 4]);
+		}
 		float phiF = 0.0f, phiB = 0.0f;
 #pragma unroll
 		for (int q = 0; q < 8; ++q) {
-			phiF = __fmaf_rn(lds1(rf, bo[q]), bw[q], phiF);
-			phiB = __fmaf_rn(lds1(rf, fo[q]), fw[q], phiB);
+			phiF = __fmaf_rn(vb[q], bw[q], phiF);
+			phiB = __fmaf_rn(vf8[q], fw[q], phiB);
 		}
 		const float error = phiOrig - phiB;
 		const float phiCorr = __fmaf_rn(0.5f, error, phiF);
