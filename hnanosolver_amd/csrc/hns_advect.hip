@@ -383,6 +383,51 @@ __global__ __launch_bounds__(512) void k_advect_vector(const GridDev g, const fl
 // advect_scalar (reference Kernel.cu:269-352): single field, nested-lerp trilinear
 // ---------------------------------------------------------------------------------------------------------------
 
+// 32-bit addressed form (no collision field)
+__global__ __launch_bounds__(512) void k_advect_scalar_n(const GridDev g, const float* __restrict__ u, const float* __restrict__ in, float* __restrict__ out,
+                                                         const float scaled_dt) {
+	__shared__ int s_nbr[27];
+	__shared__ int s_base[27];
+	__shared__ unsigned s_b4[27];
+	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4);
+	const int n = threadIdx.x;
+	const int idx = L.leaf * 512 + n;
+	const float px = (float)(L.org.x + (n >> 6)), py = (float)(L.org.y + ((n >> 3) & 7)), pz = (float)(L.org.z + (n & 7));
+	const unsigned bytes1 = (unsigned)g.n_leaves * 2048u, own = (unsigned)idx << 2;
+	const v4i ru = field_rsrc(u, bytes1 * 3u), rf = field_rsrc(in, bytes1);
+
+	const float phiOrig = lds1(rf, own);
+	const f3 vc = ldv(ru, own);
+	float sx = px - scaled_dt * vc.x, sy = py - scaled_dt * vc.y, sz = pz - scaled_dt * vc.z;
+	float phiForward = 0.0f, phiBackward = 0.0f;
+#pragma unroll 1
+	for (int pass = 0; pass < 2; ++pass) {
+		const TapsB T = make_taps_b(g, s_nbr, s_b4, L.org, sx, sy, sz);
+		const float phi = tri_f_b(rf, T);
+		if (pass == 0) {
+			phiForward = phi;
+			const f3 vf = tri_v_b(ru, T);  // same eight taps as phiForward
+			sx = sx + scaled_dt * vf.x, sy = sy + scaled_dt * vf.y, sz = sz + scaled_dt * vf.z;
+		} else {
+			phiBackward = phi;
+		}
+	}
+	const float error = phiOrig - phiBackward;
+	const float phiCorr = phiForward + 0.5f * error;
+	unsigned nb[6];
+	nbr6_b(s_b4, own, n, nb);
+	float mn = phiOrig, mx = phiOrig;
+#pragma unroll
+	for (int d = 0; d < 6; ++d) {
+		const float nv = lds1(rf, nb[d]);
+		mn = fminf(mn, nv);
+		mx = fmaxf(mx, nv);
+	}
+	mn = fminf(mn, phiForward);
+	mx = fmaxf(mx, phiForward);
+	out[idx] = fmaxf(mn, fminf(phiCorr, mx));
+}
+
 template <bool COLL>
 __global__ __launch_bounds__(512) void k_advect_scalar(const GridDev g, const float* __restrict__ u, const float* __restrict__ in,
                                                        float* __restrict__ out, const float* __restrict__ sdf, const float scaled_dt) {
@@ -646,6 +691,8 @@ int hns_dev_advect_scalar(hns_grid* g, const float* vel3, const float* in, float
 	const dim3 grid((unsigned)g->n_active), block(512);
 	if (has_collision && sdf)
 		hipLaunchKernelGGL(k_advect_scalar<true>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, in, out, sdf, scaled_dt);
+	else if (narrow_fields(g))
+		hipLaunchKernelGGL(k_advect_scalar_n, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, in, out, scaled_dt);
 	else
 		hipLaunchKernelGGL(k_advect_scalar<false>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, in, out, sdf, scaled_dt);
 	return launch_status("hns_dev_advect_scalar");
