@@ -51,87 +51,11 @@ struct f3 {
 	float x, y, z;
 };
 
-__device__ __forceinline__ f3 ld0v(const float* __restrict__ ux, const float* __restrict__ uy, const float* __restrict__ uz, int idx) {
-	f3 r;
-	r.x = idx < 0 ? 0.0f : ux[idx];
-	r.y = idx < 0 ? 0.0f : uy[idx];
-	r.z = idx < 0 ? 0.0f : uz[idx];
-	return r;
-}
-
-// The eight corner indices of the trilinear stencil at base (i,j,k): order v[di][dj][dk] -> t[di*4+dj*2+dk]
-__device__ __forceinline__ void tap8(const GridDev& g, const int* s_nbr, const int4 org, int i, int j, int k, int (&t)[8]) {
-	// Fast path: all eight corners in one leaf (true for (7/8)^3 of positions) -> one leaf lookup.
-	if ((i & 7) != 7 && (j & 7) != 7 && (k & 7) != 7) {
-		const int b = tap_index(g, s_nbr, org, i, j, k);
-		t[0] = b;
-		t[1] = b < 0 ? -1 : b + 1;
-		t[2] = b < 0 ? -1 : b + 8;
-		t[3] = b < 0 ? -1 : b + 9;
-		t[4] = b < 0 ? -1 : b + 64;
-		t[5] = b < 0 ? -1 : b + 65;
-		t[6] = b < 0 ? -1 : b + 72;
-		t[7] = b < 0 ? -1 : b + 73;
-	} else {
-		t[0] = tap_index(g, s_nbr, org, i, j, k);
-		t[1] = tap_index(g, s_nbr, org, i, j, k + 1);
-		t[2] = tap_index(g, s_nbr, org, i, j + 1, k);
-		t[3] = tap_index(g, s_nbr, org, i, j + 1, k + 1);
-		t[4] = tap_index(g, s_nbr, org, i + 1, j, k);
-		t[5] = tap_index(g, s_nbr, org, i + 1, j, k + 1);
-		t[6] = tap_index(g, s_nbr, org, i + 1, j + 1, k);
-		t[7] = tap_index(g, s_nbr, org, i + 1, j + 1, k + 1);
-	}
-}
-
 // float lerp of TrilinearSampler (Stencils.hpp:140): a + w*(b-a), unfused
 __device__ __forceinline__ float lerp_f(float a, float b, float w) { return a + w * (b - a); }
 // Vec3f lerp on the device branch (Stencils.hpp:131-135): fmaf(w, b-a, a)
 __device__ __forceinline__ float lerp_c(float a, float b, float w) { return __fmaf_rn(w, b - a, a); }
 
-// IndexSampler<float,1>(Vec3f) (Stencils.hpp:117-153): Floor, 8 taps, lerp z then y then x
-__device__ __forceinline__ float tri_f(const GridDev& g, const int* s_nbr, const int4 org, const float* __restrict__ f, float x, float y,
-                                       float z) {
-	const int i = __float2int_rd(x), j = __float2int_rd(y), k = __float2int_rd(z);
-	x -= (float)i;
-	y -= (float)j;
-	z -= (float)k;
-	int t[8];
-	tap8(g, s_nbr, org, i, j, k, t);
-	const float z0 = lerp_f(ld0(f, t[0]), ld0(f, t[1]), z);
-	const float z1 = lerp_f(ld0(f, t[2]), ld0(f, t[3]), z);
-	const float z2 = lerp_f(ld0(f, t[4]), ld0(f, t[5]), z);
-	const float z3 = lerp_f(ld0(f, t[6]), ld0(f, t[7]), z);
-	const float y0 = lerp_f(z0, z1, y);
-	const float y1 = lerp_f(z2, z3, y);
-	return lerp_f(y0, y1, x);
-}
-
-__device__ __forceinline__ float tri_c(const float* __restrict__ f, const int (&t)[8], float x, float y, float z) {
-	const float z0 = lerp_c(ld0(f, t[0]), ld0(f, t[1]), z);
-	const float z1 = lerp_c(ld0(f, t[2]), ld0(f, t[3]), z);
-	const float z2 = lerp_c(ld0(f, t[4]), ld0(f, t[5]), z);
-	const float z3 = lerp_c(ld0(f, t[6]), ld0(f, t[7]), z);
-	const float y0 = lerp_c(z0, z1, y);
-	const float y1 = lerp_c(z2, z3, y);
-	return lerp_c(y0, y1, x);
-}
-
-// IndexSampler<Vec3f,1>(Vec3f): one index set shared by the three planar components
-__device__ __forceinline__ f3 tri_v(const GridDev& g, const int* s_nbr, const int4 org, const float* __restrict__ ux,
-                                    const float* __restrict__ uy, const float* __restrict__ uz, float x, float y, float z) {
-	const int i = __float2int_rd(x), j = __float2int_rd(y), k = __float2int_rd(z);
-	x -= (float)i;
-	y -= (float)j;
-	z -= (float)k;
-	int t[8];
-	tap8(g, s_nbr, org, i, j, k, t);
-	f3 r;
-	r.x = tri_c(ux, t, x, y, z);
-	r.y = tri_c(uy, t, x, y, z);
-	r.z = tri_c(uz, t, x, y, z);
-	return r;
-}
 
 // Stage the workgroup's leaf id, origin and 27-neighbour table. Returns false for an out-of-range block.
 struct LeafCtx {
