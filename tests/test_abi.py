@@ -203,6 +203,25 @@ def test_cpp_host_mirror_builds_and_behaves(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_host_code_under_address_and_ub_sanitizers(tmp_path):
+    """hns_topology.cpp + hns_nanovdb.cpp (all of libhns that runs on the host without a device) compiled with
+    -fsanitize=address,undefined and driven through int32-edge origins, threaded validation, malformed inputs and
+    exact-size export buffers (tests/cpp/host_sanitize.cpp). GPU sanitizers are not available on the target pool."""
+    rocm_inc = "/opt/rocm/include"
+    if not os.path.exists(os.path.join(rocm_inc, "hip", "hip_runtime.h")):
+        pytest.skip("HIP headers not found")
+    exe = str(tmp_path / "host_sanitize")
+    csrc = os.path.join(ROOT, "hnanosolver_amd", "csrc")
+    cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+           "-D__HIP_PLATFORM_AMD__", "-I" + rocm_inc, "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+           os.path.join(ROOT, "tests", "cpp", "host_sanitize.cpp"), os.path.join(csrc, "hns_topology.cpp"), os.path.join(csrc, "hns_nanovdb.cpp"),
+           "-pthread", "-o", exe]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, env={**os.environ, "ASAN_OPTIONS": "detect_leaks=1"})
+    assert r.returncode == 0 and "host_sanitize OK" in r.stdout, r.stdout + r.stderr[-3000:]
+
+
 @pytest.mark.gpu
 def test_cpp_host_mirror_matches_python_path_on_gpu(tmp_path):
     exe = _build_host_mirror(tmp_path)
