@@ -67,3 +67,55 @@ def test_variant_is_bit_identical(name, default_outputs, tmp_path):
     assert got.keys() == default_outputs.keys()
     for k in default_outputs:
         assert np.array_equal(got[k], default_outputs[k]), (name, k)
+
+
+BIG_CHILD = r"""
+import sys, json, numpy as np, torch
+sys.path.insert(0, sys.argv[2])
+from hnanosolver_amd import api, device as D, fields
+R = 576                                   # 72^3 leaves, 191 M voxels: a Vec3f field of 2.29 GB, byte offsets beyond 2^31
+origins = fields.dense_leaves(R)
+grid = api.create_grid_from_leaves(origins, 1.0 / R)
+N = len(origins) * 512
+o = torch.from_numpy(origins).cuda()
+n = torch.arange(512, device="cuda", dtype=torch.int32)
+loc = torch.stack([n >> 6, (n >> 3) & 7, n & 7], -1)
+q = ((o[:, None, :] + loc[None, :, :]).reshape(-1, 3).to(torch.float32) + 0.5) / R
+two_pi = 6.283185307179586
+u = torch.stack([0.5 * torch.sin(two_pi * q[:, 1]) * torch.cos(two_pi * q[:, 2]), 0.25 * torch.sin(two_pi * q[:, 0]) + torch.exp(-((q - 0.5) ** 2).sum(1) / 0.02),
+                 0.5 * torch.cos(two_pi * q[:, 0]) * torch.sin(two_pi * q[:, 1])], -1).contiguous() * (96.0 / R)
+phi = [torch.sin(7.0 * q[:, 0] + 3.0 * q[:, 2]).contiguous(), (q[:, 1] * q[:, 2]).contiguous()]
+del q
+w = (torch.arange(N, device="cuda", dtype=torch.int64) % 65521) + 1
+def digest(t):
+    b = t.contiguous().view(torch.int32).to(torch.int64).reshape(N, -1)
+    return [int(b.sum()), int((b * w[:, None]).sum())]
+out = {}
+adv = torch.empty_like(u)
+D.advect_vector(grid, u, adv, 1.0 / 24.0, float(R))
+out["advect_vector"] = digest(adv)
+dst = [torch.empty_like(phi[0]), torch.empty_like(phi[1])]
+D.advect_scalars(grid, u, phi, dst, 1.0 / 24.0, float(R))
+out["advect_scalars"] = digest(dst[0]) + digest(dst[1])
+D.advect_scalar(grid, u, phi[0], dst[1], 1.0 / 24.0, float(R))
+out["advect_scalar"] = digest(dst[1])
+tail = slice(N - 4096, N)                 # and the raw values of the last leaves, where the offsets are largest
+out["tail"] = [adv[tail].cpu().numpy().tobytes().hex()[:512], dst[0][tail].cpu().numpy().tobytes().hex()[:512]]
+json.dump(out, open(sys.argv[1], "w"))
+"""
+
+
+def test_byte_offsets_beyond_2_gib_match_the_64_bit_kernels(tmp_path):
+    """The 32-bit addressed advection kernels on a field larger than 2 GiB (offsets with the top bit set) against the
+    64-bit addressed ones on the same inputs: position-weighted checksums of the raw bits of every output."""
+    import json
+
+    res = []
+    for name, extra in (("narrow", {}), ("generic", {"HNS_ADVECT": "generic"})):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("HNS_")}
+        env.update(extra)
+        path = str(tmp_path / f"{name}.json")
+        r = subprocess.run([sys.executable, "-c", BIG_CHILD, path, ROOT], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.load(open(path)))
+    assert res[0] == res[1]
