@@ -828,17 +828,21 @@ int hns_dev_rbgs_color(hns_grid* g, const float* div, float* p, float dx, float 
 }
 
 // which form sweeps this grid: the pair kernel, unless a debug mode or the shape of the grid says otherwise
+// Grids of a few hundred leaves cannot fill 256 CUs with one wave per leaf or per pair; the 256-thread-per-leaf form puts
+// four waves on each leaf and wins there (64^3 = 512 leaves: 3.7 vs 4.1 us per sweep; at 128^3 it loses, 8.4 vs 8.0).
+static bool uses_block_form(const hns_grid* g, int mode) { return mode == 1 || (mode == 0 && g->n_active <= 1024); }
+
 static bool uses_pair_form(const hns_grid* g, int mode) {
 	// one leaf per wave is also the better choice for SMALL IRREGULAR grids, which are latency-bound (twice as many, shorter
 	// waves; no half-empty pair waves). Measured on the 3.9k-leaf plume: 9.0 vs 11.9 us per iteration.
-	return !(mode == 1 || mode == 2 || !g->d_pairs || (mode == 0 && g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs));
+	return !(uses_block_form(g, mode) || mode == 2 || !g->d_pairs || (mode == 0 && g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs));
 }
 
 // one full (red, black) iteration src -> dst. src_is_zero (pair form only): the caller vouches that src is 0 on every
 // leaf (first iteration of a solve) and the kernel skips reading it.
 static void launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* div, const float* src, float* dst, float dx2, float omega, int mode,
                                   hipStream_t st, bool src_is_zero = false) {
-	if (mode == 1) {
+	if (uses_block_form(g, mode)) {
 		hipLaunchKernelGGL(k_rbgs_fused, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, src, dst, dx2, omega);
 	} else if (!uses_pair_form(g, mode)) {
 		hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_active), dim3(64), 0, st, gd, div, src, dst, dx2, omega);
@@ -870,7 +874,8 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 	}
 	const float dx2 = dx * dx;  // Kernel.cu:608
 	const GridDev gd = g->dev();
-	static const int mode_env = !getenv("HNS_RBGS") ? 0 : (strcmp(getenv("HNS_RBGS"), "block") == 0 ? 1 : (strcmp(getenv("HNS_RBGS"), "wave") == 0 ? 2 : 0));
+	static const int mode_env = !getenv("HNS_RBGS") ? 0
+	                            : (strcmp(getenv("HNS_RBGS"), "block") == 0 ? 1 : (strcmp(getenv("HNS_RBGS"), "wave") == 0 ? 2 : (strcmp(getenv("HNS_RBGS"), "pair") == 0 ? 3 : 0)));
 	if (from_zero && !uses_pair_form(g, mode_env)) {  // the other forms read their input: give them the zeros
 		HNS_HIP(hipMemsetAsync(p_a, 0, sizeof(float) * 512 * (size_t)g->topo.n_leaves, (hipStream_t)stream));
 		from_zero = false;

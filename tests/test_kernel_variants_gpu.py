@@ -40,6 +40,7 @@ np.savez(sys.argv[1], **out)
 VARIANTS = {
     "advect_64bit": {"HNS_ADVECT": "generic"},
     "sor_wave_per_leaf": {"HNS_RBGS": "wave"},
+    "sor_wave_per_leaf_pair": {"HNS_RBGS": "pair"},  # the production form at scale; small grids default to the block form
     "sor_block_per_leaf": {"HNS_RBGS": "block"},
     "sor_graph_replay": {"HNS_GRAPH": "1"},
     "schedule_linear": {"HNS_SCHEDULE": "linear"},
