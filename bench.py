@@ -100,7 +100,7 @@ def cpu_baseline(origins, R, iterations, budget_s=25.0):
     from hnanosolver_amd import fields
     from oracle_lib import OracleGrid, oracle
 
-    L = oracle()
+    L = oracle()  # sets the OpenMP thread count to the CPUs this process may use (affinity and cgroup quota)
     cores = int(L.orc_get_threads())
     G = OracleGrid(origins)
     f = fields.synthetic_fields(origins, R)
