@@ -24,6 +24,10 @@
  * synchronous: it returns after the stream has drained, like the reference's cudaStreamSynchronize at the end of
  * each driver (HNanoSolver.cu:371, PressureProjection.cu:72, Advection.cu:99-103,158).
  *
+ * Threading: like the reference's entry points there is no global state; hns_last_error() is thread-local. One grid may
+ * be used by several host threads at once (Houdini cooks verbs concurrently): each operator call works on its own
+ * device buffers -- the set kept with the grid if it is free, a private one otherwise.
+ *
  * There is no CPU fallback: without a usable HIP device every compute entry point fails with HNS_ERR_NO_DEVICE.
  */
 #ifndef HNS_H
