@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from hnanosolver_amd import api, device as D, fields
 
-R = 256
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 base = fields.dense_leaves(R)
 vs = 1.0 / R
 
@@ -19,7 +19,7 @@ def morton2(a, b):
 
 def order(kind):
     o = base.astype(np.int64)
-    node = ((o[:, 0] >> 7) << 2) | ((o[:, 1] >> 7) << 1) | (o[:, 2] >> 7)
+    node = ((o[:, 0] >> 7) << 8) | ((o[:, 1] >> 7) << 4) | (o[:, 2] >> 7)
     lx, ly, lz = (o[:, 0] & 127) >> 3, (o[:, 1] & 127) >> 3, (o[:, 2] & 127) >> 3
     if kind == "nanovdb":
         key = (lx << 8) | (ly << 4) | lz
@@ -42,6 +42,6 @@ for kind in ("nanovdb", "tile4", "tile4x4", "morton"):
     div = torch.empty(N, dtype=torch.float32, device="cuda")
     D.divergence(grid, adv, div, float(R))
     p_a = torch.zeros(N, dtype=torch.float32, device="cuda"); p_b = torch.zeros_like(p_a)
-    ms = min(D.time_rbgs(grid, div, p_a, p_b, vs, 1.9758, 50, 4) for _ in range(2))
+    ms = min(D.time_rbgs(grid, div, p_a, p_b, vs, 1.9758, 20, 3) for _ in range(2))
     print(f"{kind:8s}: {1e3 * ms:.2f} us per sweep")
     del grid

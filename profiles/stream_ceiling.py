@@ -3,16 +3,19 @@
 (read 8 B/voxel, write 4 B/voxel = the 12 algorithmic B/voxel of one RB-SOR iteration), timed like the kernel itself.
 Not product code: a calibration point for DESIGN.md section 7."""
 import json
+import sys
+
 import torch
 
-n = 256 ** 3
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 256  # 256: the working set (201 MB) fits the Infinity Cache; 512: it does not
+n = R ** 3
 p = torch.rand(n, device="cuda")
 d = torch.rand(n, device="cuda")
 q = torch.empty(n, device="cuda")
 for _ in range(5):
     torch.add(p, d, out=q)
 torch.cuda.synchronize()
-res = {}
+res = {"R": R}
 for reps in (50, 200):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
