@@ -45,6 +45,7 @@ SIGNATURES = {
     "hns_last_error": (C.c_char_p, []),
     "hns_version": (_i, []),
     "hns_device_count": (_i, []),
+    "hns_trim_memory": (_i, []),
     "hns_grid_create": (_vp, [_vp, _u64, _f, C.c_uint, _ip]),
     "hns_grid_create_from_leaves": (_vp, [_vp, _u64, _f, C.c_uint, _ip]),
     "hns_grid_destroy": (None, [_vp]),

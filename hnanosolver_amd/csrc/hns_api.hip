@@ -75,6 +75,9 @@ struct hns_sim {
 	hipStream_t xfer = nullptr;  // transfer stream + hand-off events of the pipelined operator path (compute_sim_pipelined)
 	hipEvent_t xev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 	bool cached = false, in_use = false;  // owned by the grid's cook cache / currently lent to an operator call
+	void* arena = nullptr;  // every field above is a slice of this one allocation (see the arena pool below)
+	size_t arena_bytes = 0;
+	int device = -1;
 	int find(const char* name) const {
 		for (size_t i = 0; i < names.size(); ++i)
 			if (names[i] == name) return (int)i;
@@ -82,26 +85,88 @@ struct hns_sim {
 	}
 };
 
-static int sim_alloc(float** p, uint64_t n) {
-	HNS_HIP(hipMalloc((void**)p, sizeof(float) * (size_t)(n ? n : 1)));
-	HNS_HIP(hipMemset(*p, 0, sizeof(float) * (size_t)(n ? n : 1)));
+// ---- arena pool ------------------------------------------------------------------------------------------------
+// A sim's fields are slices of ONE device allocation, and allocations that are no longer needed go to a small
+// process-wide pool instead of back to the driver. The reference pays cudaMallocAsync x 15+ and the matching frees every
+// cook (HNanoSolver.cu:87-133,361-369); with separate hipMallocs here a cold cook at 256^3 spent 4.2 ms in hipFree
+// alone. A sparse simulation changes its topology nearly every frame, so "cold" is its normal cook: with the pool the
+// new grid's fields land in the previous grid's memory whenever that is large enough. hns_trim_memory() empties it.
+namespace {
+struct Arena {
+	void* p;
+	size_t bytes;
+	int device;
+};
+std::mutex g_pool_mutex;
+std::vector<Arena> g_pool;  // at most kPoolMax idle arenas
+constexpr size_t kPoolMax = 3;
+
+int arena_get(size_t need, int device, Arena& out) {
+	{
+		std::lock_guard<std::mutex> lock(g_pool_mutex);
+		int best = -1;
+		for (size_t i = 0; i < g_pool.size(); ++i)
+			if (g_pool[i].device == device && g_pool[i].bytes >= need && g_pool[i].bytes <= 2 * need + (64u << 20) &&
+			    (best < 0 || g_pool[i].bytes < g_pool[(size_t)best].bytes))
+				best = (int)i;
+		if (best >= 0) {
+			out = g_pool[(size_t)best];
+			g_pool.erase(g_pool.begin() + best);
+			return HNS_OK;
+		}
+	}
+	out.bytes = need + need / 8;  // headroom: the next, slightly larger topology still fits
+	out.device = device;
+	if (hipMalloc(&out.p, out.bytes) != hipSuccess) {
+		(void)hipGetLastError();
+		std::vector<Arena> drop;  // out of memory with idle arenas around: release them and retry at the exact size
+		{
+			std::lock_guard<std::mutex> lock(g_pool_mutex);
+			drop.swap(g_pool);
+		}
+		for (Arena& a : drop) (void)hipFree(a.p);
+		out.bytes = need;
+		HNS_HIP(hipMalloc(&out.p, out.bytes));
+	}
+	return HNS_OK;
+}
+
+void arena_put(const Arena& a) {
+	if (!a.p) return;
+	Arena evict{nullptr, 0, -1};
+	{
+		std::lock_guard<std::mutex> lock(g_pool_mutex);
+		g_pool.push_back(a);
+		if (g_pool.size() > kPoolMax) {  // drop the smallest
+			size_t k = 0;
+			for (size_t i = 1; i < g_pool.size(); ++i)
+				if (g_pool[i].bytes < g_pool[k].bytes) k = i;
+			evict = g_pool[k];
+			g_pool.erase(g_pool.begin() + (long)k);
+		}
+	}
+	if (evict.p) (void)hipFree(evict.p);
+}
+}  // namespace
+
+// Returns the idle pooled device memory to the driver.
+extern "C" int hns_trim_memory(void) {
+	std::vector<Arena> drop;
+	{
+		std::lock_guard<std::mutex> lock(g_pool_mutex);
+		drop.swap(g_pool);
+	}
+	for (Arena& a : drop) HNS_HIP(hipFree(a.p));
 	return HNS_OK;
 }
 
 extern "C" void hns_sim_destroy(hns_sim* s) {
 	if (!s) return;
-	for (float* p : s->cur) hipFree(p);
-	for (float* p : s->nxt) hipFree(p);
-	hipFree(s->vel);
-	hipFree(s->adv);
-	hipFree(s->tmp);
-	hipFree(s->div);
-	hipFree(s->p_a);
-	hipFree(s->p_b);
 	for (hipEvent_t e : s->ev) hipEventDestroy(e);
 	for (hipEvent_t e : s->xev)
 		if (e) hipEventDestroy(e);
 	if (s->xfer) hipStreamDestroy(s->xfer);
+	arena_put(Arena{s->arena, s->arena_bytes, s->device});
 	delete s;
 }
 
@@ -127,6 +192,54 @@ extern "C" int hns_grid_release_cache(hns_grid* g) {
 	return HNS_OK;
 }
 
+// zero: clear the arena (what hns_sim_create promises); the operator path skips it when every buffer is written before it is read
+static hns_sim* sim_create(hns_grid* g, const char* const* float_names, int n_float, bool zero, void* stream, int* rc_out) {
+	hns_sim* s = new hns_sim;
+	s->grid = g;
+	s->n = hns_grid_voxel_count(g);
+	s->device = g->device;
+	int rc = HNS_OK;
+	for (int i = 0; i < n_float && rc == HNS_OK; ++i) {
+		if (!float_names[i]) {
+			rc = fail(HNS_ERR_INVALID_ARGUMENT, "hns_sim_create: null field name");
+		} else if (s->find(float_names[i]) >= 0) {
+			set_error("hns_sim_create: duplicate field name '%s'", float_names[i]);
+			rc = HNS_ERR_INVALID_ARGUMENT;
+		} else {
+			s->names.push_back(float_names[i]);
+		}
+	}
+	if (rc == HNS_OK) {
+		const size_t unit = (sizeof(float) * (size_t)(s->n ? s->n : 1) + 255) & ~(size_t)255;  // one float field, 256-byte aligned
+		const size_t units = 3 * 3 + 3 + 2 * s->names.size();                                   // vel, adv, tmp | div, p_a, p_b | cur, nxt per field
+		Arena a{nullptr, 0, -1};
+		rc = arena_get(unit * units, s->device, a);
+		if (rc == HNS_OK) {
+			s->arena = a.p, s->arena_bytes = a.bytes;
+			char* q = (char*)a.p;
+			auto take = [&](size_t k) {
+				float* r = (float*)q;
+				q += k * unit;
+				return r;
+			};
+			s->vel = take(3), s->adv = take(3), s->tmp = take(3);
+			s->div = take(1), s->p_a = take(1), s->p_b = take(1);
+			for (size_t i = 0; i < s->names.size(); ++i) {
+				s->cur.push_back(take(1));
+				s->nxt.push_back(take(1));
+			}
+			s->p_result = s->p_a;
+			if (zero && hipMemsetAsync(a.p, 0, unit * units, (hipStream_t)stream) != hipSuccess) rc = fail(HNS_ERR_HIP, "hns_sim_create: clearing the field memory failed");
+		}
+	}
+	if (rc != HNS_OK) {
+		hns_sim_destroy(s);
+		s = nullptr;
+	}
+	*rc_out = rc;
+	return s;
+}
+
 extern "C" hns_sim* hns_sim_create(hns_grid* g, const char* const* float_names, int n_float, int* err) {
 	int rc = HNS_OK;
 	if (!g || n_float < 0 || (n_float > 0 && !float_names)) {
@@ -138,36 +251,7 @@ extern "C" hns_sim* hns_sim_create(hns_grid* g, const char* const* float_names, 
 		if (err) *err = rc;
 		return nullptr;
 	}
-	hns_sim* s = new hns_sim;
-	s->grid = g;
-	s->n = hns_grid_voxel_count(g);
-	auto alloc_all = [&]() -> int {
-		for (int i = 0; i < n_float; ++i) {
-			if (!float_names[i]) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_sim_create: null field name");
-			if (s->find(float_names[i]) >= 0) {
-				set_error("hns_sim_create: duplicate field name '%s'", float_names[i]);
-				return HNS_ERR_INVALID_ARGUMENT;
-			}
-			s->names.push_back(float_names[i]);
-			s->cur.push_back(nullptr);
-			s->nxt.push_back(nullptr);
-			HNS_TRY(sim_alloc(&s->cur.back(), s->n));
-			HNS_TRY(sim_alloc(&s->nxt.back(), s->n));
-		}
-		HNS_TRY(sim_alloc(&s->vel, 3 * s->n));
-		HNS_TRY(sim_alloc(&s->adv, 3 * s->n));
-		HNS_TRY(sim_alloc(&s->tmp, 3 * s->n));
-		HNS_TRY(sim_alloc(&s->div, s->n));
-		HNS_TRY(sim_alloc(&s->p_a, s->n));
-		HNS_TRY(sim_alloc(&s->p_b, s->n));
-		s->p_result = s->p_a;
-		return HNS_OK;
-	};
-	rc = alloc_all();
-	if (rc != HNS_OK) {
-		hns_sim_destroy(s);
-		s = nullptr;
-	}
+	hns_sim* s = sim_create(g, float_names, n_float, true, nullptr, &rc);
 	if (err) *err = rc;
 	return s;
 }
@@ -483,7 +567,8 @@ int make_sim(hns_grid* g, const FieldSplit& fs, SimGuard& guard, void* stream) {
 		return HNS_OK;
 	}
 	int err = HNS_OK;
-	guard.s = hns_sim_create(g, names.data(), (int)names.size(), &err);
+	// every operator writes each buffer before it reads it when all leaves are active, so the new memory is not cleared
+	guard.s = sim_create(g, names.data(), (int)names.size(), g->n_active != (uint64_t)g->topo.n_leaves, stream, &err);
 	if (err != HNS_OK || !use_cache) return err;
 	std::lock_guard<std::mutex> lock(g->host_mutex);
 	if (g->sim_cache.size() >= 2) {  // evict the oldest entry that is not lent out

@@ -52,6 +52,9 @@ extern "C" {
 const char* hns_last_error(void);
 int hns_version(void);
 int hns_device_count(void); /* 0 when no HIP device is visible; never initialises a device context */
+/* Device memory of destroyed simulation state is kept in a small process-wide pool (at most three allocations) so that the
+ * next cook, typically on a slightly different topology, does not pay hipMalloc/hipFree again; this returns it to the driver. */
+int hns_trim_memory(void);
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Index grid (topology)                                                                                         */

@@ -321,3 +321,33 @@ def test_concurrent_cooks_on_one_grid():
         for n in serial[i]:
             assert np.array_equal(serial[i][n], results[i][n]), (i, n)
     h.reset()
+
+
+def test_memory_pool_reuse_across_topologies():
+    """A sparse simulation changes topology every frame: each cook builds a new grid, and its fields land in the memory
+    the previous grid's fields occupied (process-wide arena pool). Results must not depend on what that memory held."""
+    p = api.CombustionParams(factorScale=1.0)
+    shapes = [fields.plume_leaves(8, 1.0, 0.3), fields.dense_leaves(32), fields.plume_leaves(8, 1.2, 0.28), fields.plume_leaves(8, 1.0, 0.3)]
+    first = {}
+    for round_ in range(2):
+        for k, origins in enumerate(shapes):
+            d = build_data(origins, 64, with_sdf=True, amplitude=120.0 + 10.0 * k)
+            h = api.IndexGridHandle()
+            api.CreateIndexGrid(d, h, 1.0 / 64)
+            api.Compute_Sim(d, h, 6, 1.0 / 24.0, 1.0 / 64, p, True)
+            api.ProjectNonDivergent(d, 5, 1.0 / 64, handle=h)
+            snap = snapshot(d)
+            h.reset()                      # the grid's buffers go to the pool
+            if round_ == 0:
+                first[k] = snap
+            else:
+                for n in snap:
+                    assert np.array_equal(first[k][n], snap[n]), (k, n)
+        if round_ == 0:
+            assert _trim() == 0            # second round starts from an empty pool again
+
+
+def _trim():
+    from hnanosolver_amd import _lib
+
+    return _lib.lib.hns_trim_memory()
