@@ -99,7 +99,7 @@ struct Arena {
 };
 std::mutex g_pool_mutex;
 std::vector<Arena> g_pool;  // at most kPoolMax idle arenas
-constexpr size_t kPoolMax = 3;
+constexpr size_t kPoolMax = 6;  // simulation states (GBs) and grid tables (MBs) share it; the smallest goes first
 
 int arena_get(size_t need, int device, Arena& out) {
 	{
@@ -148,6 +148,15 @@ void arena_put(const Arena& a) {
 	if (evict.p) (void)hipFree(evict.p);
 }
 }  // namespace
+
+extern "C" int hns_arena_get(size_t need, int device, void** p, size_t* bytes) {
+	Arena a{nullptr, 0, -1};
+	const int rc = arena_get(need, device, a);
+	*p = a.p;
+	*bytes = a.bytes;
+	return rc;
+}
+extern "C" void hns_arena_put(void* p, size_t bytes, int device) { arena_put(Arena{p, bytes, device}); }
 
 // Returns the idle pooled device memory to the driver.
 extern "C" int hns_trim_memory(void) {

@@ -11,6 +11,12 @@
 
 #include "hns_device.hpp"
 
+#define HNS_TRY_RC(call)           \
+	do {                            \
+		int rc__ = (call);          \
+		if (rc__ != HNS_OK) return rc__; \
+	} while (0)
+
 namespace hns {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -176,17 +182,10 @@ __global__ __launch_bounds__(256) void k_write_pairs(const int* __restrict__ nbr
 
 using namespace hns;
 
-static void free_ptr(void*& p) {
-	if (p) (void)hipFree(p);
-	p = nullptr;
-}
-
 // Launch order tables for the current n_active: d_sched, d_blk, d_pairs, n_pairs, n_singles. Called at build time and
-// whenever hns_grid_set_active_leaves changes the active prefix.
+// whenever hns_grid_set_active_leaves changes the active prefix. All of them are slices of the grid's one device
+// allocation (hns_grid_upload), sized for n_active = n_leaves, so nothing is allocated here.
 int hns_grid_upload_schedule(hns_grid* g) {
-	free_ptr(g->d_sched);
-	free_ptr(g->d_blk);
-	free_ptr(g->d_pairs);
 	g->n_pairs = g->n_singles = 0;
 	for (auto& e : g->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);  // captured launches hold the old lists
 	g->graphs.clear();
@@ -194,49 +193,27 @@ int hns_grid_upload_schedule(hns_grid* g) {
 	if (n == 0) return HNS_OK;
 	const char* mode = getenv("HNS_SCHEDULE");
 	const int linear = mode && strcmp(mode, "linear") == 0;
+	g->d_sched = linear ? nullptr : g->d_sched_mem;
 	const int* nbr27 = (const int*)g->d_nbr27;
 	const int n_blocks = (n + 255) / 256;
-	int *partner = nullptr, *block_heads = nullptr, *totals = nullptr;
-	HNS_HIP(hipMalloc(&g->d_blk, sizeof(int) * 28 * (size_t)n));
-	if (!linear) HNS_HIP(hipMalloc(&g->d_sched, sizeof(int) * (size_t)n));
-	// one scratch allocation: partner[n] | block_heads[n_blocks] | totals[2]
-	HNS_HIP(hipMalloc(&partner, sizeof(int) * ((size_t)n + n_blocks + 2)));
-	block_heads = partner + n;
-	totals = block_heads + n_blocks;
-	int rc = HNS_OK;
+	int* partner = (int*)g->d_scratch;  // partner[n] | block_heads[n_blocks] | totals[2]
+	int* block_heads = partner + n;
+	int* totals = block_heads + n_blocks;
 	int h_totals[2] = {0, 0};
-	do {
-		hipError_t e = hipMemsetAsync(totals, 0, 2 * sizeof(int), 0);
-		if (e != hipSuccess) break;
-		k_build_blk<<<(unsigned)(((int64_t)n * 28 + 255) / 256), 256, 0, 0>>>(nbr27, n, linear, (int*)g->d_sched, (int*)g->d_blk);
-		k_pair_heads<<<n_blocks, 256, 0, 0>>>(nbr27, n, linear, partner, block_heads, totals);
-		k_scan_blocks<<<1, 1024, 0, 0>>>(block_heads, n_blocks);
-		e = hipMemcpy(h_totals, totals, sizeof(h_totals), hipMemcpyDeviceToHost);  // also the sync point for the launches above
-		if (e != hipSuccess) {
-			set_error("hns_grid: schedule build failed: %s", hipGetErrorString(e));
-			rc = HNS_ERR_HIP;
-			break;
-		}
-		g->n_pairs = (uint64_t)h_totals[0];
-		g->n_singles = (uint64_t)h_totals[1];
-		e = hipMalloc(&g->d_pairs, sizeof(int) * 56 * (size_t)h_totals[0]);
-		if (e != hipSuccess) {
-			set_error("hns_grid: hipMalloc of the wave records failed: %s", hipGetErrorString(e));
-			rc = HNS_ERR_HIP;
-			break;
-		}
-		k_write_pairs<<<n_blocks, 256, 0, 0>>>(nbr27, n, linear, partner, block_heads, (int*)g->d_pairs);
-		e = hipDeviceSynchronize();
-		if (e != hipSuccess) {
-			set_error("hns_grid: schedule build failed: %s", hipGetErrorString(e));
-			rc = HNS_ERR_HIP;
-		}
-	} while (0);
-	(void)hipFree(partner);
-	return rc;
+	HNS_HIP(hipMemsetAsync(totals, 0, 2 * sizeof(int), 0));
+	k_build_blk<<<(unsigned)(((int64_t)n * 28 + 255) / 256), 256, 0, 0>>>(nbr27, n, linear, (int*)g->d_sched, (int*)g->d_blk);
+	k_pair_heads<<<n_blocks, 256, 0, 0>>>(nbr27, n, linear, partner, block_heads, totals);
+	k_scan_blocks<<<1, 1024, 0, 0>>>(block_heads, n_blocks);
+	HNS_HIP(hipMemcpy(h_totals, totals, sizeof(h_totals), hipMemcpyDeviceToHost));  // also the sync point for the launches above
+	g->n_pairs = (uint64_t)h_totals[0];
+	g->n_singles = (uint64_t)h_totals[1];
+	k_write_pairs<<<n_blocks, 256, 0, 0>>>(nbr27, n, linear, partner, block_heads, (int*)g->d_pairs);
+	HNS_HIP(hipDeviceSynchronize());
+	return HNS_OK;
 }
 
-// Device tables from the host origin list (g->topo.origins / hash_mask prepared by Topology::prepare).
+// Device tables from the host origin list (g->topo.origins / hash_mask prepared by Topology::prepare). One allocation
+// from the arena pool (hns_api.hip) holds all of them: a cook that rebuilds the grid reuses the previous grid's memory.
 int hns_grid_upload(hns_grid* g) {
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -247,11 +224,25 @@ int hns_grid_upload(hns_grid* g) {
 	Topology& t = g->topo;
 	const size_t nl = (size_t)(t.n_leaves > 0 ? t.n_leaves : 1);
 	const size_t hash_size = (size_t)t.hash_mask + 1;
-	int* status = nullptr;
-	HNS_HIP(hipMalloc(&g->d_origins, sizeof(int32_t) * 4 * nl));
-	HNS_HIP(hipMalloc(&g->d_nbr27, sizeof(int32_t) * 27 * nl));
-	HNS_HIP(hipMalloc(&g->d_hash, sizeof(int32_t) * (hash_size + 1)));  // +1: the duplicate-origin status word
-	status = (int*)g->d_hash + hash_size;
+	const size_t n_blocks = (nl + 255) / 256;
+	auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+	const size_t sz[7] = {pad(16 * nl),                        // origins (int4)
+	                      pad(4 * 27 * nl),                    // nbr27
+	                      pad(4 * (hash_size + 1)),            // hash + the duplicate-origin status word
+	                      pad(4 * nl),                         // sched
+	                      pad(4 * 28 * nl),                    // blk records
+	                      pad(4 * 56 * nl),                    // wave records: at most one wave per leaf
+	                      pad(4 * (nl + n_blocks + 2))};       // schedule-build scratch
+	size_t total = 0;
+	for (size_t s : sz) total += s;
+	HNS_TRY_RC(hns_arena_get(total, g->device, &g->d_arena, &g->arena_bytes));
+	char* q = (char*)g->d_arena;
+	void** slot[7] = {&g->d_origins, &g->d_nbr27, &g->d_hash, &g->d_sched_mem, &g->d_blk, &g->d_pairs, &g->d_scratch};
+	for (int i = 0; i < 7; ++i) {
+		*slot[i] = q;
+		q += sz[i];
+	}
+	int* status = (int*)g->d_hash + hash_size;
 	g->on_device = true;
 	HNS_HIP(hipMemsetAsync(g->d_hash, 0xFF, sizeof(int32_t) * hash_size, 0));
 	if (t.n_leaves > 0) {
@@ -297,12 +288,10 @@ void hns_grid_free_device(hns_grid* g) {
 	g->graphs.clear();
 	if (g->cap_stream) (void)hipStreamDestroy((hipStream_t)g->cap_stream);
 	g->cap_stream = nullptr;
-	free_ptr(g->d_origins);
-	free_ptr(g->d_nbr27);
-	free_ptr(g->d_hash);
-	free_ptr(g->d_sched);
-	free_ptr(g->d_blk);
-	free_ptr(g->d_pairs);
+	hns_arena_put(g->d_arena, g->arena_bytes, g->device);
+	g->d_arena = nullptr;
+	g->arena_bytes = 0;
+	g->d_origins = g->d_nbr27 = g->d_hash = g->d_sched = g->d_sched_mem = g->d_blk = g->d_pairs = g->d_scratch = nullptr;
 	g->on_device = false;
 }
 

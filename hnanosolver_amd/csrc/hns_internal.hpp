@@ -84,6 +84,10 @@ struct hns_grid {
 	void* d_sched = nullptr;
 	void* d_blk = nullptr;
 	void* d_pairs = nullptr;    // launch-ordered wave records {leaf0, nbr27, leaf1 or -1, nbr27} (56 ints): z-adjacent pairs and lone leaves
+	void* d_sched_mem = nullptr;  // storage of d_sched (d_sched itself is null under HNS_SCHEDULE=linear)
+	void* d_scratch = nullptr;    // schedule-build scratch
+	void* d_arena = nullptr;      // the one device allocation all of the above are slices of (arena pool, hns_api.hip)
+	size_t arena_bytes = 0;
 	uint64_t n_pairs = 0, n_singles = 0;  // waves to launch / how many of them carry a lone leaf
 	std::vector<hns::RbgsGraph> graphs;  // cached hipGraph replays of the pressure loop (dropped when the schedule changes)
 	void* cap_stream = nullptr;          // private capture stream
@@ -96,6 +100,10 @@ struct hns_grid {
 // implemented in hns_pressure.hip: hns_dev_rbgs_iterate with the option of starting from p = 0 without reading (or clearing) p_a
 extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int* result_in_b,
                                 void* stream, bool from_zero);
+
+// implemented in hns_api.hip: process-wide pool of device allocations (simulation state and grid tables)
+extern "C" __attribute__((visibility("hidden"))) int hns_arena_get(size_t need, int device, void** p, size_t* bytes);
+extern "C" __attribute__((visibility("hidden"))) void hns_arena_put(void* p, size_t bytes, int device);
 
 // implemented in hns_gridbuild.hip
 int hns_grid_upload(hns_grid* g);           // device build of every table from topo.origins
