@@ -639,15 +639,16 @@ static int compute_sim_pipelined(hns_sim* s, FieldSplit& fs, int iterations, flo
 	HNS_TRY(handoff(s->xev[2], xf, st));
 	HNS_TRY(step.part_b());
 	HNS_HIP(hipEventRecord(s->xev[3], st));  // s->vel is final here
-	for (hns_field* f : fs.floats)
-		if (!is_combustion(f->name) && !(step.coll && !strcmp(f->name, "collision_sdf"))) HNS_TRY(hns_sim_upload(s, f, 1, xf));
+	for (hns_field* f : fs.floats)  // "collision_sdf" went up first if this call uses it; if not, nothing reads it and it returns zeroed
+		if (!is_combustion(f->name) && strcmp(f->name, "collision_sdf") != 0) HNS_TRY(hns_sim_upload(s, f, 1, xf));
 	HNS_TRY(handoff(s->xev[4], xf, st));
 	HNS_TRY(step.part_c());
 	HNS_HIP(hipStreamWaitEvent(xf, s->xev[3], 0));
 	HNS_HIP(hipMemcpyAsync(fs.velocity->host, s->vel, sizeof(float) * 3 * (size_t)s->n, hipMemcpyDeviceToHost, xf));
 	HNS_TRY(handoff(s->xev[0], st, xf));
 	std::vector<hns_field> outs;
-	for (hns_field* f : fs.floats) outs.push_back(*f);
+	for (hns_field* f : fs.floats)
+		if (strcmp(f->name, "collision_sdf") != 0) outs.push_back(*f);  // the caller's SDF array comes back zeroed (hns_compute_sim): no bytes to fetch
 	HNS_TRY(hns_sim_download(s, outs.data(), (int)outs.size(), xf));  // synchronises xf
 	HNS_HIP(hipStreamSynchronize(st));
 	return HNS_OK;

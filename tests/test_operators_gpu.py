@@ -75,6 +75,28 @@ def test_compute_sim(gname, collision, factor_scale):
         assert not d.pValues("collision_sdf").any()
 
 
+def test_compute_sim_with_an_unused_sdf_block():
+    """A "collision_sdf" block is present but hasCollision is false: the reference ignores it, advects every other block
+    and still hands the SDF array back zeroed (HNanoSolver.cu:66-75,327,364-369)."""
+    from oracle_lib import OracleGrid
+
+    origins, R = fields.plume_leaves(8, 1.0, 0.3), 64
+    vs, dt, iters = 1.0 / R, 1.0 / 24.0, 10
+    d = build_data(origins, R, with_sdf=True)
+    want = snapshot(d)
+    params = api.CombustionParams()
+    names = d.getBlocksOfType(d.FLOAT)
+    assert OracleGrid(origins).compute_sim(want["vel"], {n: want[n] for n in names}, iters, dt, vs, params, False) == 0
+    h = api.IndexGridHandle()
+    api.CreateIndexGrid(d, h, vs)
+    for _ in range(2):  # second call: warm buffers
+        d2 = build_data(origins, R, with_sdf=True)
+        api.Compute_Sim(d2, h, iters, dt, vs, params, False)
+        for n in names + ["vel"]:
+            assert np.array_equal(d2.pValues(n), want[n]), n
+        assert not d2.pValues("collision_sdf").any()
+
+
 @pytest.mark.parametrize("iters", [1, 2, 50])
 def test_project_non_divergent(iters):
     from oracle_lib import OracleGrid
