@@ -255,6 +255,31 @@ __device__ __forceinline__ void nbr6(const int* s_base, int leaf, int n, int (&t
 // advect_vector (reference Kernel.cu:354-453): BFECC self-advection of the velocity, clamped
 // ---------------------------------------------------------------------------------------------------------------
 
+// ---- clamp neighbours through LDS ------------------------------------------------------------------------------------
+// Tile entry e: [0,512) own voxel n; 512 + 64*f + (a*8+b): face layer f (-x,+x,-y,+y,-z,+z) of the neighbouring leaf,
+// (a,b) = the two other coordinates in x,y,z order. 384 threads fetch one halo value each (0 where the leaf is absent).
+constexpr int kTile = 512 + 6 * 64;
+
+__device__ __forceinline__ unsigned halo_off(const unsigned* s_b4, int h) {  // float-field byte offset of halo entry h
+	const int f = h >> 6, a = (h >> 3) & 7, b = h & 7;
+	const int axis = f >> 1, dir = (f & 1) ? 1 : -1;
+	const int dslot = axis == 0 ? 9 : (axis == 1 ? 3 : 1);
+	const int c = dir > 0 ? 0 : 7;  // the layer of the neighbour that touches our face
+	const int local = axis == 0 ? ((c << 6) | (a << 3) | b) : (axis == 1 ? ((a << 6) | (c << 3) | b) : ((a << 6) | (b << 3) | c));
+	return s_b4[13 + dir * dslot] + ((unsigned)local << 2);
+}
+
+template <int AXIS, int DIR>
+__device__ __forceinline__ int tile_nbr(int n) {  // tile entry of the face neighbour of own voxel n
+	constexpr int shift = AXIS == 0 ? 6 : (AXIS == 1 ? 3 : 0);
+	constexpr int f = 2 * AXIS + (DIR > 0 ? 1 : 0);
+	const int c = (n >> shift) & 7;
+	const bool inside = DIR > 0 ? c != 7 : c != 0;
+	const int x = n >> 6, y = (n >> 3) & 7, z = n & 7;
+	const int ab = AXIS == 0 ? ((y << 3) | z) : (AXIS == 1 ? ((x << 3) | z) : ((x << 3) | y));
+	return inside ? n + DIR * (1 << shift) : 512 + 64 * f + ab;
+}
+
 // 32-bit addressed form (no collision field): same loads and arithmetic as the generic kernel below
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_advect_vector_n(const GridDev g, const float* __restrict__ u, float* __restrict__ out, const float scaled_dt) {
 	__shared__ int s_nbr[27];
@@ -267,7 +292,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 	const v4i ru = field_rsrc(u, (unsigned)g.n_leaves * 6144u);
 	const unsigned own = (unsigned)idx << 2;
 
+	__shared__ float s_tile[kTile * 3];
 	const f3 vo = ldv(ru, own);
+	s_tile[3 * n] = vo.x, s_tile[3 * n + 1] = vo.y, s_tile[3 * n + 2] = vo.z;
+	if (n < 384) {
+		const f3 h = ldv(ru, halo_off(s_b4, n));
+		s_tile[3 * (512 + n)] = h.x, s_tile[3 * (512 + n) + 1] = h.y, s_tile[3 * (512 + n) + 2] = h.z;
+	}
 	float sx = px - scaled_dt * vo.x, sy = py - scaled_dt * vo.y, sz = pz - scaled_dt * vo.z;  // backPos (Kernel.cu:374)
 	f3 vf = {0.0f, 0.0f, 0.0f}, vb = {0.0f, 0.0f, 0.0f};
 #pragma unroll 1
@@ -282,12 +313,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 		}
 	}
 	f3 vc = {vf.x + 0.5f * (vo.x - vb.x), vf.y + 0.5f * (vo.y - vb.y), vf.z + 0.5f * (vo.z - vb.z)};
-	unsigned nb[6];
-	nbr6_b(s_b4, own, n, nb);
+	__syncthreads();  // tile complete (the gathers above had the memory system to themselves)
+	const int e[6] = {tile_nbr<0, -1>(n), tile_nbr<0, 1>(n), tile_nbr<1, -1>(n), tile_nbr<1, 1>(n), tile_nbr<2, -1>(n), tile_nbr<2, 1>(n)};
 	f3 mn = vo, mx = vo;
 #pragma unroll
 	for (int d = 0; d < 6; ++d) {
-		const f3 nv = ldv(ru, nb[d]);
+		const f3 nv = {s_tile[3 * e[d]], s_tile[3 * e[d] + 1], s_tile[3 * e[d] + 2]};
 		mn.x = fminf(mn.x, nv.x);
 		mx.x = fmaxf(mx.x, nv.x);
 		mn.y = fminf(mn.y, nv.y);
@@ -396,7 +427,10 @@ __global__ __launch_bounds__(512) void k_advect_scalar_n(const GridDev g, const 
 	const unsigned bytes1 = (unsigned)g.n_leaves * 2048u, own = (unsigned)idx << 2;
 	const v4i ru = field_rsrc(u, bytes1 * 3u), rf = field_rsrc(in, bytes1);
 
+	__shared__ float s_tile[kTile];  // clamp neighbours through LDS (see k_advect_vector_n)
 	const float phiOrig = lds1(rf, own);
+	s_tile[n] = phiOrig;
+	if (n < 384) s_tile[512 + n] = lds1(rf, halo_off(s_b4, n));
 	const f3 vc = ldv(ru, own);
 	float sx = px - scaled_dt * vc.x, sy = py - scaled_dt * vc.y, sz = pz - scaled_dt * vc.z;
 	float phiForward = 0.0f, phiBackward = 0.0f;
@@ -414,12 +448,12 @@ __global__ __launch_bounds__(512) void k_advect_scalar_n(const GridDev g, const 
 	}
 	const float error = phiOrig - phiBackward;
 	const float phiCorr = phiForward + 0.5f * error;
-	unsigned nb[6];
-	nbr6_b(s_b4, own, n, nb);
+	__syncthreads();
+	const int e[6] = {tile_nbr<0, -1>(n), tile_nbr<0, 1>(n), tile_nbr<1, -1>(n), tile_nbr<1, 1>(n), tile_nbr<2, -1>(n), tile_nbr<2, 1>(n)};
 	float mn = phiOrig, mx = phiOrig;
 #pragma unroll
 	for (int d = 0; d < 6; ++d) {
-		const float nv = lds1(rf, nb[d]);
+		const float nv = s_tile[e[d]];
 		mn = fminf(mn, nv);
 		mx = fmaxf(mx, nv);
 	}
@@ -551,13 +585,18 @@ __global__ __launch_bounds__(512) void k_advect_scalars_n(const GridDev g, const
 #pragma unroll
 		for (int q = 0; q < 8; ++q) fo[q] = T.o[perm[q]] >= kOutside ? oob4 : T.o[perm[q]];
 	}
-	unsigned nb[6];
-	nbr6_b(s_b4, own, n, nb);
-#pragma unroll
-	for (int d = 0; d < 6; ++d) nb[d] = nb[d] >= kOutside ? oob4 : nb[d];
+	// clamp neighbours through LDS (see k_advect_vector_n): per field one own value per thread and one halo value per thread
+	// of the first six waves; two tiles alternate so that one barrier per field suffices
+	__shared__ float s_tile[2][kTile];
+	const int e[6] = {tile_nbr<0, -1>(n), tile_nbr<0, 1>(n), tile_nbr<1, -1>(n), tile_nbr<1, 1>(n), tile_nbr<2, -1>(n), tile_nbr<2, 1>(n)};
+	unsigned ho = n < 384 ? halo_off(s_b4, n) : 0u;
+	ho = ho >= kOutside ? oob4 : ho;  // out-of-domain neighbours read element g.oob here (Kernel.cu:225)
 	for (int s = 0; s < P.n; ++s) {
 		const v4i rf = field_rsrc(P.in[s], bytes1);
+		float* tile = s_tile[s & 1];
 		const float phiOrig = lds1(rf, own);
+		tile[n] = phiOrig;
+		if (n < 384) tile[512 + n] = lds1(rf, ho);
 		float vb[8], vf8[8];  // corner q and q+4 of the interpolation order differ only in z
 #pragma unroll
 		for (int q = 0; q < 4; ++q) {
@@ -572,10 +611,11 @@ __global__ __launch_bounds__(512) void k_advect_scalars_n(const GridDev g, const
 		}
 		const float error = phiOrig - phiB;
 		const float phiCorr = __fmaf_rn(0.5f, error, phiF);
+		__syncthreads();
 		float mn = phiOrig, mx = phiOrig;
 #pragma unroll
 		for (int d = 0; d < 6; ++d) {
-			const float v = lds1(rf, nb[d]);
+			const float v = tile[e[d]];
 			mn = fminf(mn, v);
 			mx = fmaxf(mx, v);
 		}
