@@ -255,29 +255,11 @@ __device__ __forceinline__ void nbr6(const int* s_base, int leaf, int n, int (&t
 // advect_vector (reference Kernel.cu:354-453): BFECC self-advection of the velocity, clamped
 // ---------------------------------------------------------------------------------------------------------------
 
-// ---- clamp neighbours through LDS ------------------------------------------------------------------------------------
-// Tile entry e: [0,512) own voxel n; 512 + 64*f + (a*8+b): face layer f (-x,+x,-y,+y,-z,+z) of the neighbouring leaf,
-// (a,b) = the two other coordinates in x,y,z order. 384 threads fetch one halo value each (0 where the leaf is absent).
-constexpr int kTile = 512 + 6 * 64;
-
-__device__ __forceinline__ unsigned halo_off(const unsigned* s_b4, int h) {  // float-field byte offset of halo entry h
-	const int f = h >> 6, a = (h >> 3) & 7, b = h & 7;
-	const int axis = f >> 1, dir = (f & 1) ? 1 : -1;
-	const int dslot = axis == 0 ? 9 : (axis == 1 ? 3 : 1);
-	const int c = dir > 0 ? 0 : 7;  // the layer of the neighbour that touches our face
-	const int local = axis == 0 ? ((c << 6) | (a << 3) | b) : (axis == 1 ? ((a << 6) | (c << 3) | b) : ((a << 6) | (b << 3) | c));
-	return s_b4[13 + dir * dslot] + ((unsigned)local << 2);
-}
-
-template <int AXIS, int DIR>
-__device__ __forceinline__ int tile_nbr(int n) {  // tile entry of the face neighbour of own voxel n
-	constexpr int shift = AXIS == 0 ? 6 : (AXIS == 1 ? 3 : 0);
-	constexpr int f = 2 * AXIS + (DIR > 0 ? 1 : 0);
-	const int c = (n >> shift) & 7;
-	const bool inside = DIR > 0 ? c != 7 : c != 0;
-	const int x = n >> 6, y = (n >> 3) & 7, z = n & 7;
-	const int ab = AXIS == 0 ? ((y << 3) | z) : (AXIS == 1 ? ((x << 3) | z) : ((x << 3) | y));
-	return inside ? n + DIR * (1 << shift) : 512 + 64 * f + ab;
+// float-field byte offset of LDS-tile halo entry h (hns_device.hpp); >= kOutside where that neighbour leaf is absent
+__device__ __forceinline__ unsigned halo_off(const unsigned* s_b4, int h) {
+	int slot, local;
+	halo_entry(h, slot, local);
+	return s_b4[slot] + ((unsigned)local << 2);
 }
 
 // 32-bit addressed form (no collision field): same loads and arithmetic as the generic kernel below

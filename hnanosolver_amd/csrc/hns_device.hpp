@@ -57,6 +57,35 @@ __device__ __forceinline__ float lerp_f(float a, float b, float w) { return a + 
 __device__ __forceinline__ float lerp_c(float a, float b, float w) { return __fmaf_rn(w, b - a, a); }
 
 
+// ---- face-neighbour values through LDS ------------------------------------------------------------------------------
+// Kernels that need the six face neighbours of every voxel of a leaf (BFECC clamps, pressure gradient) would issue six
+// wave-wide loads per thread, and on gfx950 the L1 charges a load instruction 16 cycles per wave whatever it touches. A
+// 512-thread workgroup instead stages a tile: its own 512 values plus the six 8x8 face layers of the neighbouring
+// leaves (384 values, one per thread of the first six waves), and every thread reads its neighbours from LDS, branch-free.
+// Tile entry e: [0,512) own voxel n; 512 + 64*f + (a*8+b): face layer f (-x,+x,-y,+y,-z,+z) of the neighbouring leaf,
+// (a,b) = the two other coordinates in x,y,z order.
+constexpr int kTile = 512 + 6 * 64;
+
+// halo entry h in [0,384): slot of the neighbour leaf in the 27-table and the voxel of that leaf to fetch
+__device__ __forceinline__ void halo_entry(int h, int& slot, int& local) {
+	const int f = h >> 6, a = (h >> 3) & 7, b = h & 7;
+	const int axis = f >> 1, dir = (f & 1) ? 1 : -1;
+	const int c = dir > 0 ? 0 : 7;  // the layer of the neighbour that touches our face
+	slot = 13 + dir * (axis == 0 ? 9 : (axis == 1 ? 3 : 1));
+	local = axis == 0 ? ((c << 6) | (a << 3) | b) : (axis == 1 ? ((a << 6) | (c << 3) | b) : ((a << 6) | (b << 3) | c));
+}
+
+template <int AXIS, int DIR>
+__device__ __forceinline__ int tile_nbr(int n) {  // tile entry of the face neighbour of own voxel n
+	constexpr int shift = AXIS == 0 ? 6 : (AXIS == 1 ? 3 : 0);
+	constexpr int f = 2 * AXIS + (DIR > 0 ? 1 : 0);
+	const int c = (n >> shift) & 7;
+	const bool inside = DIR > 0 ? c != 7 : c != 0;
+	const int x = n >> 6, y = (n >> 3) & 7, z = n & 7;
+	const int ab = AXIS == 0 ? ((y << 3) | z) : (AXIS == 1 ? ((x << 3) | z) : ((x << 3) | y));
+	return inside ? n + DIR * (1 << shift) : 512 + 64 * f + ab;
+}
+
 // Stage the workgroup's leaf id, origin and 27-neighbour table. Returns false for an out-of-range block.
 struct LeafCtx {
 	int leaf;

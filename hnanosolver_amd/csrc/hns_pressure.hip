@@ -975,6 +975,8 @@ int hns_dev_subtract_pressure_gradient(hns_grid* g, const float* vel3, const flo
 	if (g->n_active == 0) return HNS_OK;
 	const dim3 grid((unsigned)g->n_active), block(512);
 	// (a wave-per-leaf row form like k_divergence_row was measured for this kernel too: 118 us vs 111 us at 256^3 -- not kept)
+	// (also measured and not kept for this kernel: the six taps through an LDS tile as in the advection kernels, 125 vs 116 us --
+	// at 470 MB per launch it streams from HBM and the extra barrier costs more than the loads it saves)
 	if (has_collision && sdf)
 		hipLaunchKernelGGL(k_subtract_gradient<true>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, p, out3, sdf, inv_dx);
 	else
