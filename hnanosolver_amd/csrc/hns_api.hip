@@ -171,10 +171,10 @@ extern "C" int hns_trim_memory(void) {
 
 extern "C" void hns_sim_destroy(hns_sim* s) {
 	if (!s) return;
-	for (hipEvent_t e : s->ev) hipEventDestroy(e);
+	for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
 	for (hipEvent_t e : s->xev)
-		if (e) hipEventDestroy(e);
-	if (s->xfer) hipStreamDestroy(s->xfer);
+		if (e) (void)hipEventDestroy(e);
+	if (s->xfer) (void)hipStreamDestroy(s->xfer);
 	arena_put(Arena{s->arena, s->arena_bytes, s->device});
 	delete s;
 }

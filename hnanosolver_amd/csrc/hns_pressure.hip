@@ -962,8 +962,8 @@ int hns_dev_time_rbgs(hns_grid* g, const float* div, float* p_a, float* p_b, flo
 		HNS_HIP(hipEventElapsedTime(&ms, e0, e1));
 		total += ms;
 	}
-	hipEventDestroy(e0);
-	hipEventDestroy(e1);
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
 	*ms_per_launch = (float)(total / ((double)reps * iterations));
 	return rc;
 }
