@@ -373,3 +373,79 @@ def _trim():
     from hnanosolver_amd import _lib
 
     return _lib.lib.hns_trim_memory()
+
+
+def test_c_abi_misuse_returns_codes_not_crashes():
+    """Every entry point called the wrong way straight through ctypes: null pointers, zero / negative counts, unknown
+    component counts, unnamed fields, aliased buffers. Each must return a negative code with a message; none may fault."""
+    import ctypes as C
+
+    from hnanosolver_amd import _lib
+
+    L = _lib.lib
+    origins, R = fields.dense_leaves(16), 16
+    d = build_data(origins, R)
+    h = api.IndexGridHandle()
+    api.CreateIndexGrid(d, h, 1.0 / R)
+    flds, n, keep = d._fields()
+    p = api.CombustionParams()._c()
+    neg = []
+
+    def bad(rc):
+        assert rc < 0, "call was accepted"
+        assert L.hns_last_error(), "no message"
+        neg.append(rc)
+
+    bad(L.hns_compute_sim(None, flds, n, 5, 0.1, 1.0 / R, C.byref(p), 0, None))
+    bad(L.hns_compute_sim(h.ptr, None, n, 5, 0.1, 1.0 / R, C.byref(p), 0, None))
+    bad(L.hns_compute_sim(h.ptr, flds, 0, 5, 0.1, 1.0 / R, C.byref(p), 0, None))
+    bad(L.hns_compute_sim(h.ptr, flds, -3, 5, 0.1, 1.0 / R, C.byref(p), 0, None))
+    bad(L.hns_compute_sim(h.ptr, flds, n, 5, 0.1, 1.0 / R, None, 0, None))
+    bad(L.hns_compute_sim(h.ptr, flds, n, 5, float("nan"), -1.0, C.byref(p), 0, None))
+    for op in (L.hns_advect_index_grid, L.hns_advect_index_grid_velocity):
+        bad(op(None, flds, n, 0.1, 1.0 / R, None))
+        bad(op(h.ptr, None, n, 0.1, 1.0 / R, None))
+    bad(L.hns_project_non_divergent(h.ptr, flds, n, 1 << 40, 1.0 / R, None))
+    bad(L.hns_project_non_divergent(h.ptr, flds, n, 5, 0.0, None))
+    bad(L.hns_divergence(h.ptr, flds, n, 1.0 / R, None))  # no block named "divergence"
+    # a field with an unknown component count, one without a name, one without memory
+    saved = (flds[0].ncomp, flds[0].name, flds[1].host)
+    flds[0].ncomp = 2
+    bad(L.hns_compute_sim(h.ptr, flds, n, 5, 0.1, 1.0 / R, C.byref(p), 0, None))
+    flds[0].ncomp = saved[0]
+    flds[0].name = None
+    bad(L.hns_compute_sim(h.ptr, flds, n, 5, 0.1, 1.0 / R, C.byref(p), 0, None))
+    flds[0].name = saved[1]
+    flds[1].host = None
+    bad(L.hns_compute_sim(h.ptr, flds, n, 5, 0.1, 1.0 / R, C.byref(p), 0, None))
+    flds[1].host = saved[2]
+    # grid functions
+    err = C.c_int(0)
+    assert not L.hns_grid_create(None, 512, 1.0, 0, C.byref(err)) and err.value < 0
+    assert not L.hns_grid_create_from_leaves(None, 3, 1.0, 0, C.byref(err)) and err.value < 0
+    bad(L.hns_grid_offsets(h.ptr, None, 4, None))
+    bad(L.hns_grid_neighbor_table(h.ptr, None))
+    bad(L.hns_grid_set_active_leaves(h.ptr, 10 ** 9))
+    bad(L.hns_grid_matches(None, None, 0, 0))
+    bad(L.hns_grid_export_nanovdb(h.ptr, None, 0, None))
+    bad(L.hns_grid_launch_tables(None, None, None, None, None))
+    bad(L.hns_grid_release_cache(None))
+    # kernel-level API
+    import torch
+
+    N = len(origins) * 512
+    u, v = torch.zeros(N, 3, device="cuda"), torch.zeros(N, device="cuda")
+    up, vp = u.data_ptr(), v.data_ptr()
+    bad(L.hns_dev_advect_vector(h.ptr, up, up, None, 0, 0.1, float(R), None))      # output aliases input
+    bad(L.hns_dev_advect_vector(h.ptr, None, up, None, 0, 0.1, float(R), None))
+    bad(L.hns_dev_rbgs_iterate(h.ptr, vp, vp, vp, 1.0 / R, 1.5, 3, None, None))    # p_a == p_b
+    bad(L.hns_dev_rbgs_iterate(h.ptr, vp, vp, None, 1.0 / R, 1.5, 3, None, None))
+    bad(L.hns_dev_rbgs_iterate(h.ptr, vp, up, vp + 4, 1.0 / R, 1.5, -1, None, None))
+    bad(L.hns_dev_divergence(None, up, vp, float(R), None))
+    bad(L.hns_dev_pack_leaves(vp, None, 4, vp, 1, None))
+    bad(L.hns_dev_pack_leaves(vp, vp, 4, vp, 2, None))
+    bad(L.hns_sim_substep(None, 5, 0.1, 1.0 / R, C.byref(p), 0, None))
+    assert not L.hns_sim_create(h.ptr, None, 3, C.byref(err)) and err.value < 0
+    assert len(neg) >= 30
+    # and the handle still works afterwards
+    api.Compute_Sim(d, h, 3, 0.1, 1.0 / R, api.CombustionParams(), False)
