@@ -41,14 +41,7 @@ def cpu_budget() -> int:
     return max(1, n)
 
 
-def oracle():
-    global _ORC
-    if _ORC is not None:
-        return _ORC
-    path = os.path.join(ORACLE_DIR, "liboracle.so")
-    if not os.path.exists(path):
-        subprocess.run(["make", "-C", ORACLE_DIR, "oracle"], check=True, capture_output=True)
-    L = C.CDLL(path)
+def _bind(L):
     sig = {
         "orc_grid_create": (_vp, [_vp, _i64]),
         "orc_grid_destroy": (None, [_vp]),
@@ -86,8 +79,26 @@ def oracle():
         fn.restype = res
         fn.argtypes = args
     L.orc_set_threads(cpu_budget())
-    _ORC = L
     return L
+
+
+def oracle():
+    global _ORC
+    if _ORC is not None:
+        return _ORC
+    path = os.path.join(ORACLE_DIR, "liboracle.so")
+    if not os.path.exists(path):
+        subprocess.run(["make", "-C", ORACLE_DIR, "oracle"], check=True, capture_output=True)
+    _ORC = _bind(C.CDLL(path))
+    return _ORC
+
+
+def oracle_contracted():
+    """The same source built the way nvcc builds the reference by default: floating-point contraction on (every a*b+c may
+    fuse). Used only to measure how far a contracted build can drift from the strict one (tests/test_oracle_pins.py)."""
+    path = os.path.join(ORACLE_DIR, "liboracle_fma.so")
+    subprocess.run(["make", "-C", ORACLE_DIR, "oracle_fma"], check=True, capture_output=True)
+    return _bind(C.CDLL(path))
 
 
 def reference_samplers():
@@ -136,8 +147,8 @@ def _f32(a):
 class OracleGrid:
     """Thin numpy front-end of the oracle. Vec3f arrays are (N,3) float32 AoS."""
 
-    def __init__(self, leaf_origins):
-        self.L = oracle()
+    def __init__(self, leaf_origins, lib=None):
+        self.L = lib or oracle()
         self.origins = np.ascontiguousarray(leaf_origins, dtype=np.int32).reshape(-1, 3)
         self.g = self.L.orc_grid_create(self.origins.ctypes.data, self.origins.shape[0])
         if not self.g:
