@@ -203,6 +203,26 @@ def test_cpp_host_mirror_builds_and_behaves(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_header_is_plain_c99_and_links_from_c(tmp_path):
+    """include/hns.h is the boundary a cgo / JNI / ctypes binding would consume: it must compile as strict C99 (no C++
+    types in any signature) and a C program must link against libhns.so and call it."""
+    src = tmp_path / "c_abi.c"
+    src.write_text('#include "hns.h"\n#include <stdio.h>\nint main(void) {\n'
+                   '  int err = 0; const int32_t o[3] = {0, 0, 0};\n'
+                   '  hns_grid* g = hns_grid_create_from_leaves(o, 1, 0.5f, HNS_GRID_HOST_ONLY, &err);\n'
+                   '  if (!g || err != HNS_OK || hns_grid_voxel_count(g) != 512) return 1;\n'
+                   '  uint64_t off = 0; const int32_t q[3] = {1, 2, 3};\n'
+                   '  if (hns_grid_offsets(g, q, 1, &off) != HNS_OK || off != 1 + 64 + 16 + 3) return 2;\n'
+                   '  hns_grid_destroy(g);\n  printf("c abi ok %d\\n", hns_version());\n  return 0;\n}\n')
+    exe = str(tmp_path / "c_abi")
+    libdir = os.path.dirname(_lib.library_path())
+    b = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-L" + libdir, "-lhns",
+                        "-Wl,-rpath," + libdir, "-o", exe], capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "c abi ok 100" in r.stdout, r.stdout + r.stderr
+
+
 def test_host_code_under_address_and_ub_sanitizers(tmp_path):
     """hns_topology.cpp + hns_nanovdb.cpp (all of libhns that runs on the host without a device) compiled with
     -fsanitize=address,undefined and driven through int32-edge origins, threaded validation, malformed inputs and
