@@ -403,6 +403,7 @@ static int sim_advect_scalars(hns_sim* s, const float* sdf, bool coll, float dt,
 //   part A  needs velocity (+ collision_sdf)      collision, advect_vector, vorticity, divergence
 //   part B  needs fuel/waste/temperature/flame     combustion, buoyancy, pressure solve, gradient subtraction, collision
 //   part C  needs every advected float field       advect_scalars
+namespace {
 struct Substep {
 	hns_sim* s;
 	int iterations;
@@ -460,8 +461,27 @@ struct Substep {
 		if (coll) HNS_TRY(hns_dev_enforce_collision_boundaries(g, s->vel, sdf, voxel_size, stream));  // :292-296
 		return HNS_OK;
 	}
+	// Part B in the order the cook pipeline wants it. The pressure solve reads nothing but the divergence, and combustion's
+	// contribution to it depends on fuel and waste only: B1 (those two fields on the device) finishes the divergence and
+	// solves; B2 (temperature and flame too) does what B1 skipped. Buoyancy moves from before the solve to after it, which
+	// changes nothing: the solve does not read the velocity and nothing in between reads what buoyancy writes.
+	int part_b1() {
+		HNS_TRY(hns_combustion_div(s->cur[ci[0]], s->cur[ci[1]], s->div, params->expansionRate, s->n, stream));
+		return sim_pressure(s, iterations, voxel_size, omega_compute(voxel_size), stream);
+	}
+	int part_b2() {
+		hns_grid* g = s->grid;
+		HNS_TRY(hns_combustion_fields(s->cur[ci[0]], s->cur[ci[1]], s->cur[ci[2]], s->cur[ci[3]], s->nxt[ci[0]], s->nxt[ci[1]], s->nxt[ci[2]], s->nxt[ci[3]],
+		                              params->temperatureRelease, s->n, stream));
+		HNS_TRY(hns_dev_temperature_buoyancy(s->adv, s->nxt[ci[2]], s->adv, dt, params->ambientTemp, params->buoyancyStrength, s->n, stream));
+		for (int c = 0; c < 4; ++c) std::swap(s->cur[ci[c]], s->nxt[ci[c]]);
+		HNS_TRY(hns_dev_subtract_pressure_gradient(g, s->adv, s->p_result, s->vel, sdf, coll, inv_dx, stream));
+		if (coll) HNS_TRY(hns_dev_enforce_collision_boundaries(g, s->vel, sdf, voxel_size, stream));
+		return HNS_OK;
+	}
 	int part_c() { return sim_advect_scalars(s, sdf, coll, dt, inv_dx, stream); }  // :321-356
 };
+}  // namespace
 
 extern "C" int hns_sim_substep(hns_sim* s, int iterations, float dt, float voxel_size, const hns_combustion_params* params, int has_collision,
                                void* stream) {
@@ -600,8 +620,8 @@ int make_sim(hns_grid* g, const FieldSplit& fs, SimGuard& guard, void* stream) {
 // hns_compute_sim's data movement. The reference uploads everything, runs, downloads everything (HNanoSolver.cu:87-133,
 // 361-371). Here the fields go up in the order the substep consumes them, on a transfer stream of the sim's own, and each
 // part of the substep is enqueued on the caller's stream as soon as its inputs are queued: advect_vector + divergence
-// run under the upload of the combustion fields, the remaining fields arrive under the pressure solve, and
-// advect_scalars runs under the download of the final velocity. Same kernels, same order per buffer; only the overlap
+// run under the upload of fuel and waste, the pressure solve under the upload of every other field (Substep::part_b1),
+// and advect_scalars under the download of the final velocity. Same kernels, same order per buffer; only the overlap
 // differs. HNS_COOK_PIPELINE=0 falls back to upload-all / run / download-all.
 static int compute_sim_pipelined(hns_sim* s, FieldSplit& fs, int iterations, float dt, float voxel_size, const hns_combustion_params* params,
                                  int has_collision, void* stream) {
@@ -621,7 +641,7 @@ static int compute_sim_pipelined(hns_sim* s, FieldSplit& fs, int iterations, flo
 	}
 	hipStream_t st = (hipStream_t)stream, xf = s->xfer;
 	HNS_TRY(step.prepare(s, iterations, dt, voxel_size, params, has_collision, stream));
-	auto is_combustion = [](const char* n) { return !strcmp(n, "fuel") || !strcmp(n, "waste") || !strcmp(n, "temperature") || !strcmp(n, "flame"); };
+	auto is_fuel_or_waste = [](const char* n) { return !strcmp(n, "fuel") || !strcmp(n, "waste"); };
 	auto handoff = [&](hipEvent_t e, hipStream_t from, hipStream_t to) -> int {
 		HNS_HIP(hipEventRecord(e, from));
 		HNS_HIP(hipStreamWaitEvent(to, e, 0));
@@ -635,13 +655,14 @@ static int compute_sim_pipelined(hns_sim* s, FieldSplit& fs, int iterations, flo
 	HNS_TRY(handoff(s->xev[1], xf, st));
 	HNS_TRY(step.part_a());
 	for (hns_field* f : fs.floats)
-		if (is_combustion(f->name)) HNS_TRY(hns_sim_upload(s, f, 1, xf));
+		if (is_fuel_or_waste(f->name)) HNS_TRY(hns_sim_upload(s, f, 1, xf));
 	HNS_TRY(handoff(s->xev[2], xf, st));
-	HNS_TRY(step.part_b());
-	HNS_HIP(hipEventRecord(s->xev[3], st));  // s->vel is final here
+	HNS_TRY(step.part_b1());  // the solve runs while every remaining field is still on its way
 	for (hns_field* f : fs.floats)  // "collision_sdf" went up first if this call uses it; if not, nothing reads it and it returns zeroed
-		if (!is_combustion(f->name) && strcmp(f->name, "collision_sdf") != 0) HNS_TRY(hns_sim_upload(s, f, 1, xf));
+		if (!is_fuel_or_waste(f->name) && strcmp(f->name, "collision_sdf") != 0) HNS_TRY(hns_sim_upload(s, f, 1, xf));
 	HNS_TRY(handoff(s->xev[4], xf, st));
+	HNS_TRY(step.part_b2());
+	HNS_HIP(hipEventRecord(s->xev[3], st));  // s->vel is final here
 	HNS_TRY(step.part_c());
 	HNS_HIP(hipStreamWaitEvent(xf, s->xev[3], 0));
 	HNS_HIP(hipMemcpyAsync(fs.velocity->host, s->vel, sizeof(float) * 3 * (size_t)s->n, hipMemcpyDeviceToHost, xf));

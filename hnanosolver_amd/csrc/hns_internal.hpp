@@ -101,6 +101,13 @@ struct hns_grid {
 extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int* result_in_b,
                                 void* stream, bool from_zero);
 
+// implemented in hns_pointwise.hip: combustion_oxygen split into its divergence update (needs fuel, waste) and the rest
+extern "C" __attribute__((visibility("hidden"))) int hns_combustion_div(const float* fuel, const float* waste, float* divergence, float expansion, uint64_t n,
+                                                                        void* stream);
+extern "C" __attribute__((visibility("hidden"))) int hns_combustion_fields(const float* fuel, const float* waste, const float* temperature, const float* flame,
+                                                                           float* out_fuel, float* out_waste, float* out_temperature, float* out_flame,
+                                                                           float temp_gain, uint64_t n, void* stream);
+
 // implemented in hns_api.hip: process-wide pool of device allocations (simulation state and grid tables)
 extern "C" __attribute__((visibility("hidden"))) int hns_arena_get(size_t need, int device, void** p, size_t* bytes);
 extern "C" __attribute__((visibility("hidden"))) void hns_arena_put(void* p, size_t bytes, int device);

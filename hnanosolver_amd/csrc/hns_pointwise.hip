@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void k_combustion_oxygen(const float* __restri
                                                            const float* __restrict__ flameData, float* __restrict__ outFuel,
                                                            float* __restrict__ outWaste, float* __restrict__ outTemperature,
                                                            float* __restrict__ outFlame, const float temp_gain, const float expansion,
-                                                           const uint64_t n) {
+                                                           const uint64_t n, const int update_div) {
 	for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (uint64_t)gridDim.x * blockDim.x) {
 		float fuel = fuelData[idx];
 		const float waste = wasteData[idx];
@@ -36,8 +36,24 @@ __global__ __launch_bounds__(256) void k_combustion_oxygen(const float* __restri
 		outFuel[idx] = fuel - burn;
 		outWaste[idx] = waste + burn * 2.0f;
 		outTemperature[idx] = temperature + burn * temp_gain;
-		divergenceData[idx] += burn * expansion;
+		if (update_div) divergenceData[idx] += burn * expansion;
 		outFlame[idx] = fmaxf(flame, fminf(1.0f, burn * 10.0f));
+	}
+}
+
+// The divergence update of combustion_oxygen alone. It depends on fuel and waste only, and it is all the pressure solve
+// waits for: the cook pipeline (hns_api.hip) runs it as soon as those two fields are on the device and lets the solve
+// overlap the upload of the others; k_combustion_oxygen then runs with update_div = 0. Same expressions, same result.
+__global__ __launch_bounds__(256) void k_combustion_div(const float* __restrict__ fuelData, const float* __restrict__ wasteData,
+                                                        float* __restrict__ divergenceData, const float expansion, const uint64_t n) {
+	for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (uint64_t)gridDim.x * blockDim.x) {
+		float fuel = fuelData[idx];
+		const float waste = wasteData[idx];
+		if (fuel < 0.001f) fuel = 0.0f;
+		const float oxygen = 1.0f - fuel - waste;
+		if (oxygen < 0.0f) continue;
+		const float burn = fminf(oxygen, fuel);
+		divergenceData[idx] += burn * expansion;
 	}
 }
 
@@ -154,8 +170,22 @@ int hns_dev_combustion_oxygen(const float* fuel, const float* waste, const float
 	        "hns_dev_combustion_oxygen");
 	if (n == 0) return HNS_OK;
 	hipLaunchKernelGGL(k_combustion_oxygen, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, fuel, waste, temperature, divergence, flame,
-	                   out_fuel, out_waste, out_temperature, out_flame, temp_gain, expansion, n);
+	                   out_fuel, out_waste, out_temperature, out_flame, temp_gain, expansion, n, 1);
 	return launch_status("hns_dev_combustion_oxygen");
+}
+
+// the two halves of combustion_oxygen for the cook pipeline (see k_combustion_div)
+int hns_combustion_div(const float* fuel, const float* waste, float* divergence, float expansion, uint64_t n, void* stream) {
+	if (n == 0) return HNS_OK;
+	hipLaunchKernelGGL(k_combustion_div, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, fuel, waste, divergence, expansion, n);
+	return launch_status("hns_combustion_div");
+}
+int hns_combustion_fields(const float* fuel, const float* waste, const float* temperature, const float* flame, float* out_fuel, float* out_waste,
+                          float* out_temperature, float* out_flame, float temp_gain, uint64_t n, void* stream) {
+	if (n == 0) return HNS_OK;
+	hipLaunchKernelGGL(k_combustion_oxygen, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, fuel, waste, temperature, (float*)nullptr, flame,
+	                   out_fuel, out_waste, out_temperature, out_flame, temp_gain, 0.0f, n, 0);
+	return launch_status("hns_combustion_fields");
 }
 
 int hns_dev_temperature_buoyancy(const float* vel3, const float* temperature, float* out3, float dt, float ambient, float strength, uint64_t n,
