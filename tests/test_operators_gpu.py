@@ -449,3 +449,51 @@ def test_c_abi_misuse_returns_codes_not_crashes():
     assert len(neg) >= 30
     # and the handle still works afterwards
     api.Compute_Sim(d, h, 3, 0.1, 1.0 / R, api.CombustionParams(), False)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_sparse_domains_against_the_oracle(seed):
+    """Seeded random domains: scattered leaves around the origin (negative coordinates, lone leaves, short and long
+    z-runs, holes), random field amplitude, collision and vorticity on or off, the SOR form chosen by the library's own
+    heuristics -- whole Compute_Sim cooks must equal the oracle bit for bit."""
+    from oracle_lib import OracleGrid
+
+    rng = np.random.default_rng(1000 + seed)
+    span = int(rng.integers(2, 7))
+    lat = np.stack(np.meshgrid(*[np.arange(-span, span)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    keep = rng.random(len(lat)) < rng.uniform(0.15, 0.9)
+    keep[rng.integers(0, len(lat))] = True
+    o = (lat[keep] * 8).astype(np.int32)
+    origins = np.ascontiguousarray(o[fields.nanovdb_order(o)])
+    R = 16 * span
+    collision, fs = bool(seed & 1), (1.0 if seed & 2 else 0.5)
+    c = fields.leaves_to_coords(origins)
+    q = (c.astype(np.float64) + 0.5) / R
+    N = len(c)
+    amp = float(rng.uniform(20.0, 300.0)) / R
+    vel = (amp * np.stack([np.sin(5.0 * q[:, 1] + seed) * np.cos(3.0 * q[:, 2]), np.cos(4.0 * q[:, 0]) + 0.3 * rng.standard_normal(N),
+                           np.sin(6.0 * q[:, 0] * q[:, 1])], -1)).astype(np.float32)
+    d = api.GridIndexedData()
+    d.allocateCoords(N)
+    d.pCoords()[:] = c
+    vals = {"density": rng.random(N), "temperature": 20.0 + 60.0 * rng.random(N), "fuel": 0.3 * rng.random(N) * (rng.random(N) < 0.3),
+            "waste": 0.2 * rng.random(N), "flame": rng.random(N) * (rng.random(N) < 0.1)}
+    for n, v in vals.items():
+        d.addValueBlock(n, d.FLOAT)
+        d.pValues(n)[:] = v.astype(np.float32)
+    if collision:
+        d.addValueBlock("collision_sdf", d.FLOAT)
+        d.pValues("collision_sdf")[:] = ((np.linalg.norm(q - 0.1, axis=1) - 0.35) * R).astype(np.float32)
+    d.addValueBlock("vel", d.VEC3F)
+    d.pValues("vel")[:] = vel
+    want = snapshot(d)
+    params = api.CombustionParams(factorScale=fs, vorticityScale=0.7)
+    names = d.getBlocksOfType(d.FLOAT)
+    iters = int(rng.integers(1, 40))
+    assert OracleGrid(origins).compute_sim(want["vel"], {n: want[n] for n in names}, iters, 0.05, 1.0 / R, params, collision) == 0
+    h = api.IndexGridHandle()
+    api.CreateIndexGrid(d, h, 1.0 / R)
+    api.Compute_Sim(d, h, iters, 0.05, 1.0 / R, params, collision)
+    for n in names + ["vel"]:
+        assert np.array_equal(d.pValues(n), want[n]), f"seed {seed} ({len(origins)} leaves, {iters} iterations, collision={collision}, fs={fs}): {n} differs, rel L-inf {rel_linf(d.pValues(n), want[n]):.2e}"
+    h.reset()
