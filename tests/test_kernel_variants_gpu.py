@@ -18,7 +18,11 @@ sys.path.insert(0, sys.argv[2]); sys.path.insert(0, sys.argv[2] + "/tests")
 from hnanosolver_amd import api, fields
 from test_operators_gpu import build_data, snapshot
 out = {}
-for gname, origins, R in (("dense32", fields.dense_leaves(32), 32), ("plume", fields.plume_leaves(8, 1.0, 0.3), 64)):
+rng = np.random.default_rng(77)
+lat = np.stack(np.meshgrid(*[np.arange(-5, 5)] * 3, indexing="ij"), -1).reshape(-1, 3)
+scat = (lat[rng.random(len(lat)) < 0.45] * 8).astype(np.int32)
+scat = np.ascontiguousarray(scat[fields.nanovdb_order(scat)])   # ragged z-runs, lone leaves, negative coordinates
+for gname, origins, R in (("dense32", fields.dense_leaves(32), 32), ("plume", fields.plume_leaves(8, 1.0, 0.3), 64), ("scattered", scat, 80)):
     vs = 1.0 / R
     for coll in (False, True):
         d = build_data(origins, R, with_sdf=coll, amplitude=160.0)
