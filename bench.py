@@ -9,7 +9,8 @@ SOR iterations -> pressure-gradient subtraction -> advect_scalars (S=1), i.e. 68
 are the closed-form synthetic fields of hnanosolver_amd.fields, already resident in HBM when the timed region starts.
 
 N = 1: the workload is BASELINE.json's roofline configuration, the 256^3 dense-active grid (16,777,216 voxels).
-N > 1: weak scaling -- every rank owns one such x-slab of a (256*N) x 256 x 256 domain; ranks exchange the halo
+N > 1: weak scaling -- every rank owns one such x-slab of a (256*N) x 256 x 256 domain (--partition: ONE --config domain,
+e.g. plume1024 = BASELINE.json's 1024^3-extent sparse grid, split across the ranks instead); ranks exchange the halo
 leaves of u / p / phi over RCCL each time the reference would have a global kernel boundary that the stencil crosses
 (hnanosolver_amd/dist.py). `value` = slab-substeps/s summed over ranks = N x (global substeps/s).
 
@@ -45,6 +46,7 @@ def parse():
     ap.add_argument("--config", default="256", help="256 (default, roofline config) | 128 | 64 | plume")
     ap.add_argument("--iterations", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--partition", action="store_true", help="N > 1: split ONE --config domain across the ranks (strong scaling) instead of one slab per rank")
     ap.add_argument("--cook", action="store_true", help="time the cook-equivalent hns_compute_sim call (upload + grid build + substep + download) instead")
     return ap.parse_args()
 
@@ -178,7 +180,9 @@ def main():
     else:
         from hnanosolver_amd import dist as HD
 
-        runner = HD.SlabBench(origins, R, rank, world, args.iterations, dt)
+        runner = HD.SlabBench(origins, R, rank, world, args.iterations, dt, partition=args.partition)
+        if args.partition:
+            n_vox_rank = runner.plan.n_owned * 512
         step, timing_on, pressure_time = runner.step, runner.timing_on, runner.pressure_time
 
     for _ in range(args.warmup):
@@ -204,7 +208,7 @@ def main():
     p_ms, launches = pressure_time()
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * args.steps / elapsed  # slab-substeps/s over all ranks
+        value = (1 if args.partition and world > 1 else world) * args.steps / elapsed  # slab-substeps/s over all ranks (partitioned: substeps/s of the one domain)
         ms_launch = p_ms / max(1, launches)
         achieved = BYTES_PER_VOXEL_ITER * n_vox_rank / (ms_launch * 1e-3) / 1e9 if launches else None
         traffic = None
@@ -225,7 +229,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (args.partition and world > 1) else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -236,7 +240,8 @@ def main():
                 "pressure_iterations": args.iterations,
                 "substep": "advect_vector + divergence + RB-SOR + gradient subtraction + advect_scalars(S=1)",
                 "algorithmic_bytes_per_voxel_substep": BYTES_PER_VOXEL_SUBSTEP - 600 + 12 * args.iterations,
-                "parallelism": "single GPU" if world == 1 else f"x-slab leaf partition over {world} GPUs, RCCL halo exchange",
+                "parallelism": "single GPU" if world == 1 else (f"one domain in {world} contiguous leaf ranges, RCCL halo exchange" if args.partition
+                                                                else f"x-slab leaf partition over {world} GPUs, RCCL halo exchange"),
             },
             "roofline": {
                 "kernel": "k_rbgs_pair (one launch = one full red+black SOR iteration over all leaves)",

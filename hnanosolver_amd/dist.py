@@ -384,29 +384,35 @@ class SlabBench:
     """Rank r owns the slab `origins + (r*R, 0, 0)` of a (world*R) x R x R domain; fields are the closed-form synthetic
     inputs evaluated on the global domain. Used by bench.py for --gpus N > 1."""
 
-    def __init__(self, slab_origins: np.ndarray, R: int, rank: int, world: int, iterations: int, dt: float):
+    def __init__(self, slab_origins: np.ndarray, R: int, rank: int, world: int, iterations: int, dt: float, partition: bool = False):
         import torch
 
         from . import fields
 
         self.torch = torch
         slab_origins = np.asarray(slab_origins, dtype=np.int32)
-        glob = np.concatenate([slab_origins + np.array([r * R, 0, 0], dtype=np.int32) for r in range(world)])
-        n_slab = len(slab_origins)
-        # only the leaves near this rank's slab matter for its plan: restrict the neighbour search to slabs r-1..r+1
-        lo, hi = max(0, rank - 1), min(world, rank + 2)
-        sub = glob[lo * n_slab:hi * n_slab]
-        nbr_sub = neighbor_ids(sub)
-        nbr = np.full((len(glob), 27), -1, dtype=np.int64)
-        nbr[lo * n_slab:hi * n_slab] = np.where(nbr_sub >= 0, nbr_sub + lo * n_slab, -1)
-        self.plan = make_plan_slabs(glob, n_slab, world, rank, nbr)
+        if partition:
+            # strong scaling: ONE domain (e.g. the 1024^3-extent plume of BASELINE.json configs[4]) split into `world`
+            # contiguous leaf ranges of its NanoVDB order
+            self.plan = make_plan(slab_origins, world, rank)
+            eval_origins = self.plan.local_origins
+        else:
+            glob = np.concatenate([slab_origins + np.array([r * R, 0, 0], dtype=np.int32) for r in range(world)])
+            n_slab = len(slab_origins)
+            # only the leaves near this rank's slab matter for its plan: restrict the neighbour search to slabs r-1..r+1
+            lo, hi = max(0, rank - 1), min(world, rank + 2)
+            sub = glob[lo * n_slab:hi * n_slab]
+            nbr_sub = neighbor_ids(sub)
+            nbr = np.full((len(glob), 27), -1, dtype=np.int64)
+            nbr[lo * n_slab:hi * n_slab] = np.where(nbr_sub >= 0, nbr_sub + lo * n_slab, -1)
+            self.plan = make_plan_slabs(glob, n_slab, world, rank, nbr)
+            eval_origins = self.plan.local_origins.copy()
+            eval_origins[:, 0] %= R  # evaluate the closed-form fields periodically in x: every slab carries the same plume
         self.iterations, self.dt = iterations, dt
         self.vs = 1.0 / R  # same voxel size (and omega) as the single-GPU workload
         self.engine = HipEngine(self.plan.local_origins, self.plan.n_owned, self.vs)
         self.solver = DistributedSolver(self.plan, self.engine, self.vs, n_scalars=1)
-        wrapped = self.plan.local_origins.copy()
-        wrapped[:, 0] %= R  # evaluate the closed-form fields periodically in x: every slab carries the same plume
-        f = fields.synthetic_fields(wrapped, R)
+        f = fields.synthetic_fields(eval_origins, R)
         self.solver.load_local(f["vel"], [f["density"]])
         self._ev = []
         self._timing = False

@@ -129,3 +129,19 @@ def test_slab_bench_driver_single_rank():
     assert launches == 10 and ms > 0.0
     torch.cuda.synchronize()
     assert torch.isfinite(b.solver.u).all()
+
+
+def test_partitioned_bench_driver_matches_the_slab_driver_at_world_one():
+    """bench.py --partition splits ONE domain across the ranks (BASELINE.json's 1024^3-extent configuration); with one
+    rank both drivers run the same substeps on the same leaves."""
+    import torch
+
+    o = fields.plume_leaves(8, 1.0, 0.3)
+    a = HD.SlabBench(o, 64, 0, 1, 6, 1.0 / 24.0)
+    b = HD.SlabBench(o, 64, 0, 1, 6, 1.0 / 24.0, partition=True)
+    for _ in range(2):
+        a.step()
+        b.step()
+    torch.cuda.synchronize()
+    assert torch.equal(a.solver.u, b.solver.u) and torch.equal(a.solver.phi[0], b.solver.phi[0])
+    assert b.plan.n_owned == len(o)
