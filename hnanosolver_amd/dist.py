@@ -14,7 +14,8 @@ refreshes ghost payloads with whole-leaf messages: received data lands directly 
 Exchanges sit exactly where the single-GPU code has a global kernel boundary that a stencil crosses, so owned results
 are bit-identical to the single-GPU run:
 
-    exchange(u, phi) -> advect_vector -> exchange(u*) -> divergence -> exchange(div)
+    exchange(u, phi) [u only on the first substep: the last exchange of a substep already refreshed it]
+      -> advect_vector -> exchange(u*) -> divergence -> exchange(div)
       -> iterations x fused red+black sweep, exchange(p) after every 4th sweep
       -> gradient subtraction -> exchange(u) -> advect_scalars
 
@@ -329,11 +330,13 @@ class DistributedSolver:
         self.phi_next = [engine.zeros(n) for _ in range(n_scalars)]
         self.p = self.p_a
         self.halo = HaloExchanger(plan, engine, group)
+        self._u_ghosts_fresh = False  # whoever writes self.u outside core_substep must reset this
         self.omega = omega_compute(voxel_size)
         engine.set_outside_element(plan.outside_element)
 
     def load_local(self, vel_aos: np.ndarray, scalars: Sequence[np.ndarray]) -> None:
         """Initial data for the LOCAL leaves (owned + ghosts), velocity as (n_local*512, 3) AoS."""
+        self._u_ghosts_fresh = False
         self.u.copy_(self.e.from_numpy(vel_aos).view(-1, 3))
         for k, s in enumerate(scalars):
             self.phi[k].copy_(self.e.from_numpy(s))
@@ -358,9 +361,15 @@ class DistributedSolver:
             src, dst = dst, src
         self.p = src
 
+    def start_exchange(self) -> None:
+        """Ghosts of u and phi before advection (with the mirror of global leaf 0: advect_scalars reads phi's and u's element
+        0). The previous substep ended by exchanging u and nothing has written it since: then only phi travels."""
+        self.halo.exchange(([] if self._u_ghosts_fresh else [self.u]) + self.phi)
+        self._u_ghosts_fresh = False
+
     def core_substep(self, iterations: int, dt: float) -> None:
         e, h = self.e, self.halo
-        h.exchange([self.u] + self.phi)  # with the mirror of global leaf 0: advect_scalars reads phi's (and u's) element 0
+        self.start_exchange()
         e.advect_vector(self.u, self.adv, dt, self.inv_dx)
         h.exchange([self.adv], mirror=False)
         e.divergence(self.adv, self.div, self.inv_dx)
@@ -368,6 +377,7 @@ class DistributedSolver:
         self.pressure_solve(iterations)
         e.subtract_pressure_gradient(self.adv, self.p, self.u, self.inv_dx)
         h.exchange([self.u])
+        self._u_ghosts_fresh = True
         e.advect_scalars(self.u, self.phi, self.phi_next, dt, self.inv_dx)
         self.phi, self.phi_next = self.phi_next, self.phi
 
@@ -425,7 +435,7 @@ class SlabBench:
             return
         # same as DistributedSolver.core_substep with the pressure loop bracketed by events on the launch stream
         e, h = s.e, s.halo
-        h.exchange([s.u] + s.phi)
+        s.start_exchange()
         e.advect_vector(s.u, s.adv, self.dt, s.inv_dx)
         h.exchange([s.adv], mirror=False)
         e.divergence(s.adv, s.div, s.inv_dx)
@@ -438,6 +448,7 @@ class SlabBench:
         self._launches += self.iterations
         e.subtract_pressure_gradient(s.adv, s.p, s.u, s.inv_dx)
         h.exchange([s.u])
+        s._u_ghosts_fresh = True
         e.advect_scalars(s.u, s.phi, s.phi_next, self.dt, s.inv_dx)
         s.phi, s.phi_next = s.phi_next, s.phi
 
