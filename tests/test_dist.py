@@ -69,7 +69,7 @@ def test_slab_plan_matches_generic_plan():
 
 
 class OracleEngine:
-    """TEST-ONLY engine: runs the oracle on the rank's local leaves (CPU torch tensors, planar velocity)."""
+    """TEST-ONLY engine: runs the oracle on the rank's local leaves (CPU torch tensors, Vec3f AoS velocity like the device engine)."""
 
     def __init__(self, local_origins, n_owned, voxel_size):
         import torch

@@ -77,7 +77,7 @@ class Case:
     def dev(self, a):
         return self.torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
-    def planar(self, vel_aos):  # velocity lives on the device as Vec3f AoS, the host layout
+    def device_velocity(self, vel_aos):  # velocity lives on the device as Vec3f AoS, the host layout
         return self.dev(vel_aos)
 
     @staticmethod
@@ -111,7 +111,7 @@ def test_offsets_match_oracle(case):
 def test_divergence(case):
     from hnanosolver_amd import device as D
 
-    u = case.planar(case.f["vel"])
+    u = case.device_velocity(case.f["vel"])
     div = case.torch.zeros(case.N, device="cuda")
     D.divergence(case.grid, u, div, case.inv_dx)
     assert_close(div.cpu().numpy(), case.oracle.divergence(case.f["vel"], case.inv_dx), "divergence")
@@ -144,7 +144,7 @@ def test_subtract_pressure_gradient(case):
     from hnanosolver_amd import device as D
 
     p_h = (np.random.default_rng(6).standard_normal(case.N)).astype(np.float32)
-    u = case.planar(case.f["vel"])
+    u = case.device_velocity(case.f["vel"])
     out = case.torch.zeros_like(u)
     D.subtract_pressure_gradient(case.grid, u, case.dev(p_h), out, case.inv_dx)
     assert_close(Case.aos(out), case.oracle.subtract_pressure_gradient(case.f["vel"], p_h, case.inv_dx), "subtract_pressure_gradient")
@@ -156,7 +156,7 @@ def test_subtract_pressure_gradient(case):
 def test_advect_vector(case):
     from hnanosolver_amd import device as D
 
-    u = case.planar(case.f["vel"])
+    u = case.device_velocity(case.f["vel"])
     out = case.torch.zeros_like(u)
     D.advect_vector(case.grid, u, out, case.dt, case.inv_dx)
     assert_close(Case.aos(out), case.oracle.advect_vector(case.f["vel"], case.dt, case.inv_dx), "advect_vector")
@@ -165,7 +165,7 @@ def test_advect_vector(case):
 def test_advect_scalar(case):
     from hnanosolver_amd import device as D
 
-    u = case.planar(case.f["vel"])
+    u = case.device_velocity(case.f["vel"])
     out = case.torch.zeros(case.N, device="cuda")
     D.advect_scalar(case.grid, u, case.dev(case.f["density"]), out, case.dt, case.inv_dx)
     assert_close(out.cpu().numpy(), case.oracle.advect_scalar(case.f["vel"], case.f["density"], case.dt, case.inv_dx), "advect_scalar")
@@ -180,7 +180,7 @@ def test_advect_scalars(case, S):
     phis = [case.f[names[i % 5]] if i < 5 else rng.standard_normal(case.N).astype(np.float32) for i in range(S)]
     phis = [p.copy() for p in phis]
     phis[0][0] = 100.0  # pins the "out-of-domain taps read element 0" behaviour (Kernel.cu:133,192,225)
-    u = case.planar(case.f["vel"])
+    u = case.device_velocity(case.f["vel"])
     outs = [case.torch.zeros(case.N, device="cuda") for _ in range(S)]
     D.advect_scalars(case.grid, u, [case.dev(p) for p in phis], outs, case.dt, case.inv_dx)
     want = case.oracle.advect_scalars(case.f["vel"], phis, case.dt, case.inv_dx)
@@ -193,7 +193,7 @@ def test_long_backtrace_uses_hash():
     from hnanosolver_amd import device as D
 
     c = Case("dense32", amplitude=400.0)
-    u = c.planar(c.f["vel"])
+    u = c.device_velocity(c.f["vel"])
     out = c.torch.zeros_like(u)
     D.advect_vector(c.grid, u, out, c.dt, c.inv_dx)
     assert_close(Case.aos(out), c.oracle.advect_vector(c.f["vel"], c.dt, c.inv_dx), "advect_vector long")
@@ -215,7 +215,7 @@ def test_combustion_and_buoyancy(case):
     want = case.oracle.combustion_oxygen(f["fuel"], waste, f["temperature"], div_h, f["flame"], 0.5, 0.1)
     for got, w, name in zip(outs + [div], want, ["fuel", "waste", "temperature", "flame", "divergence"]):
         assert_close(got.cpu().numpy(), w, f"combustion {name}")
-    u = case.planar(f["vel"])
+    u = case.device_velocity(f["vel"])
     D.temperature_buoyancy(u, case.dev(f["temperature"]), u, case.dt, 23.0, 1.0)
     assert_close(Case.aos(u), case.oracle.temperature_buoyancy(f["vel"], f["temperature"], case.dt, 23.0, 1.0), "buoyancy")
 
@@ -224,7 +224,7 @@ def test_combustion_and_buoyancy(case):
 def test_vorticity_confinement(case, factor_scale):
     from hnanosolver_amd import device as D
 
-    u = case.planar(case.f["vel"])
+    u = case.device_velocity(case.f["vel"])
     out = case.torch.zeros_like(u)
     D.vorticity_confinement(case.grid, u, out, case.dt, case.inv_dx, 1.0, factor_scale)
     assert_close(Case.aos(out), case.oracle.vorticity_confinement(case.f["vel"], case.dt, case.inv_dx, 1.0, factor_scale), f"vorticity fs={factor_scale}")
@@ -238,10 +238,10 @@ def test_collision_paths(case):
     sdf_h[::7] = np.float32(0.05)
     sdf = case.dev(sdf_h)
     f = case.f
-    u = case.planar(f["vel"])
+    u = case.device_velocity(f["vel"])
     D.enforce_collision_boundaries(case.grid, u, sdf, case.vs)
     assert_close(Case.aos(u), case.oracle.enforce_collision_boundaries(f["vel"], sdf_h, case.vs), "enforce_collision")
-    u = case.planar(f["vel"])
+    u = case.device_velocity(f["vel"])
     out = case.torch.zeros_like(u)
     D.advect_vector(case.grid, u, out, case.dt, case.inv_dx, sdf, True)
     assert_close(Case.aos(out), case.oracle.advect_vector(f["vel"], case.dt, case.inv_dx, sdf_h, True), "advect_vector+collision")
