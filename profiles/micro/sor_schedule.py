@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""XCD-chunked vs linear launch order of the SOR sweep against grid size (run once per HNS_SCHEDULE setting)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from hnanosolver_amd import api, device as D, fields
+for R in (192, 224, 256, 288, 320, 384):
+    origins = fields.dense_leaves(R)
+    grid = api.create_grid_from_leaves(origins, 1.0 / R)
+    N = len(origins) * 512
+    div = torch.randn(N, device="cuda"); p_a = torch.zeros(N, device="cuda"); p_b = torch.zeros(N, device="cuda")
+    ms = min(D.time_rbgs(grid, div, p_a, p_b, 1.0 / R, 1.97, 50, 3) for _ in range(2))
+    print(os.environ.get("HNS_SCHEDULE", "chunk"), R, f"{1e3 * ms:.2f} us", flush=True)
+    del grid, div, p_a, p_b
+    torch.cuda.empty_cache()
