@@ -670,12 +670,15 @@ __device__ __forceinline__ void pair_compute(PairTile& S, const PairLaneCtx& c, 
 	}
 }
 
+// `last`: index of the last record when this sweep walks the list backwards (odd sweeps of a solve), else -1. Beyond the
+// Infinity Cache a sweep ends with the tail of the arrays cached; the next one starts there.
 template <bool ZERO>
 __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs, const float* __restrict__ div, const float* __restrict__ p_in,
-                                                  float* __restrict__ p_out, const float dx2, const float omega) {
+                                                  float* __restrict__ p_out, const float dx2, const float omega, const int last) {
 	__shared__ __attribute__((aligned(16))) PairTile S;
 	const PairLaneCtx c = pair_lane_ctx();
-	const PairIn in = pair_load<ZERO>(c, pairs + (size_t)blockIdx.x * 56, div, p_in);
+	const unsigned rec = last < 0 ? blockIdx.x : (unsigned)last - blockIdx.x;
+	const PairIn in = pair_load<ZERO>(c, pairs + (size_t)rec * 56, div, p_in);
 	pair_compute(S, c, in, p_out, dx2, omega);
 }
 
@@ -841,16 +844,17 @@ static bool uses_pair_form(const hns_grid* g, int mode) {
 // one full (red, black) iteration src -> dst. src_is_zero (pair form only): the caller vouches that src is 0 on every
 // leaf (first iteration of a solve) and the kernel skips reading it.
 static void launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* div, const float* src, float* dst, float dx2, float omega, int mode,
-                                  hipStream_t st, bool src_is_zero = false) {
+                                  hipStream_t st, bool src_is_zero = false, bool backwards = false) {
+	const int last = backwards ? (int)g->n_pairs - 1 : -1;
 	if (uses_block_form(g, mode)) {
 		hipLaunchKernelGGL(k_rbgs_fused, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, src, dst, dx2, omega);
 	} else if (!uses_pair_form(g, mode)) {
 		hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_active), dim3(64), 0, st, gd, div, src, dst, dx2, omega);
 	} else if (src_is_zero) {
-		hipLaunchKernelGGL(k_rbgs_pair<true>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, src, dst, dx2, omega);
+		hipLaunchKernelGGL(k_rbgs_pair<true>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, src, dst, dx2, omega, last);
 	} else {
 		// one launch: the record list holds the z-adjacent pairs and, as {leaf, nbr27, -1, ...}, the leaves that found no partner
-		hipLaunchKernelGGL(k_rbgs_pair<false>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, src, dst, dx2, omega);
+		hipLaunchKernelGGL(k_rbgs_pair<false>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, src, dst, dx2, omega, last);
 	}
 }
 
@@ -881,6 +885,10 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 		from_zero = false;
 	}
 	const int mode = mode_env | (from_zero ? 256 : 0);  // graph-cache key: kernel form + whether the first sweep skips p_a
+	// Odd sweeps walk the record list backwards: a sweep ends with the tail of p / div in the Infinity Cache and the next one
+	// begins there. Nothing below the cache size, -11 % at 288^3 (287 MB of sweep arrays against 256 MB of cache), -6 % at
+	// 320^3, -1.4 % at 512^3 (profiles/micro/sor_schedule.py). The result does not depend on the order. HNS_ALTERNATE=0: off.
+	static const bool alternate = !(getenv("HNS_ALTERNATE") && atoi(getenv("HNS_ALTERNATE")) == 0);
 	static const bool use_graph = getenv("HNS_GRAPH") && strcmp(getenv("HNS_GRAPH"), "1") == 0;
 
 	// Optional (HNS_GRAPH=1): replay the loop as one hipGraph, captured once per (buffers, parameters) on a private stream
@@ -904,7 +912,7 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 				float* src = p_a;
 				float* dst = p_b;
 				for (int it = 0; it < iterations; ++it) {
-					launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode_env, cs, from_zero && it == 0);
+					launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode_env, cs, from_zero && it == 0, alternate && (it & 1));
 					float* tmp = src;
 					src = dst;
 					dst = tmp;
@@ -936,7 +944,7 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 	float* src = p_a;
 	float* dst = p_b;
 	for (int it = 0; it < iterations; ++it) {
-		launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode_env, (hipStream_t)stream, from_zero && it == 0);
+		launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode_env, (hipStream_t)stream, from_zero && it == 0, alternate && (it & 1));
 		float* tmp = src;
 		src = dst;
 		dst = tmp;
