@@ -677,7 +677,13 @@ __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs,
                                                   float* __restrict__ p_out, const float dx2, const float omega, const int last) {
 	__shared__ __attribute__((aligned(16))) PairTile S;
 	const PairLaneCtx c = pair_lane_ctx();
-	const unsigned rec = last < 0 ? blockIdx.x : (unsigned)last - blockIdx.x;
+	// backwards = rows of eight records in reverse order, the position inside a row kept: workgroup b still lands on XCD
+	// b % 8, whose L2 holds that chunk's leaves from the previous sweep when the grid is small enough (128^3: all of it)
+	unsigned rec = blockIdx.x;
+	if (last >= 0) {
+		const unsigned rows = ((unsigned)last + 1u) >> 3;
+		if ((rec >> 3) < rows) rec = ((rows - 1u - (rec >> 3)) << 3) | (rec & 7u);
+	}
 	const PairIn in = pair_load<ZERO>(c, pairs + (size_t)rec * 56, div, p_in);
 	pair_compute(S, c, in, p_out, dx2, omega);
 }
