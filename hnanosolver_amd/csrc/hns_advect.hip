@@ -70,7 +70,8 @@ __device__ __forceinline__ void ld_zpair(const v4i& r, unsigned lo, unsigned hi,
 // base byte offsets in a float field (kOutside = absent)
 __device__ __forceinline__ LeafCtx stage_leaf_base(const GridDev& g, int* s_nbr, int* s_base, int block, unsigned* s_b4 = nullptr) {
 	LeafCtx c;
-	c.leaf = g.sched ? g.sched[block] : block;
+	const int pos = (int)launch_pos(g, (unsigned)block);
+	c.leaf = g.sched ? g.sched[pos] : pos;
 	c.org = g.origins[c.leaf];
 	if (threadIdx.x < 27) {
 		const int nb = g.nbr27[c.leaf * 27 + threadIdx.x];
@@ -742,7 +743,14 @@ int hns_dev_advect_scalars(hns_grid* g, const float* vel3, const float* const* i
 		if (has_collision && sdf)
 			hipLaunchKernelGGL(k_advect_scalars<true>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, P, sdf, scaled_dt);
 		else if (narrow_fields(g))
-			hipLaunchKernelGGL(k_advect_scalars_n, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, P, scaled_dt);
+		{
+			GridDev gd = g->dev();
+			// backwards: the gradient kernel has just written the velocity front to back; starting on its cached tail also
+			// leaves the head cached for the next substep's advect_vector (256^3: -1 % here, -4 % there). HNS_REV=0: forwards.
+			static const bool rv = !(getenv("HNS_REV") && atoi(getenv("HNS_REV")) == 0);
+			gd.rev = rv;
+			hipLaunchKernelGGL(k_advect_scalars_n, grid, block, 0, (hipStream_t)stream, gd, vel3, P, scaled_dt);
+		}
 		else
 			hipLaunchKernelGGL(k_advect_scalars<false>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, P, sdf, scaled_dt);
 	}

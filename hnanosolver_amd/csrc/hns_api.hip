@@ -41,6 +41,7 @@ GridDev hns_grid::dev() const {
 	d.n_leaves = (int)topo.n_leaves;
 	d.n_active = (int)n_active;
 	d.oob = (int)outside_element;
+	d.rev = 0;
 	return d;
 }
 

@@ -54,7 +54,15 @@ struct GridDev {
 	int n_leaves;
 	int n_active;
 	int oob;  // element read by advect_scalars for out-of-domain taps (0 on an unpartitioned grid)
+	int rev;  // 1: walk the launch order backwards (rows of eight workgroups reversed, see k_rbgs_pair)
 };
+
+// workgroup -> position in the launch-order tables, honouring GridDev::rev
+__device__ __forceinline__ unsigned launch_pos(const GridDev& g, unsigned b) {
+	if (!g.rev) return b;
+	const unsigned rows = (unsigned)g.n_active >> 3;
+	return (b >> 3) < rows ? (((rows - 1u - (b >> 3)) << 3) | (b & 7u)) : b;
+}
 
 // a captured pressure loop (hipGraphExec_t) and the arguments it was captured for
 struct RbgsGraph {

@@ -49,6 +49,7 @@ VARIANTS = {
     "sor_graph_replay": {"HNS_GRAPH": "1"},
     "schedule_linear": {"HNS_SCHEDULE": "linear"},
     "sor_one_direction": {"HNS_ALTERNATE": "0", "HNS_RBGS": "pair"},
+    "all_kernels_forwards": {"HNS_REV": "0"},
     "divergence_block": {"HNS_STENCIL": "block"},
     "cook_unpipelined_uncached": {"HNS_COOK_PIPELINE": "0", "HNS_COOK_CACHE": "0"},
 }
