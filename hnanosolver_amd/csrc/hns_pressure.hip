@@ -718,6 +718,57 @@ __global__ __launch_bounds__(512) void k_subtract_gradient(const GridDev g, cons
 	st3(out, idx, r);
 }
 
+// Streaming form (no collision field): one wave per leaf. The pressure of the leaf and of the six touching face layers is
+// staged in LDS (own values: two 16-byte loads per lane; a face layer: one value per lane); the velocity then streams
+// through as 384 fully coalesced 16-byte chunks per leaf, each float subtracting the gradient component it belongs to
+// (float f of the leaf: voxel f / 3, component f % 3, taps along that axis only). Same expression per component:
+// ((p(+) - p(-)) * 0.5f) * inv_dx. The 512-thread form issues ~12 load/store instructions per wave of 64 voxels, mostly
+// 12-byte and scattered 4-byte accesses; this one issues 20 per 512 voxels.
+__global__ __launch_bounds__(64) void k_subtract_gradient_s(const GridDev g, const float* u, const float* __restrict__ p, float* out, const float inv_dx) {
+	__shared__ __attribute__((aligned(16))) float P[kTile];
+	const int l = threadIdx.x;
+	const int* __restrict__ rec = g.blk + (size_t)launch_pos(g, blockIdx.x) * 28;
+	const int leaf = __builtin_amdgcn_readfirstlane(rec[0]);
+	{
+		const float4* q = reinterpret_cast<const float4*>(p + (size_t)leaf * 512 + l * 8);
+		const float4 a = q[0], b = q[1];
+		*reinterpret_cast<float4*>(&P[l * 8]) = a;
+		*reinterpret_cast<float4*>(&P[l * 8 + 4]) = b;
+	}
+#pragma unroll
+	for (int f = 0; f < 6; ++f) {  // face f: -x,+x,-y,+y,-z,+z; its 64 entries are one per lane
+		int slot, local;
+		halo_entry(f * 64 + l, slot, local);
+		const int nb = __builtin_amdgcn_readfirstlane(rec[1 + slot]);
+		const float v = p[(size_t)(nb < 0 ? 0 : nb) * 512 + local];
+		P[512 + f * 64 + l] = nb < 0 ? 0.0f : v;
+	}
+	__syncthreads();
+	const float4* src = reinterpret_cast<const float4*>(u + (size_t)leaf * 1536);
+	float4* dst = reinterpret_cast<float4*>(out + (size_t)leaf * 1536);
+	float4 a[6];
+#pragma unroll
+	for (int j = 0; j < 6; ++j) a[j] = src[l + 64 * j];
+#pragma unroll
+	for (int j = 0; j < 6; ++j) {
+		float r[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
+#pragma unroll
+		for (int e = 0; e < 4; ++e) {
+			const int f = 4 * (l + 64 * j) + e;
+			const int v = __mul24(f, 683) >> 11;  // f / 3 for f < 1536
+			const int comp = f - 3 * v;
+			const int shift = comp == 0 ? 6 : (comp == 1 ? 3 : 0);
+			const int c = (v >> shift) & 7;
+			const int x = v >> 6, y = (v >> 3) & 7, z = v & 7;
+			const int ab = comp == 0 ? ((y << 3) | z) : (comp == 1 ? ((x << 3) | z) : ((x << 3) | y));
+			const int plus = c != 7 ? v + (1 << shift) : 512 + 64 * (2 * comp + 1) + ab;
+			const int minus = c != 0 ? v - (1 << shift) : 512 + 64 * (2 * comp) + ab;
+			r[e] = r[e] - ((P[plus] - P[minus]) * 0.5f) * inv_dx;
+		}
+		dst[l + 64 * j] = make_float4(r[0], r[1], r[2], r[3]);
+	}
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // divergence, one wave per leaf (the production form)
 // ---------------------------------------------------------------------------------------------------------------
@@ -998,10 +1049,13 @@ int hns_dev_subtract_pressure_gradient(hns_grid* g, const float* vel3, const flo
 	// (a wave-per-leaf row form like k_divergence_row was measured for this kernel too: 118 us vs 111 us at 256^3 -- not kept)
 	// (also measured and not kept for this kernel: the six taps through an LDS tile as in the advection kernels, 125 vs 116 us --
 	// at 470 MB per launch it streams from HBM and the extra barrier costs more than the loads it saves)
+	static const bool block_form = getenv("HNS_STENCIL") && strcmp(getenv("HNS_STENCIL"), "block") == 0;  // A/B switch
 	if (has_collision && sdf)
 		hipLaunchKernelGGL(k_subtract_gradient<true>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, p, out3, sdf, inv_dx);
-	else
+	else if (block_form || !g->d_blk)
 		hipLaunchKernelGGL(k_subtract_gradient<false>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, p, out3, sdf, inv_dx);
+	else
+		hipLaunchKernelGGL(k_subtract_gradient_s, grid, dim3(64), 0, (hipStream_t)stream, g->dev(), vel3, p, out3, inv_dx);
 	return launch_status("hns_dev_subtract_pressure_gradient");
 }
 
