@@ -12,6 +12,6 @@ of the reference's operator interface used by the tests, the benchmark and the m
 
 There is no CPU fallback: importing works anywhere, computing needs a HIP device and the built library.
 """
-from ._lib import lib, load_library, HNSError, library_path  # noqa: F401
+from ._lib import lib, load_library, HNSError, library_path, set_option, get_option  # noqa: F401
 
-__all__ = ["lib", "load_library", "HNSError", "library_path"]
+__all__ = ["lib", "load_library", "HNSError", "library_path", "set_option", "get_option"]

@@ -46,6 +46,8 @@ SIGNATURES = {
     "hns_version": (_i, []),
     "hns_device_count": (_i, []),
     "hns_trim_memory": (_i, []),
+    "hns_set_option": (_i, [C.c_char_p, C.c_char_p]),
+    "hns_get_option": (C.c_char_p, [C.c_char_p]),
     "hns_grid_create": (_vp, [_vp, _u64, _f, C.c_uint, _ip]),
     "hns_grid_create_from_leaves": (_vp, [_vp, _u64, _f, C.c_uint, _ip]),
     "hns_grid_destroy": (None, [_vp]),
@@ -128,6 +130,16 @@ class _LazyLib:
 
 
 lib = _LazyLib()
+
+
+def set_option(name: str, value=None) -> None:
+    """hns_set_option: switch an alternative kernel form / data-movement strategy (include/hns.h); value None = default."""
+    check(load_library().hns_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+def get_option(name: str):
+    v = load_library().hns_get_option(name.encode())
+    return None if v is None else v.decode()
 
 
 def check(code: int) -> None:

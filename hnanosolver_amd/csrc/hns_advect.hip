@@ -681,10 +681,9 @@ __global__ __launch_bounds__(512) void k_advect_scalars(const GridDev g, const f
 
 using namespace hns;
 
-// the 32-bit addressed kernels apply while a Vec3f field stays below kNarrowBytes; HNS_ADVECT=generic forces the 64-bit ones (A/B, tests)
+// the 32-bit addressed kernels apply while a Vec3f field stays below kNarrowBytes; option "advect" = generic forces the 64-bit ones (A/B, tests)
 static bool narrow_fields(const hns_grid* g) {
-	static const bool generic = getenv("HNS_ADVECT") && strcmp(getenv("HNS_ADVECT"), "generic") == 0;
-	return !generic && (uint64_t)g->topo.n_leaves * 6144u <= hns::kNarrowBytes;
+	return !options().advect_generic.load() && (uint64_t)g->topo.n_leaves * 6144u <= hns::kNarrowBytes;
 }
 
 extern "C" {
@@ -746,9 +745,8 @@ int hns_dev_advect_scalars(hns_grid* g, const float* vel3, const float* const* i
 		{
 			GridDev gd = g->dev();
 			// backwards: the gradient kernel has just written the velocity front to back; starting on its cached tail also
-			// leaves the head cached for the next substep's advect_vector (256^3: -1 % here, -4 % there). HNS_REV=0: forwards.
-			static const bool rv = !(getenv("HNS_REV") && atoi(getenv("HNS_REV")) == 0);
-			gd.rev = rv;
+			// leaves the head cached for the next substep's advect_vector (256^3: -1 % here, -4 % there). Option "rev" = 0: forwards.
+			gd.rev = options().rev.load();
 			hipLaunchKernelGGL(k_advect_scalars_n, grid, block, 0, (hipStream_t)stream, gd, vel3, P, scaled_dt);
 		}
 		else

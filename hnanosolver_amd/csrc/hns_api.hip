@@ -98,6 +98,18 @@ struct Arena {
 	size_t bytes;
 	int device;
 };
+// makes `device` current for the scope (allocations, frees and synchronisation of pooled memory belong to ITS device,
+// whatever the calling thread has current)
+struct DeviceScope {
+	int prev = -1;
+	bool switched = false;
+	explicit DeviceScope(int device) {
+		if (device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+	}
+	~DeviceScope() {
+		if (switched) (void)hipSetDevice(prev);
+	}
+};
 std::mutex g_pool_mutex;
 std::vector<Arena> g_pool;  // at most kPoolMax idle arenas
 constexpr size_t kPoolMax = 6;  // simulation states (GBs) and grid tables (MBs) share it; the smallest goes first
@@ -118,6 +130,7 @@ int arena_get(size_t need, int device, Arena& out) {
 	}
 	out.bytes = need + need / 8;  // headroom: the next, slightly larger topology still fits
 	out.device = device;
+	DeviceScope scope(device);
 	if (hipMalloc(&out.p, out.bytes) != hipSuccess) {
 		(void)hipGetLastError();
 		std::vector<Arena> drop;  // out of memory with idle arenas around: release them and retry at the exact size
@@ -132,8 +145,13 @@ int arena_get(size_t need, int device, Arena& out) {
 	return HNS_OK;
 }
 
+// The hipFree this pool replaces waits for the device; so does this: whoever draws the memory next may use it on any
+// stream without ordering itself after the previous owner's queued kernels and copies. Cooks are synchronous, so the
+// device is normally idle here and the wait costs microseconds.
 void arena_put(const Arena& a) {
 	if (!a.p) return;
+	DeviceScope scope(a.device);
+	(void)hipDeviceSynchronize();
 	Arena evict{nullptr, 0, -1};
 	{
 		std::lock_guard<std::mutex> lock(g_pool_mutex);
@@ -262,6 +280,12 @@ extern "C" hns_sim* hns_sim_create(hns_grid* g, const char* const* float_names, 
 		return nullptr;
 	}
 	hns_sim* s = sim_create(g, float_names, n_float, true, nullptr, &rc);
+	// the clear ran on the null stream: finish it, so that the caller may use any stream (also a non-blocking one) afterwards
+	if (s && hipStreamSynchronize(nullptr) != hipSuccess) {
+		rc = fail(HNS_ERR_HIP, "hns_sim_create: clearing the field memory failed");
+		hns_sim_destroy(s);
+		s = nullptr;
+	}
 	if (err) *err = rc;
 	return s;
 }
@@ -549,7 +573,7 @@ int split_fields(hns_field* fields, int n_fields, FieldSplit& out, const char* w
 // device-resident hns_sim for its field-name list from the grid and returns it afterwards; the buffers live until the
 // grid is destroyed or hns_grid_release_cache() is called. Two entries cover the usual "full solver + one single-field
 // operator" pattern; a call that finds its entry lent out (concurrent cooks on one grid) works on a private sim.
-// HNS_COOK_CACHE=0 disables the cache.
+// Option "cook_cache" = 0 disables the cache.
 struct SimGuard {
 	hns_sim* s = nullptr;
 	~SimGuard() {
@@ -566,8 +590,7 @@ struct SimGuard {
 int make_sim(hns_grid* g, const FieldSplit& fs, SimGuard& guard, void* stream) {
 	std::vector<const char*> names;
 	for (hns_field* f : fs.floats) names.push_back(f->name);
-	const char* env = getenv("HNS_COOK_CACHE");
-	const bool use_cache = !(env && strcmp(env, "0") == 0);
+	const bool use_cache = options().cook_cache.load() != 0;
 	if (use_cache) {
 		std::lock_guard<std::mutex> lock(g->host_mutex);
 		for (hns_sim* c : g->sim_cache) {
@@ -623,12 +646,11 @@ int make_sim(hns_grid* g, const FieldSplit& fs, SimGuard& guard, void* stream) {
 // part of the substep is enqueued on the caller's stream as soon as its inputs are queued: advect_vector + divergence
 // run under the upload of fuel and waste, the pressure solve under the upload of every other field (Substep::part_b1),
 // and advect_scalars under the download of the final velocity. Same kernels, same order per buffer; only the overlap
-// differs. HNS_COOK_PIPELINE=0 falls back to upload-all / run / download-all.
+// differs. Option "cook_pipeline" = 0 falls back to upload-all / run / download-all.
 static int compute_sim_pipelined(hns_sim* s, FieldSplit& fs, int iterations, float dt, float voxel_size, const hns_combustion_params* params,
                                  int has_collision, void* stream) {
-	const char* env = getenv("HNS_COOK_PIPELINE");
 	Substep step;
-	if (env && strcmp(env, "0") == 0) {
+	if (!options().cook_pipeline.load()) {
 		std::vector<hns_field> all;
 		all.push_back(*fs.velocity);
 		for (hns_field* f : fs.floats) all.push_back(*f);
@@ -698,7 +720,13 @@ extern "C" int hns_compute_sim(hns_grid* g, hns_field* fields, int n_fields, int
 	if (!g->on_device) return fail(HNS_ERR_NO_DEVICE, "hns_compute_sim: grid has no device tables (there is no CPU fallback)");
 	SimGuard guard;
 	HNS_TRY(make_sim(g, fs, guard, stream));
-	HNS_TRY(compute_sim_pipelined(guard.s, fs, iterations, dt, voxel_size, params, has_collision, stream));
+	if (int rc = compute_sim_pipelined(guard.s, fs, iterations, dt, voxel_size, params, has_collision, stream)) {
+		// copies on the transfer stream and kernels on the caller's may still be queued: let them finish before the
+		// guard hands the buffers on (and before the caller reuses its host arrays)
+		if (guard.s->xfer) (void)hipStreamSynchronize(guard.s->xfer);
+		(void)hipStreamSynchronize((hipStream_t)stream);
+		return rc;
+	}
 	// The reference copies every float block back from its OUTPUT buffer; "collision_sdf" is never advected, so its
 	// output buffer is still the memset zeros and the caller's SDF array comes back zeroed (HNanoSolver.cu:115-117,327,364-369).
 	for (hns_field* f : fs.floats)

@@ -211,6 +211,11 @@ inline int check_grid(const hns_grid* g, const char* who) {
 		hns::set_error("%s: grid has no device tables (host-only grid or no HIP device); there is no CPU fallback", who);
 		return HNS_ERR_NO_DEVICE;
 	}
+	int cur = -1;
+	if (hipGetDevice(&cur) != hipSuccess || cur != g->device) {  // launches go to the CURRENT device; the grid's tables live on g->device
+		hns::set_error("%s: the grid lives on HIP device %d but device %d is current in this thread", who, g->device, cur);
+		return HNS_ERR_INVALID_ARGUMENT;
+	}
 	return HNS_OK;
 }
 

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_build_nbr27(GridDev g, int* __restrict_
 // Block -> leaf order. The dispatcher places workgroup b on XCD b % 8 (observed, not contractual), each XCD has a
 // private 4 MiB L2, and a leaf's halo is its neighbours' payload: every XCD gets one contiguous chunk of the leaf
 // list (sizes differ by at most one leaf), so halo reads hit the L2 that already holds those leaves. Speed only; any
-// order is correct. HNS_SCHEDULE=linear disables it.
+// order is correct. Option "schedule" = linear disables it.
 __host__ __device__ inline int sched_leaf(int b, int n, bool linear) {
 	if (linear) return b;
 	const int base = n >> 3, rem = n & 7;
@@ -187,15 +187,18 @@ using namespace hns;
 // allocation (hns_grid_upload), sized for n_active = n_leaves, so nothing is allocated here.
 int hns_grid_upload_schedule(hns_grid* g) {
 	g->n_pairs = g->n_singles = 0;
-	for (auto& e : g->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);  // captured launches hold the old lists
-	g->graphs.clear();
+	{
+		std::lock_guard<std::mutex> lock(g->graph_mutex);
+		for (auto& e : g->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);  // captured launches hold the old lists
+		g->graphs.clear();
+	}
 	const int n = (int)g->n_active;
 	if (n == 0) return HNS_OK;
 	// XCD-chunked order wins by a wide margin while the sweep arrays fit the Infinity Cache and its neighbourhood (256^3:
 	// 40.6 vs 53.5 us per sweep, 320^3: 108 vs 114); far beyond it plain leaf order is a little better (384^3: 186.6 vs
-	// 189.5, 512^3: 444 vs 462: all eight XCDs then stream through the same DRAM pages). HNS_SCHEDULE=linear|chunk forces one.
-	const char* mode = getenv("HNS_SCHEDULE");
-	const int linear = mode ? strcmp(mode, "linear") == 0 : n > 100000;
+	// 189.5, 512^3: 444 vs 462: all eight XCDs then stream through the same DRAM pages). Option "schedule" = linear|chunk forces one.
+	const int sched_opt = options().schedule.load();
+	const int linear = sched_opt == kScheduleAuto ? n > 100000 : sched_opt == kScheduleLinear;
 	g->d_sched = linear ? nullptr : g->d_sched_mem;
 	const int* nbr27 = (const int*)g->d_nbr27;
 	const int n_blocks = (n + 255) / 256;

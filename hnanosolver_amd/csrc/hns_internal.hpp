@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -20,6 +21,25 @@ inline int fail(int code, const char* msg) {
 	set_error("%s", msg);
 	return code;
 }
+
+// ---- options (hns_set_option) -------------------------------------------------------------------------------------
+// Alternative kernel forms and data-movement strategies kept for A/B measurement and as cross-checks of the default one.
+// Every entry point reads the current value when it is called, so a test or benchmark can switch forms between calls.
+enum { kRbgsAuto = 0, kRbgsColor = 1, kRbgsWave = 2, kRbgsPair = 3, kRbgsResident = 4 };
+enum { kScheduleAuto = 0, kScheduleLinear = 1, kScheduleChunk = 2 };
+struct Options {
+	std::atomic<int> rbgs{kRbgsAuto};          // "rbgs": auto | color | wave | pair | resident
+	std::atomic<int> advect_generic{0};        // "advect": auto | generic (64-bit addressed kernels)
+	std::atomic<int> stencil_block{0};         // "stencil": auto | block (512-thread divergence / gradient)
+	std::atomic<int> schedule{kScheduleAuto};  // "schedule": auto | linear | chunk (read when launch tables are built)
+	std::atomic<int> alternate{1};             // "alternate": odd SOR sweeps walk the records backwards
+	std::atomic<int> rev{1};                   // "rev": divergence / advect_scalars walk the leaves backwards
+	std::atomic<int> graph{0};                 // "graph": replay the pressure loop as a hipGraph
+	std::atomic<int> cook_cache{1};            // "cook_cache": operator calls keep their device buffers with the grid
+	std::atomic<int> cook_pipeline{1};         // "cook_pipeline": hns_compute_sim overlaps transfers with the substep
+	std::atomic<int> sor_block{0};             // "sor_block": 0 = auto, N = leaf pairs per workgroup of the blocked SOR kernel
+};
+Options& options();
 
 // ---- host topology ----------------------------------------------------------------------------------------------
 // Replaces the NanoGrid<ValueOnIndex> tree walk (reference Stencils.hpp:51-71 -> NanoVDB.h:5549) with flat tables:
@@ -92,7 +112,7 @@ struct hns_grid {
 	void* d_sched = nullptr;
 	void* d_blk = nullptr;
 	void* d_pairs = nullptr;    // launch-ordered wave records {leaf0, nbr27, leaf1 or -1, nbr27} (56 ints): z-adjacent pairs and lone leaves
-	void* d_sched_mem = nullptr;  // storage of d_sched (d_sched itself is null under HNS_SCHEDULE=linear)
+	void* d_sched_mem = nullptr;  // storage of d_sched (d_sched itself is null under the linear schedule)
 	void* d_scratch = nullptr;    // schedule-build scratch
 	void* d_arena = nullptr;      // the one device allocation all of the above are slices of (arena pool, hns_api.hip)
 	size_t arena_bytes = 0;

@@ -11,9 +11,9 @@
 //     (staged in LDS) or, beyond one leaf away, an origin hash;
 //   * velocity is Vec3f AoS on the device (the host layout): one 12-byte access per tap, and every
 //     2 KB leaf payload is one fully coalesced run;
-//   * the red-black SOR loop runs ONE launch per iteration: the workgroup stages its leaf plus a two-voxel halo of
+//   * the red-black SOR loop runs ONE launch per iteration: a wave stages its leaves plus a two-voxel halo of
 //     p in LDS, recomputes the red updates of the face-adjacent halo voxels itself (bit-identical to what the
-//     neighbouring workgroup computes), then does black, ping-ponging p_in -> p_out. 12 B/voxel/iteration of HBM
+//     neighbouring wave computes), then does black, ping-ponging p_in -> p_out. 12 B/voxel/iteration of HBM
 //     traffic instead of the >=16 B of two in-place launches.
 #include <cstdlib>
 #include <cstring>
@@ -68,141 +68,14 @@ __global__ __launch_bounds__(256) void k_rbgs_color(const GridDev g, const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// red-black SOR, fused form: one launch = one full (red, black) iteration, p_in -> p_out
+// red-black SOR, fused form (one launch = one full (red, black) iteration, p_in -> p_out), ONE WAVE PER LEAF
 // ---------------------------------------------------------------------------------------------------------------
 //
-// LDS tile T[12][12][12] holds p_in over the leaf (offset +2) plus: the two nearest voxel layers of each face
-// neighbour and the nearest voxel line of each edge neighbour. Phase R updates the 256 red voxels of the leaf and the
-// 6*32 red voxels directly across each face (only where that neighbour leaf exists; outside the domain p stays 0);
-// a halo red voxel (x=-1,y,z) needs p at (-2,y,z), (0,y,z), (-1,y+-1,z), (-1,y,z+-1): face layers and edge lines, never
-// corners. Phase B updates the 256 black voxels from the new red values. Thread t owns the z-adjacent pair
-// (2t, 2t+1) of the leaf: it loads p and div for the pair as one 8-byte access each and stores both new values
-// as one 8-byte access, so every global access of the leaf payload is a contiguous 2 KB run per workgroup.
-// Arithmetic per voxel is exactly sor_update(); the recomputed halo reds see the same inputs as the neighbouring
-// workgroup's own update, so the result is bit-identical to the two-launch form.
-
-#define T_IDX(x, y, z) (((x) + 2) * 144 + ((y) + 2) * 12 + ((z) + 2))
-
-__global__ __launch_bounds__(256) void k_rbgs_fused(const GridDev g, const float* __restrict__ div, const float* __restrict__ p_in,
-                                                    float* __restrict__ p_out, const float dx2, const float omega) {
-	__shared__ float T[12 * 12 * 12];
-	__shared__ int s_nbr[27];
-	const int t = threadIdx.x;
-	const int leaf = g.sched ? g.sched[blockIdx.x] : blockIdx.x;
-	if (t < 27) s_nbr[t] = g.nbr27[leaf * 27 + t];
-
-	// own leaf: pair (2t, 2t+1) = voxels (x, y, 2zp) and (x, y, 2zp+1)
-	const int x = t >> 5, y = (t >> 2) & 7, zp = t & 3;
-	const float2 pown = reinterpret_cast<const float2*>(p_in + leaf * 512)[t];
-	const float2 down = reinterpret_cast<const float2*>(div + leaf * 512)[t];
-	T[T_IDX(x, y, 2 * zp)] = pown.x;
-	T[T_IDX(x, y, 2 * zp + 1)] = pown.y;
-	__syncthreads();  // s_nbr visible
-
-	{  // -x / +x faces: layers x=6,7 of the -x neighbour (offsets 384..511), x=0,1 of the +x neighbour (0..127)
-		const int side = t >> 7, e = t & 127;
-		const int nl = s_nbr[side ? 22 : 4];
-		const float v = nl < 0 ? 0.0f : p_in[nl * 512 + (side ? 0 : 384) + e];
-		T[T_IDX((side ? 8 : -2) + (e >> 6), (e >> 3) & 7, e & 7)] = v;
-	}
-	{  // -y / +y faces: rows y=6,7 / y=0,1
-		const int side = t >> 7, e = t & 127;
-		const int xx = e >> 4, yy = (e >> 3) & 1, zz = e & 7;
-		const int nl = s_nbr[side ? 16 : 10];
-		const float v = nl < 0 ? 0.0f : p_in[nl * 512 + xx * 64 + ((side ? 0 : 6) + yy) * 8 + zz];
-		T[T_IDX(xx, (side ? 8 : -2) + yy, zz)] = v;
-	}
-	{  // -z / +z faces: z=6,7 / z=0,1
-		const int side = t >> 7, e = t & 127;
-		const int xx = e >> 4, yy = (e >> 1) & 7, zz = e & 1;
-		const int nl = s_nbr[side ? 14 : 12];
-		const float v = nl < 0 ? 0.0f : p_in[nl * 512 + xx * 64 + yy * 8 + (side ? 0 : 6) + zz];
-		T[T_IDX(xx, yy, (side ? 8 : -2) + zz)] = v;
-	}
-	if (t < 96) {  // 12 edge lines of 8 voxels
-		const int e = t >> 3, i = t & 7;
-		const int grp = e >> 2, a = (e >> 1) & 1, b = e & 1;  // grp 0: (x,y) edges along z; 1: (x,z) along y; 2: (y,z) along x
-		const int da = a ? 1 : -1, db = b ? 1 : -1;
-		const int ta = a ? 8 : -1, tb = b ? 8 : -1;  // tile coordinate of the line
-		const int sa = a ? 0 : 7, sb = b ? 0 : 7;    // source coordinate inside the neighbour leaf
-		int nslot, src, dst;
-		if (grp == 0) {
-			nslot = (da + 1) * 9 + (db + 1) * 3 + 1;
-			src = sa * 64 + sb * 8 + i;
-			dst = T_IDX(ta, tb, i);
-		} else if (grp == 1) {
-			nslot = (da + 1) * 9 + 3 + (db + 1);
-			src = sa * 64 + i * 8 + sb;
-			dst = T_IDX(ta, i, tb);
-		} else {
-			nslot = 9 + (da + 1) * 3 + (db + 1);
-			src = i * 64 + sa * 8 + sb;
-			dst = T_IDX(i, ta, tb);
-		}
-		const int nl = s_nbr[nslot];
-		T[dst] = nl < 0 ? 0.0f : p_in[nl * 512 + src];
-	}
-
-	// halo red site owned by this thread (t < 192): face f, in-face cell (a, b) with a+b+c0 even
-	int hx = 0, hy = 0, hz = 0, hleaf = -1;
-	float hdiv = 0.0f;
-	if (t < 192) {
-		const int f = t >> 5, r = t & 31;
-		const int axis = f >> 1, side = f & 1;
-		const int c0 = side ? 8 : -1;
-		const int a = r >> 2;
-		const int b = 2 * (r & 3) + ((a + (side ? 0 : 1)) & 1);
-		const int cs = side ? 0 : 7;  // coordinate inside the neighbour leaf
-		int src;
-		if (axis == 0) {
-			hx = c0, hy = a, hz = b;
-			src = cs * 64 + a * 8 + b;
-			hleaf = s_nbr[side ? 22 : 4];
-		} else if (axis == 1) {
-			hx = a, hy = c0, hz = b;
-			src = a * 64 + cs * 8 + b;
-			hleaf = s_nbr[side ? 16 : 10];
-		} else {
-			hx = a, hy = b, hz = c0;
-			src = a * 64 + b * 8 + cs;
-			hleaf = s_nbr[side ? 14 : 12];
-		}
-		if (hleaf >= 0) hdiv = div[hleaf * 512 + src];
-	}
-	__syncthreads();  // tile complete
-
-	// ---- phase R: red = (x+y+z) even ----
-	const int zr = 2 * zp + ((x + y) & 1);  // red voxel of the pair
-	const int zb = zr ^ 1;                   // black voxel of the pair
-	const int cr = T_IDX(x, y, zr);
-	const float p_red_old = (zr & 1) ? pown.y : pown.x;
-	const float d_red = (zr & 1) ? down.y : down.x;
-	const float p_red = sor_update(T[cr + 144], T[cr - 144], T[cr + 12], T[cr - 12], T[cr + 1], T[cr - 1], d_red, p_red_old, dx2, omega);
-	float h_new = 0.0f;
-	const int ch = T_IDX(hx, hy, hz);
-	if (hleaf >= 0) h_new = sor_update(T[ch + 144], T[ch - 144], T[ch + 12], T[ch - 12], T[ch + 1], T[ch - 1], hdiv, T[ch], dx2, omega);
-	// red sites only read black sites, so the in-place tile update needs no extra barrier before the writes
-	T[cr] = p_red;
-	if (hleaf >= 0) T[ch] = h_new;
-	__syncthreads();
-
-	// ---- phase B: black = (x+y+z) odd, reads the new reds ----
-	const int cb = T_IDX(x, y, zb);
-	const float p_blk_old = (zb & 1) ? pown.y : pown.x;
-	const float d_blk = (zb & 1) ? down.y : down.x;
-	const float p_blk = sor_update(T[cb + 144], T[cb - 144], T[cb + 12], T[cb - 12], T[cb + 1], T[cb - 1], d_blk, p_blk_old, dx2, omega);
-
-	float2 o;
-	o.x = (zr & 1) ? p_blk : p_red;
-	o.y = (zr & 1) ? p_red : p_blk;
-	reinterpret_cast<float2*>(p_out + leaf * 512)[t] = o;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// red-black SOR, fused form, ONE WAVE PER LEAF (the production kernel)
-// ---------------------------------------------------------------------------------------------------------------
-//
-// Same algorithm and the same per-voxel arithmetic as k_rbgs_fused above, reorganised for the CDNA4 wave: the 64 lanes
+// The wave updates the 256 red voxels of its leaf AND the 6*32 red voxels directly across each face (where that neighbour
+// leaf exists; outside the domain p stays 0) -- a halo red voxel (x=-1,y,z) needs p at (-2,y,z), (0,y,z), (-1,y+-1,z),
+// (-1,y,z+-1): face layers two deep and edge lines, never corners -- then the 256 black voxels from the new reds. The
+// recomputed halo reds see the same inputs as the neighbouring wave's own update, so the result is bit-identical to the
+// two-launch form (k_rbgs_color). Organised for the CDNA4 wave: the 64 lanes
 // of one wave own the 64 z-rows of a leaf (lane = x*8+y, the memory order, so the 2 KB payload is read and written as
 // two 16-byte accesses per lane, fully coalesced) and keep their row in registers. No workgroup barrier exists: the
 // wave's private LDS tile only carries rows between lanes. Work per lane:
@@ -870,16 +743,14 @@ int hns_dev_divergence(hns_grid* g, const float* vel3, float* div, float inv_dx,
 	if (int rc = check_grid(g, "hns_dev_divergence")) return rc;
 	NULLCHK(!vel3 || !div, "hns_dev_divergence");
 	if (g->n_active == 0) return HNS_OK;
-	static const bool block_form = getenv("HNS_STENCIL") && strcmp(getenv("HNS_STENCIL"), "block") == 0;  // A/B switch
-	if (block_form || !g->d_blk)
+	if (options().stencil_block.load() || !g->d_blk)  // option "stencil" = block: A/B switch
 		hipLaunchKernelGGL(k_divergence, dim3((unsigned)g->n_active), dim3(512), 0, (hipStream_t)stream, g->dev(), vel3, div, inv_dx);
 	else
 	{
 		GridDev gd = g->dev();
 		// backwards: advect_vector has just written the velocity front to back, so its tail is what the Infinity Cache holds
-		// (256^3: 74 -> 66 us). HNS_REV=0 walks every kernel forwards.
-		static const bool rv = !(getenv("HNS_REV") && atoi(getenv("HNS_REV")) == 0);
-		gd.rev = rv;
+		// (256^3: 74 -> 66 us). Option "rev" = 0 walks every kernel forwards.
+		gd.rev = options().rev.load();
 		hipLaunchKernelGGL(k_divergence_row, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, vel3, div, inv_dx);
 	}
 	return launch_status("hns_dev_divergence");
@@ -894,25 +765,29 @@ int hns_dev_rbgs_color(hns_grid* g, const float* div, float* p, float dx, float 
 	return launch_status("hns_dev_rbgs_color");
 }
 
-// which form sweeps this grid: the pair kernel, unless a debug mode or the shape of the grid says otherwise
-// Grids of a few hundred leaves cannot fill 256 CUs with one wave per leaf or per pair; the 256-thread-per-leaf form puts
-// four waves on each leaf and wins there (64^3 = 512 leaves: 3.7 vs 4.1 us per sweep; at 128^3 it loses, 8.4 vs 8.0).
-static bool uses_block_form(const hns_grid* g, int mode) { return mode == 1 || (mode == 0 && g->n_active <= 1024); }
-
-static bool uses_pair_form(const hns_grid* g, int mode) {
-	// one leaf per wave is also the better choice for SMALL IRREGULAR grids, which are latency-bound (twice as many, shorter
-	// waves; no half-empty pair waves). Measured on the 3.9k-leaf plume: 9.0 vs 11.9 us per iteration.
-	return !(uses_block_form(g, mode) || mode == 2 || !g->d_pairs || (mode == 0 && g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs));
+// Which form sweeps this grid (option "rbgs"): the pair kernel, unless the option or the shape of the grid says otherwise.
+// One leaf per wave is the better choice for SMALL IRREGULAR grids, which are latency-bound (twice as many, shorter waves;
+// no half-empty pair waves): measured on the 3.9k-leaf plume 9.0 vs 11.9 us per iteration; and for grids of a few hundred
+// leaves, which cannot fill 256 CUs with one wave per pair.
+static int rbgs_form(const hns_grid* g, int opt) {
+	if (opt == kRbgsColor || opt == kRbgsWave) return opt;
+	if (!g->d_pairs) return kRbgsWave;
+	if (opt == kRbgsPair) return kRbgsPair;
+	if (g->n_active <= 1024 || (g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs)) return kRbgsWave;
+	return kRbgsPair;
 }
 
 // one full (red, black) iteration src -> dst. src_is_zero (pair form only): the caller vouches that src is 0 on every
 // leaf (first iteration of a solve) and the kernel skips reading it.
-static void launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* div, const float* src, float* dst, float dx2, float omega, int mode,
-                                  hipStream_t st, bool src_is_zero = false, bool backwards = false) {
+static int launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* div, const float* src, float* dst, float dx2, float omega, int form,
+                                 hipStream_t st, bool src_is_zero = false, bool backwards = false) {
 	const int last = backwards ? (int)g->n_pairs - 1 : -1;
-	if (uses_block_form(g, mode)) {
-		hipLaunchKernelGGL(k_rbgs_fused, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, src, dst, dx2, omega);
-	} else if (!uses_pair_form(g, mode)) {
+	if (form == kRbgsColor) {
+		// the reference's own decomposition, kept as the independent cross-check: copy, then one launch per colour in place
+		HNS_HIP(hipMemcpyAsync(dst, src, sizeof(float) * 512 * (size_t)g->topo.n_leaves, hipMemcpyDeviceToDevice, st));
+		hipLaunchKernelGGL(k_rbgs_color, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, dst, dx2, omega, 0);
+		hipLaunchKernelGGL(k_rbgs_color, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, dst, dx2, omega, 1);
+	} else if (form == kRbgsWave) {
 		hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_active), dim3(64), 0, st, gd, div, src, dst, dx2, omega);
 	} else if (src_is_zero) {
 		hipLaunchKernelGGL(k_rbgs_pair<true>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, src, dst, dx2, omega, last);
@@ -920,6 +795,7 @@ static void launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* d
 		// one launch: the record list holds the z-adjacent pairs and, as {leaf, nbr27, -1, ...}, the leaves that found no partner
 		hipLaunchKernelGGL(k_rbgs_pair<false>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, src, dst, dx2, omega, last);
 	}
+	return HNS_OK;
 }
 
 int hns_dev_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int* result_in_b,
@@ -942,20 +818,19 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 	}
 	const float dx2 = dx * dx;  // Kernel.cu:608
 	const GridDev gd = g->dev();
-	static const int mode_env = !getenv("HNS_RBGS") ? 0
-	                            : (strcmp(getenv("HNS_RBGS"), "block") == 0 ? 1 : (strcmp(getenv("HNS_RBGS"), "wave") == 0 ? 2 : (strcmp(getenv("HNS_RBGS"), "pair") == 0 ? 3 : 0)));
-	if (from_zero && !uses_pair_form(g, mode_env)) {  // the other forms read their input: give them the zeros
+	const int form = rbgs_form(g, options().rbgs.load());
+	if (from_zero && form != kRbgsPair) {  // the other forms read their input: give them the zeros
 		HNS_HIP(hipMemsetAsync(p_a, 0, sizeof(float) * 512 * (size_t)g->topo.n_leaves, (hipStream_t)stream));
 		from_zero = false;
 	}
-	const int mode = mode_env | (from_zero ? 256 : 0);  // graph-cache key: kernel form + whether the first sweep skips p_a
+	const int mode = form | (from_zero ? 256 : 0);  // graph-cache key: kernel form + whether the first sweep skips p_a
 	// Odd sweeps walk the record list backwards: a sweep ends with the tail of p / div in the Infinity Cache and the next one
 	// begins there. Nothing below the cache size, -11 % at 288^3 (287 MB of sweep arrays against 256 MB of cache), -6 % at
-	// 320^3, -1.4 % at 512^3 (profiles/micro/sor_schedule.py). The result does not depend on the order. HNS_ALTERNATE=0: off.
-	static const bool alternate = !(getenv("HNS_ALTERNATE") && atoi(getenv("HNS_ALTERNATE")) == 0);
-	static const bool use_graph = getenv("HNS_GRAPH") && strcmp(getenv("HNS_GRAPH"), "1") == 0;
+	// 320^3, -1.4 % at 512^3 (profiles/micro/sor_schedule.py). The result does not depend on the order. Option "alternate" = 0: off.
+	const bool alternate = options().alternate.load() != 0;
+	const bool use_graph = options().graph.load() != 0;
 
-	// Optional (HNS_GRAPH=1): replay the loop as one hipGraph, captured once per (buffers, parameters) on a private stream
+	// Optional (option "graph" = 1): replay the loop as one hipGraph, captured once per (buffers, parameters) on a private stream
 	// and cached in the grid. Off by default: measured on MI355X the eager loop is never launch-bound (64^3: 4.11 vs
 	// 4.14 us per sweep, 128^3: 8.3 vs 8.2, 256^3: 39.2 vs 39.1 with / without the graph), and stream capture is
 	// fragile when several host threads cook at once (a legacy-stream call in another thread fails while a capture is open).
@@ -976,7 +851,7 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 				float* src = p_a;
 				float* dst = p_b;
 				for (int it = 0; it < iterations; ++it) {
-					launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode_env, cs, from_zero && it == 0, alternate && (it & 1));
+					if (launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, form, cs, from_zero && it == 0, alternate && (it & 1)) != HNS_OK) ok = false;
 					float* tmp = src;
 					src = dst;
 					dst = tmp;
@@ -1008,7 +883,7 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 	float* src = p_a;
 	float* dst = p_b;
 	for (int it = 0; it < iterations; ++it) {
-		launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, mode_env, (hipStream_t)stream, from_zero && it == 0, alternate && (it & 1));
+		if (int rc = launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, form, (hipStream_t)stream, from_zero && it == 0, alternate && (it & 1))) return rc;
 		float* tmp = src;
 		src = dst;
 		dst = tmp;
@@ -1020,24 +895,27 @@ int hns_dev_time_rbgs(hns_grid* g, const float* div, float* p_a, float* p_b, flo
                       void* stream) {
 	if (int rc = check_grid(g, "hns_dev_time_rbgs")) return rc;
 	if (!ms_per_launch || iterations <= 0 || reps <= 0) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dev_time_rbgs: bad arguments");
-	hipEvent_t e0, e1;
-	HNS_HIP(hipEventCreate(&e0));
-	HNS_HIP(hipEventCreate(&e1));
+	struct Events {  // destroyed on every return path
+		hipEvent_t e0 = nullptr, e1 = nullptr;
+		~Events() {
+			if (e0) (void)hipEventDestroy(e0);
+			if (e1) (void)hipEventDestroy(e1);
+		}
+	} ev;
+	HNS_HIP(hipEventCreate(&ev.e0));
+	HNS_HIP(hipEventCreate(&ev.e1));
 	double total = 0.0;
-	int rc = HNS_OK;
-	for (int r = 0; r < reps && rc == HNS_OK; ++r) {
-		HNS_HIP(hipEventRecord(e0, (hipStream_t)stream));
-		rc = hns_dev_rbgs_iterate(g, div, p_a, p_b, dx, omega, iterations, nullptr, stream);
-		HNS_HIP(hipEventRecord(e1, (hipStream_t)stream));
-		HNS_HIP(hipEventSynchronize(e1));
+	for (int r = 0; r < reps; ++r) {
+		HNS_HIP(hipEventRecord(ev.e0, (hipStream_t)stream));
+		if (int rc = hns_dev_rbgs_iterate(g, div, p_a, p_b, dx, omega, iterations, nullptr, stream)) return rc;
+		HNS_HIP(hipEventRecord(ev.e1, (hipStream_t)stream));
+		HNS_HIP(hipEventSynchronize(ev.e1));
 		float ms = 0.0f;
-		HNS_HIP(hipEventElapsedTime(&ms, e0, e1));
+		HNS_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
 		total += ms;
 	}
-	(void)hipEventDestroy(e0);
-	(void)hipEventDestroy(e1);
 	*ms_per_launch = (float)(total / ((double)reps * iterations));
-	return rc;
+	return HNS_OK;
 }
 
 int hns_dev_subtract_pressure_gradient(hns_grid* g, const float* vel3, const float* p, float* out3, const float* sdf, int has_collision, float inv_dx,
@@ -1049,7 +927,7 @@ int hns_dev_subtract_pressure_gradient(hns_grid* g, const float* vel3, const flo
 	// (a wave-per-leaf row form like k_divergence_row was measured for this kernel too: 118 us vs 111 us at 256^3 -- not kept)
 	// (also measured and not kept for this kernel: the six taps through an LDS tile as in the advection kernels, 125 vs 116 us --
 	// at 470 MB per launch it streams from HBM and the extra barrier costs more than the loads it saves)
-	static const bool block_form = getenv("HNS_STENCIL") && strcmp(getenv("HNS_STENCIL"), "block") == 0;  // A/B switch
+	const bool block_form = options().stencil_block.load() != 0;  // option "stencil" = block: A/B switch
 	if (has_collision && sdf)
 		hipLaunchKernelGGL(k_subtract_gradient<true>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, p, out3, sdf, inv_dx);
 	else if (block_form || !g->d_blk)

@@ -6,6 +6,7 @@
 // (src/Utils/GridBuilder.hpp:156-166,229), so the only information in that tree is "which 8^3 leaves exist and in
 // which order". This file keeps exactly that: a leaf-origin table in the caller's order, a 27-neighbour table per
 // leaf and an origin hash, so a tap costs one table read instead of three dependent node loads.
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -22,6 +23,11 @@ void set_error(const char* fmt, ...) {
 	vsnprintf(buf, sizeof(buf), fmt, ap);
 	va_end(ap);
 	g_last_error = buf;
+}
+
+Options& options() {
+	static Options o;
+	return o;
 }
 
 uint32_t hash_origin(int32_t x, int32_t y, int32_t z) {
@@ -119,6 +125,71 @@ extern "C" {
 
 const char* hns_last_error(void) { return g_last_error.c_str(); }
 int hns_version(void) { return HNS_VERSION; }
+
+namespace {
+struct OptionDesc {
+	const char* name;
+	std::atomic<int> Options::*field;
+	const char* const* words;  // value words, index = stored value; nullptr: a non-negative integer
+};
+const char* const kWordsRbgs[] = {"auto", "color", "wave", "pair", "resident", nullptr};
+const char* const kWordsAdvect[] = {"auto", "generic", nullptr};
+const char* const kWordsStencil[] = {"auto", "block", nullptr};
+const char* const kWordsSchedule[] = {"auto", "linear", "chunk", nullptr};
+const char* const kWordsBool[] = {"0", "1", nullptr};
+const OptionDesc kOptions[] = {
+    {"rbgs", &Options::rbgs, kWordsRbgs},
+    {"advect", &Options::advect_generic, kWordsAdvect},
+    {"stencil", &Options::stencil_block, kWordsStencil},
+    {"schedule", &Options::schedule, kWordsSchedule},
+    {"alternate", &Options::alternate, kWordsBool},
+    {"rev", &Options::rev, kWordsBool},
+    {"graph", &Options::graph, kWordsBool},
+    {"cook_cache", &Options::cook_cache, kWordsBool},
+    {"cook_pipeline", &Options::cook_pipeline, kWordsBool},
+    {"sor_block", &Options::sor_block, nullptr},
+};
+const Options kDefaults;
+}  // namespace
+
+int hns_set_option(const char* name, const char* value) {
+	if (!name) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_set_option: null name");
+	for (const OptionDesc& d : kOptions) {
+		if (strcmp(d.name, name) != 0) continue;
+		if (!value) {  // back to the default
+			(options().*d.field).store((kDefaults.*d.field).load());
+			return HNS_OK;
+		}
+		if (!d.words) {
+			char* end = nullptr;
+			const long v = strtol(value, &end, 10);
+			if (end == value || *end || v < 0 || v > 1 << 20) break;
+			(options().*d.field).store((int)v);
+			return HNS_OK;
+		}
+		for (int i = 0; d.words[i]; ++i)
+			if (strcmp(d.words[i], value) == 0) {
+				(options().*d.field).store(i);
+				return HNS_OK;
+			}
+		break;
+	}
+	set_error("hns_set_option: unknown option or value: %s = %s", name, value ? value : "(default)");
+	return HNS_ERR_INVALID_ARGUMENT;
+}
+
+const char* hns_get_option(const char* name) {
+	static thread_local char buf[16];
+	if (!name) return nullptr;
+	for (const OptionDesc& d : kOptions) {
+		if (strcmp(d.name, name) != 0) continue;
+		const int v = (options().*d.field).load();
+		if (d.words) return d.words[v];
+		snprintf(buf, sizeof(buf), "%d", v);
+		return buf;
+	}
+	return nullptr;
+}
 
 static hns_grid* grid_from_origins(const int32_t* origins, uint64_t n_leaves, float voxel_size, unsigned flags, int* err) {
 	int rc = HNS_OK;

@@ -52,9 +52,26 @@ extern "C" {
 const char* hns_last_error(void);
 int hns_version(void);
 int hns_device_count(void); /* 0 when no HIP device is visible; never initialises a device context */
-/* Device memory of destroyed simulation state is kept in a small process-wide pool (at most three allocations) so that the
- * next cook, typically on a slightly different topology, does not pay hipMalloc/hipFree again; this returns it to the driver. */
+/* Device memory of destroyed simulation state and grid tables is kept in a small process-wide pool (at most six idle
+ * allocations; the device is idle when memory enters it) so that the next cook, typically on a slightly different
+ * topology, does not pay hipMalloc/hipFree again; this returns it to the driver. */
 int hns_trim_memory(void);
+/* Alternative kernel forms and data-movement strategies, kept for A/B measurement and as cross-checks of the default ones
+ * (all of them produce the same bits; tests/test_kernel_variants_gpu.py). Process-wide, read by every entry point when it
+ * is called. value = NULL restores the default. Names and values:
+ *   "rbgs"          auto | color (two launches per iteration) | wave (one wave per leaf) | pair (one wave per z-adjacent leaf
+ *                   pair) | resident (whole pressure loop in one launch, small grids)
+ *   "advect"        auto | generic (64-bit addressed advection kernels)
+ *   "stencil"       auto | block (512-thread divergence and gradient kernels)
+ *   "schedule"      auto | linear | chunk (workgroup -> leaf order; takes effect when a grid's launch tables are next built)
+ *   "alternate"     1 | 0 (odd SOR sweeps walk the wave records backwards)
+ *   "rev"           1 | 0 (divergence and advect_scalars walk the leaves backwards)
+ *   "graph"         0 | 1 (replay the pressure loop as a hipGraph)
+ *   "cook_cache"    1 | 0 (operator calls keep their device buffers with the grid)
+ *   "cook_pipeline" 1 | 0 (hns_compute_sim overlaps its transfers with the substep)
+ *   "sor_block"     0 = auto | N leaf pairs per workgroup of the SOR kernel */
+int hns_set_option(const char* name, const char* value);
+const char* hns_get_option(const char* name); /* current value as a word; NULL for an unknown name */
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Index grid (topology)                                                                                         */

@@ -1,6 +1,6 @@
-"""Every alternative kernel form kept in the library behind an environment switch must produce the same bits as the
-default one. The switches are read once per process, so each variant runs in a child process: a full Compute_Sim
-(collision off and on, vorticity on) plus the single-purpose operators on two grids, results compared array by array."""
+"""Every alternative kernel form kept in the library behind hns_set_option() must produce the same bits as the default
+one: a full Compute_Sim (collision off and on, vorticity on) plus the single-purpose operators on three grids, results
+compared array by array. Options are read per call, so the variants run in this process, one after the other."""
 import os
 import subprocess
 import sys
@@ -8,78 +8,101 @@ import sys
 import numpy as np
 import pytest
 
+import hnanosolver_amd as H
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-CHILD = r"""
-import sys, numpy as np
-sys.path.insert(0, sys.argv[2]); sys.path.insert(0, sys.argv[2] + "/tests")
-from hnanosolver_amd import api, fields
-from test_operators_gpu import build_data, snapshot
-out = {}
-rng = np.random.default_rng(77)
-lat = np.stack(np.meshgrid(*[np.arange(-5, 5)] * 3, indexing="ij"), -1).reshape(-1, 3)
-scat = (lat[rng.random(len(lat)) < 0.45] * 8).astype(np.int32)
-scat = np.ascontiguousarray(scat[fields.nanovdb_order(scat)])   # ragged z-runs, lone leaves, negative coordinates
-for gname, origins, R in (("dense32", fields.dense_leaves(32), 32), ("plume", fields.plume_leaves(8, 1.0, 0.3), 64), ("scattered", scat, 80)):
-    vs = 1.0 / R
-    for coll in (False, True):
-        d = build_data(origins, R, with_sdf=coll, amplitude=160.0)
-        h = api.IndexGridHandle()
-        api.CreateIndexGrid(d, h, vs)
-        api.Compute_Sim(d, h, 9, 1.0 / 24.0, vs, api.CombustionParams(factorScale=1.0), coll)
+
+def run_workload():
+    from hnanosolver_amd import api, fields
+    from test_operators_gpu import build_data, snapshot
+
+    out = {}
+    rng = np.random.default_rng(77)
+    lat = np.stack(np.meshgrid(*[np.arange(-5, 5)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    scat = (lat[rng.random(len(lat)) < 0.45] * 8).astype(np.int32)
+    scat = np.ascontiguousarray(scat[fields.nanovdb_order(scat)])  # ragged z-runs, lone leaves, negative coordinates
+    for gname, origins, R in (("dense32", fields.dense_leaves(32), 32), ("plume", fields.plume_leaves(8, 1.0, 0.3), 64), ("scattered", scat, 80)):
+        vs = 1.0 / R
+        for coll in (False, True):
+            d = build_data(origins, R, with_sdf=coll, amplitude=160.0)
+            h = api.IndexGridHandle()
+            api.CreateIndexGrid(d, h, vs)
+            api.Compute_Sim(d, h, 9, 1.0 / 24.0, vs, api.CombustionParams(factorScale=1.0), coll)
+            for n, v in snapshot(d).items():
+                out[f"{gname}/sim{int(coll)}/{n}"] = v
+            h.reset()
+        d = build_data(origins, R, amplitude=400.0)  # long backtraces: far taps through the hash
+        api.AdvectIndexGrid(d, 1.0 / 24.0, vs)
+        api.AdvectIndexGridVelocity(d, 1.0 / 24.0, vs)
+        api.ProjectNonDivergent(d, 7, vs)
         for n, v in snapshot(d).items():
-            out[f"{gname}/sim{int(coll)}/{n}"] = v
-        h.reset()
-    d = build_data(origins, R, amplitude=400.0)  # long backtraces: far taps through the hash
-    api.AdvectIndexGrid(d, 1.0 / 24.0, vs)
-    api.AdvectIndexGridVelocity(d, 1.0 / 24.0, vs)
-    api.ProjectNonDivergent(d, 7, vs)
-    for n, v in snapshot(d).items():
-        out[f"{gname}/ops/{n}"] = v
-np.savez(sys.argv[1], **out)
-"""
+            out[f"{gname}/ops/{n}"] = v
+    return out
+
 
 VARIANTS = {
-    "advect_64bit": {"HNS_ADVECT": "generic"},
-    "sor_wave_per_leaf": {"HNS_RBGS": "wave"},
-    "sor_wave_per_leaf_pair": {"HNS_RBGS": "pair"},  # the production form at scale; small grids default to the block form
-    "sor_block_per_leaf": {"HNS_RBGS": "block"},
-    "sor_graph_replay": {"HNS_GRAPH": "1"},
-    "schedule_linear": {"HNS_SCHEDULE": "linear"},
-    "sor_one_direction": {"HNS_ALTERNATE": "0", "HNS_RBGS": "pair"},
-    "all_kernels_forwards": {"HNS_REV": "0"},
-    "divergence_block": {"HNS_STENCIL": "block"},
-    "cook_unpipelined_uncached": {"HNS_COOK_PIPELINE": "0", "HNS_COOK_CACHE": "0"},
+    "advect_64bit": {"advect": "generic"},
+    "sor_two_launches_per_iteration": {"rbgs": "color"},  # the reference's own decomposition
+    "sor_wave_per_leaf": {"rbgs": "wave"},
+    "sor_wave_per_leaf_pair": {"rbgs": "pair"},  # the production form at scale; small grids default to one wave per leaf
+    "sor_resident": {"rbgs": "resident"},  # whole pressure loop in one launch
+    "sor_graph_replay": {"graph": "1"},
+    "schedule_linear": {"schedule": "linear"},
+    "sor_one_direction": {"alternate": "0", "rbgs": "pair"},
+    "all_kernels_forwards": {"rev": "0"},
+    "divergence_block": {"stencil": "block"},
+    "cook_unpipelined_uncached": {"cook_pipeline": "0", "cook_cache": "0"},
 }
+ALL_OPTIONS = sorted({k for v in VARIANTS.values() for k in v})
 
 
-def run_child(path, extra_env):
-    env = {k: v for k, v in os.environ.items() if not k.startswith("HNS_")}
-    env.update(extra_env)
-    r = subprocess.run([sys.executable, "-c", CHILD, path, ROOT], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    return dict(np.load(path))
+@pytest.fixture()
+def options():
+    """set options for one test, defaults restored afterwards"""
+
+    def apply(d):
+        for k, v in d.items():
+            H.set_option(k, v)
+            assert H.get_option(k) == v
+
+    yield apply
+    for k in ALL_OPTIONS:
+        H.set_option(k, None)
 
 
 @pytest.fixture(scope="module")
-def default_outputs(tmp_path_factory):
-    return run_child(str(tmp_path_factory.mktemp("variants") / "default.npz"), {})
+def default_outputs():
+    for k in ALL_OPTIONS:
+        H.set_option(k, None)
+    return run_workload()
 
 
 @pytest.mark.parametrize("name", list(VARIANTS))
-def test_variant_is_bit_identical(name, default_outputs, tmp_path):
-    got = run_child(str(tmp_path / "v.npz"), VARIANTS[name])
+def test_variant_is_bit_identical(name, default_outputs, options):
+    options(VARIANTS[name])
+    got = run_workload()
     assert got.keys() == default_outputs.keys()
     for k in default_outputs:
         assert np.array_equal(got[k], default_outputs[k]), (name, k)
 
 
+def test_unknown_option_is_refused():
+    with pytest.raises(H.HNSError):
+        H.set_option("rbgs", "no-such-form")
+    with pytest.raises(H.HNSError):
+        H.set_option("no-such-option", "1")
+    assert H.get_option("no-such-option") is None
+
+
 BIG_CHILD = r"""
 import sys, json, numpy as np, torch
 sys.path.insert(0, sys.argv[2])
+import hnanosolver_amd as H
 from hnanosolver_amd import api, device as D, fields
+if len(sys.argv) > 3: H.set_option("advect", sys.argv[3])
 R = 576                                   # 72^3 leaves, 191 M voxels: a Vec3f field of 2.29 GB, byte offsets beyond 2^31
 origins = fields.dense_leaves(R)
 grid = api.create_grid_from_leaves(origins, 1.0 / R)
@@ -118,11 +141,9 @@ def test_byte_offsets_beyond_2_gib_match_the_64_bit_kernels(tmp_path):
     import json
 
     res = []
-    for name, extra in (("narrow", {}), ("generic", {"HNS_ADVECT": "generic"})):
-        env = {k: v for k, v in os.environ.items() if not k.startswith("HNS_")}
-        env.update(extra)
+    for name in ("auto", "generic"):  # child processes: each holds 10+ GB of device memory
         path = str(tmp_path / f"{name}.json")
-        r = subprocess.run([sys.executable, "-c", BIG_CHILD, path, ROOT], env=env, capture_output=True, text=True, timeout=900)
+        r = subprocess.run([sys.executable, "-c", BIG_CHILD, path, ROOT, name], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(json.load(open(path)))
     assert res[0] == res[1]

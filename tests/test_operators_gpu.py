@@ -271,20 +271,25 @@ def test_cook_cache_is_invisible():
     h.reset()
 
 
-def test_cook_cache_disabled_matches(monkeypatch):
+def test_cook_cache_disabled_matches():
+    import hnanosolver_amd as H
+
     origins, R = fields.dense_leaves(32), 32
     vs = 1.0 / R
     p = api.CombustionParams()
     outs = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("HNS_COOK_CACHE", flag)
-        h = api.IndexGridHandle()
-        d = build_data(origins, R)
-        api.CreateIndexGrid(d, h, vs)
-        api.Compute_Sim(d, h, 8, 1.0 / 24.0, vs, p, False)
-        api.Compute_Sim(d, h, 8, 1.0 / 24.0, vs, p, False)  # second cook feeds on the first one's output
-        outs.append(snapshot(d))
-        h.reset()
+        H.set_option("cook_cache", flag)
+        try:
+            h = api.IndexGridHandle()
+            d = build_data(origins, R)
+            api.CreateIndexGrid(d, h, vs)
+            api.Compute_Sim(d, h, 8, 1.0 / 24.0, vs, p, False)
+            api.Compute_Sim(d, h, 8, 1.0 / 24.0, vs, p, False)  # second cook feeds on the first one's output
+            outs.append(snapshot(d))
+            h.reset()
+        finally:
+            H.set_option("cook_cache", None)
     for n in outs[0]:
         assert np.array_equal(outs[0][n], outs[1][n]), n
 
