@@ -5,6 +5,8 @@ configs[1] 128^3 dense, 50 iterations: whole Compute_Sim cook vs the oracle.
 configs[2] 256^3 dense, 50 iterations: the metric's core substep vs the oracle, and the fused SOR kernel vs the
            independent two-launch kernel (bit-identical), linearity in the right-hand side, zero-velocity idempotence.
 configs[3] sparse plume (~3.9k leaves): whole Compute_Sim cook vs the oracle; translation invariance of the projection.
+configs[4] 1024^3-extent sparse plume (65,944 leaves, 33.8 M voxels): the metric's core substep vs the oracle on one device;
+           the same domain split into 8 leaf ranges (the 8-GPU decomposition, emulated on one device) is in test_dist_gpu.py.
 """
 import numpy as np
 import pytest
@@ -55,11 +57,47 @@ def test_compute_sim_full_size_vs_oracle(config):
         assert np.array_equal(d.pValues(n), want[n]), f"{config}: field {n} not bit-identical (rel {r:.3e})"
 
 
+def oracle_core_substep(origins, f, vs, dt, iters):
+    """The metric's core substep through the oracle: (velocity, density, pressure, divergence)."""
+    from oracle_lib import OracleGrid, oracle
+
+    G = OracleGrid(origins)
+    inv_dx = float(np.float32(1.0) / np.float32(vs))
+    omega = float(oracle().orc_omega_compute(vs))
+    adv = G.advect_vector(f["vel"], dt, inv_dx)
+    div = G.divergence(adv, inv_dx)
+    p = G.rbgs_iterations(div, float(np.float32(vs)), omega, iters)
+    u = G.subtract_pressure_gradient(adv, p, inv_dx)
+    phi = G.advect_scalars(u, [f["density"]], dt, inv_dx)[0]
+    return u, phi, p, div
+
+
+def test_core_substep_plume1024_vs_oracle():
+    """BASELINE.json configs[4] on ONE device: the 1024^3-extent sparse plume (65,944 leaves), 50 iterations, HIP vs oracle
+    bit for bit. (The sweep arrays, 405 MB, do not fit the Infinity Cache: this is the HBM regime of the SOR kernel, and the
+    leaf count puts every kernel on its large-grid launch order.)"""
+    from hnanosolver_amd import device as D
+
+    origins, R = fields.config_leaves("plume1024")
+    assert abs(len(origins) - 65536) <= 0.05 * 65536  # SURVEY 8d: 65,536 +- 5 %
+    vs, dt, iters = 1.0 / R, 1.0 / 24.0, 50
+    f = fields.synthetic_fields(origins, R)
+    grid = api.create_grid_from_leaves(origins, vs)
+    sim = D.Sim(grid, ["density"])
+    got = {"vel": f["vel"].copy(), "density": f["density"].copy()}
+    sim.upload(got)
+    sim.core_substep(iters, dt, vs, D.current_stream())
+    sim.download(got)
+    u, phi, _, _ = oracle_core_substep(origins, f, vs, dt, iters)
+    assert rel_linf(got["vel"], u) <= TOL and rel_linf(got["density"], phi) <= TOL
+    assert np.array_equal(got["vel"], u) and np.array_equal(got["density"], phi)
+
+
 def test_core_substep_256_vs_oracle_and_properties():
     import torch
 
     from hnanosolver_amd import device as D
-    from oracle_lib import OracleGrid, oracle
+    from oracle_lib import oracle
 
     origins, R = fields.config_leaves("256")
     vs, dt, iters = 1.0 / R, 1.0 / 24.0, 50
@@ -71,14 +109,9 @@ def test_core_substep_256_vs_oracle_and_properties():
     sim.core_substep(iters, dt, vs, D.current_stream())
     sim.download(got)
 
-    G = OracleGrid(origins)
     inv_dx = float(np.float32(1.0) / np.float32(vs))
     omega = float(oracle().orc_omega_compute(vs))
-    adv = G.advect_vector(f["vel"], dt, inv_dx)
-    div = G.divergence(adv, inv_dx)
-    p = G.rbgs_iterations(div, float(np.float32(vs)), omega, iters)
-    u = G.subtract_pressure_gradient(adv, p, inv_dx)
-    phi = G.advect_scalars(u, [f["density"]], dt, inv_dx)[0]
+    u, phi, p, div = oracle_core_substep(origins, f, vs, dt, iters)
     assert rel_linf(got["vel"], u) <= TOL and rel_linf(got["density"], phi) <= TOL
     assert np.array_equal(got["vel"], u) and np.array_equal(got["density"], phi)
 
