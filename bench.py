@@ -16,13 +16,17 @@ leaves of u / p / phi over RCCL each time the reference would have a global kern
 
 Rank 0 prints ONE JSON line. `roofline`: dominant kernel k_rbgs_pair, algorithmic 12 B/voxel per launch (read p, read
 div, write p once each), launch time from hipEvents recorded on the launch stream around the pressure loop of every
-timed step; `traffic` = PMC-derived HBM bytes per launch from the committed profile of this same command
-(profiles/pmc_latest.json; bench.py cannot run rocprofv3 on itself). `cpu_baseline`: the oracle (C restatement of the reference kernels, OpenMP over leaves) on the host cores,
-rank 0 at N=1 only, on a bounded sample.
+timed step. `roofline.kernels` carries the same figures for all five kernels of the substep (each bracketed by hipEvents
+on the launch stream) and `roofline.substep` the whole substep against 688 B/voxel. `traffic` is NOT measured by this
+run (bench.py cannot run rocprofv3 on itself): it is the PMC-derived HBM bytes per launch from the builder's committed
+rocprofv3 profile of this same command (profiles/pmc_latest.json), reported only while that profile was taken from the
+kernel source this library was built from, and labelled with `traffic_source`. `cpu_baseline`: the oracle (C restatement
+of the reference kernels, OpenMP over leaves) on the host cores, rank 0 at N=1 only, on a bounded sample.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -36,6 +40,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 BYTES_PER_VOXEL_ITER = 12  # RB-SOR per iteration reads p, reads div, writes p once each
 BYTES_PER_VOXEL_SUBSTEP = 688  # advect_vector 24 + divergence 16 + 50*12 + gradient 28 + advect_scalars(S=1) 20
+# SURVEY.md 8d, algorithmic bytes per voxel of each stage of the core substep (pressure: per iteration)
+STAGE_BYTES = {"advect_vector": 24, "divergence": 16, "pressure": BYTES_PER_VOXEL_ITER, "gradient": 28, "advect_scalars": 20}
+STAGE_KERNEL = {"advect_vector": "k_advect_vector_n", "divergence": "k_divergence_row", "pressure": "k_rbgs_pair", "gradient": "k_subtract_gradient_s",
+                "advect_scalars": "k_advect_scalars_n"}
+
+
+def kernel_source_sha16():
+    """Identifies the kernel source a PMC profile belongs to (profiles/pmc_latest.json carries the same stamp)."""
+    h = hashlib.sha256()
+    for f in ("hns_pressure.hip", "hns_device.hpp", "hns_internal.hpp"):
+        h.update(open(os.path.join(ROOT, "hnanosolver_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -131,8 +147,9 @@ def cpu_baseline(origins, R, iterations, budget_s=25.0):
         "unit": "substeps/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"oracle core substep on the same {G.N}-voxel grid: advect_vector+divergence+gradient+advect_scalars(S=1) timed once "
-                  f"({t_pre + t_post:.2f} s), {it_s} of {iterations} RB-SOR iterations timed ({t_it:.2f} s) and scaled linearly",
+        # no parentheses in this string: the driver's record parser cuts it at the first one
+        "sample": f"oracle core substep on the same {G.N}-voxel grid: advect_vector + divergence + gradient + advect_scalars S=1 timed once in "
+                  f"{t_pre + t_post:.2f} s, then {it_s} of {iterations} RB-SOR iterations timed in {t_it:.2f} s and scaled linearly",
     }
 
 
@@ -145,8 +162,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE is {world}: launch N>1 with torch.distributed.run --nproc-per-node N")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -177,6 +193,9 @@ def main():
 
         def pressure_time():
             return sim.pressure_time()
+
+        def stage_times():
+            return sim.stage_times()
     else:
         from hnanosolver_amd import dist as HD
 
@@ -184,6 +203,7 @@ def main():
         if args.partition:
             n_vox_rank = runner.plan.n_owned * 512
         step, timing_on, pressure_time = runner.step, runner.timing_on, runner.pressure_time
+        stage_times = getattr(runner, "stage_times", None)
 
     for _ in range(args.warmup):
         step()
@@ -206,20 +226,32 @@ def main():
         elapsed = float(t.item())
 
     p_ms, launches = pressure_time()
+    stages, n_sub = stage_times() if stage_times else ({}, 0)
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = (1 if args.partition and world > 1 else world) * args.steps / elapsed  # slab-substeps/s over all ranks (partitioned: substeps/s of the one domain)
         ms_launch = p_ms / max(1, launches)
         achieved = BYTES_PER_VOXEL_ITER * n_vox_rank / (ms_launch * 1e-3) / 1e9 if launches else None
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and world == 1:
             try:
                 j = json.load(open(pmc))
-                if j.get("config") == args.config and j.get("kernel") == "k_rbgs_pair":
+                if j.get("config") == args.config and j.get("kernel") == "k_rbgs_pair" and j.get("kernel_source_sha16") == kernel_source_sha16():
                     traffic = j.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/pmc_latest.json: builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on this kernel source; not measured by this run"
             except Exception:
                 traffic = None
+        kernels = {}
+        if n_sub:
+            for st, ms in stages.items():
+                per = ms / n_sub / (args.iterations if st == "pressure" else 1)  # ms per launch
+                alg = STAGE_BYTES[st] * n_vox_rank
+                gbs = alg / (per * 1e-3) / 1e9 if per > 0 else None
+                kernels[STAGE_KERNEL[st]] = {"stage": st, "ms_per_launch": per, "launches_per_substep": args.iterations if st == "pressure" else 1,
+                                             "algorithmic_bytes_per_launch": alg, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS if gbs else None}
+        sub_bytes = (BYTES_PER_VOXEL_SUBSTEP - 600 + 12 * args.iterations) * n_vox_rank
+        sub_gbs = sub_bytes / (ms_per_step * 1e-3) / 1e9
         out = {
             "metric": "solver substeps/sec (advect + 50 red-black SOR iterations + project) at N active voxels",
             "value": value,
@@ -236,7 +268,7 @@ def main():
             "config": {
                 "workload": f"{args.config}^3 dense-active grid" if args.config.isdigit() else args.config,
                 "active_voxels_per_gpu": n_vox_rank,
-                "leaves_per_gpu": len(origins),
+                "leaves_per_gpu": len(origins) if not (args.partition and world > 1) else n_vox_rank // 512,
                 "pressure_iterations": args.iterations,
                 "substep": "advect_vector + divergence + RB-SOR + gradient subtraction + advect_scalars(S=1)",
                 "algorithmic_bytes_per_voxel_substep": BYTES_PER_VOXEL_SUBSTEP - 600 + 12 * args.iterations,
@@ -244,16 +276,20 @@ def main():
                                                                 else f"x-slab leaf partition over {world} GPUs, RCCL halo exchange"),
             },
             "roofline": {
-                "kernel": "k_rbgs_pair (one launch = one full red+black SOR iteration over all leaves)",
+                "kernel": "k_rbgs_pair (one launch = one full red+black SOR iteration over all leaves)" if world == 1 else
+                          "pressure loop of rank 0 INCLUDING its halo exchanges (comm-inclusive; the kernel alone is the N=1 figure)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": BYTES_PER_VOXEL_ITER * n_vox_rank,
                 "ms_per_launch": ms_launch,
                 "launches_timed": launches,
+                "kernels": kernels,
+                "substep": {"algorithmic_bytes": sub_bytes, "ms": ms_per_step, "achieved": sub_gbs, "frac": sub_gbs / HBM_PEAK_GBS},
             },
         }
         if world == 1 and not args.no_cpu_baseline:

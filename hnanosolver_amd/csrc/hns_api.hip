@@ -73,6 +73,8 @@ struct hns_sim {
 	std::vector<hipEvent_t> ev;  // start/stop pairs
 	size_t ev_used = 0;
 	long long timed_launches = 0;
+	std::vector<hipEvent_t> sev;  // stage boundaries of hns_sim_core_substep while timing is on: six per substep
+	size_t sev_used = 0;
 	hipStream_t xfer = nullptr;  // transfer stream + hand-off events of the pipelined operator path (compute_sim_pipelined)
 	hipEvent_t xev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 	bool cached = false, in_use = false;  // owned by the grid's cook cache / currently lent to an operator call
@@ -191,6 +193,7 @@ extern "C" int hns_trim_memory(void) {
 extern "C" void hns_sim_destroy(hns_sim* s) {
 	if (!s) return;
 	for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
+	for (hipEvent_t e : s->sev) (void)hipEventDestroy(e);
 	for (hipEvent_t e : s->xev)
 		if (e) (void)hipEventDestroy(e);
 	if (s->xfer) (void)hipStreamDestroy(s->xfer);
@@ -386,9 +389,33 @@ extern "C" int hns_sim_timing(hns_sim* s, int max_solves) {
 		HNS_HIP(hipEventCreate(&e));
 		s->ev.push_back(e);
 	}
+	while (s->sev.size() < (size_t)max_solves * 6) {
+		hipEvent_t e;
+		HNS_HIP(hipEventCreate(&e));
+		s->sev.push_back(e);
+	}
 	s->timing = max_solves > 0;
 	s->ev_used = 0;
+	s->sev_used = 0;
 	s->timed_launches = 0;
+	return HNS_OK;
+}
+
+// Per-stage device time of the core substeps run since hns_sim_timing(): ms5 = {advect_vector, divergence, pressure loop,
+// gradient subtraction, advect_scalars}, summed over `*substeps` substeps; events sit on the launch stream.
+extern "C" int hns_sim_stage_times(hns_sim* s, float* ms5, long long* substeps) {
+	if (!s || !ms5 || !substeps) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_sim_stage_times: null argument");
+	double tot[5] = {0, 0, 0, 0, 0};
+	for (size_t i = 0; i + 5 < s->sev_used; i += 6) {
+		HNS_HIP(hipEventSynchronize(s->sev[i + 5]));
+		for (int k = 0; k < 5; ++k) {
+			float ms = 0.0f;
+			HNS_HIP(hipEventElapsedTime(&ms, s->sev[i + k], s->sev[i + k + 1]));
+			tot[k] += ms;
+		}
+	}
+	for (int k = 0; k < 5; ++k) ms5[k] = (float)tot[k];
+	*substeps = (long long)(s->sev_used / 6);
 	return HNS_OK;
 }
 
@@ -526,12 +553,24 @@ extern "C" int hns_sim_core_substep(hns_sim* s, int iterations, float dt, float 
 	if (s->n == 0) return HNS_OK;
 	const float inv_dx = 1.0f / voxel_size;
 	hns_grid* g = s->grid;
+	const bool staged = s->timing && s->sev_used + 6 <= s->sev.size();
+	hipEvent_t* se = staged ? &s->sev[s->sev_used] : nullptr;
+	if (staged) HNS_HIP(hipEventRecord(se[0], (hipStream_t)stream));
 	HNS_TRY(hns_dev_advect_vector(g, s->vel, s->adv, nullptr, 0, dt, inv_dx, stream));
+	if (staged) HNS_HIP(hipEventRecord(se[1], (hipStream_t)stream));
 	HNS_TRY(hns_dev_divergence(g, s->adv, s->div, inv_dx, stream));
+	if (staged) HNS_HIP(hipEventRecord(se[2], (hipStream_t)stream));
 	HNS_TRY(sim_pressure(s, iterations, voxel_size, omega_compute(voxel_size), stream));
+	if (staged) HNS_HIP(hipEventRecord(se[3], (hipStream_t)stream));
 	HNS_TRY(hns_dev_subtract_pressure_gradient(g, s->adv, s->p_result, s->vel, nullptr, 0,
 	                                           inv_dx, stream));
-	return sim_advect_scalars(s, nullptr, false, dt, inv_dx, stream);
+	if (staged) HNS_HIP(hipEventRecord(se[4], (hipStream_t)stream));
+	HNS_TRY(sim_advect_scalars(s, nullptr, false, dt, inv_dx, stream));
+	if (staged) {
+		HNS_HIP(hipEventRecord(se[5], (hipStream_t)stream));
+		s->sev_used += 6;
+	}
+	return HNS_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -167,6 +167,12 @@ class Sim:
         _raise(lib.hns_sim_pressure_time(self._ptr, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
+    def stage_times(self):
+        """({stage: total ms} over the core substeps timed since timing(), number of substeps)"""
+        ms, n = (C.c_float * 5)(), C.c_longlong(0)
+        _raise(lib.hns_sim_stage_times(self._ptr, ms, C.byref(n)))
+        return dict(zip(("advect_vector", "divergence", "pressure", "gradient", "advect_scalars"), [float(x) for x in ms])), int(n.value)
+
     def close(self) -> None:
         if self._ptr:
             lib.hns_sim_destroy(self._ptr)

@@ -25,12 +25,14 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TA_TA_BUSY_sum 
 done
 python3 $root/profiles/summarize_pmc.py $out/pmc.json $dirs > $out/pmc_summary.txt
 python3 - "$out" <<'PY'
-import json, sys
+import json, sys, os
 out = sys.argv[1]
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+from bench import kernel_source_sha16
 p = json.load(open(out + "/pmc.json"))
 k = p.get("hns::k_rbgs_pair<false>") or p["hns::k_rbgs_pair"]
 fetch_kb, write_kb = k["FETCH_SIZE"]["mean"], k["WRITE_SIZE"]["mean"]
-j = {"config": "256", "kernel": "k_rbgs_pair", "hbm_bytes_per_launch": 1024.0 * (2.0 * fetch_kb + write_kb), "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
+j = {"config": "256", "kernel": "k_rbgs_pair", "kernel_source_sha16": kernel_source_sha16(), "hbm_bytes_per_launch": 1024.0 * (2.0 * fetch_kb + write_kb), "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
      "correction": "FETCH_SIZE x2 (gfx950: reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported (= 4 B/voxel exactly)",
      "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 3 --warmup 1 (profiles/collect.sh)",
      "algorithmic_bytes_per_launch": 201326592}
