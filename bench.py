@@ -11,8 +11,8 @@ are the closed-form synthetic fields of hnanosolver_amd.fields, already resident
 N = 1: the workload is BASELINE.json's roofline configuration, the 256^3 dense-active grid (16,777,216 voxels).
 N > 1: weak scaling -- every rank owns one such x-slab of a (256*N) x 256 x 256 domain (--partition: ONE --config domain,
 e.g. plume1024 = BASELINE.json's 1024^3-extent sparse grid, split across the ranks instead); ranks exchange the halo
-leaves of u / p / phi over RCCL each time the reference would have a global kernel boundary that the stencil crosses
-(hnanosolver_amd/dist.py). `value` = slab-substeps/s summed over ranks = N x (global substeps/s).
+voxels of u / div / p / phi over RCCL where the single-GPU code has a kernel boundary that a stencil crosses, under the
+interior kernels (csrc/hns_dist.hip; hnanosolver_amd/dist.py is the host mirror). `value` = slab-substeps/s summed over ranks = N x (global substeps/s).
 
 Rank 0 prints ONE JSON line. `roofline`: dominant kernel k_rbgs_pair, algorithmic 12 B/voxel per launch (read p, read
 div, write p once each), launch time from hipEvents recorded on the launch stream around the pressure loop of every
@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--iterations", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--partition", action="store_true", help="N > 1: split ONE --config domain across the ranks (strong scaling) instead of one slab per rank")
+    ap.add_argument("--sweeps-per-exchange", type=int, default=0, help="N > 1: fused SOR sweeps between two halo refreshes of p (1..4, 0 = library default)")
     ap.add_argument("--cook", action="store_true", help="time the cook-equivalent hns_compute_sim call (upload + grid build + substep + download) instead")
     return ap.parse_args()
 
@@ -199,11 +200,12 @@ def main():
     else:
         from hnanosolver_amd import dist as HD
 
-        runner = HD.SlabBench(origins, R, rank, world, args.iterations, dt, partition=args.partition)
-        if args.partition:
-            n_vox_rank = runner.plan.n_owned * 512
-        step, timing_on, pressure_time = runner.step, runner.timing_on, runner.pressure_time
-        stage_times = getattr(runner, "stage_times", None)
+        runner = HD.SlabBench(origins, R, rank, world, args.iterations, dt, partition=args.partition, sweeps_per_exchange=args.sweeps_per_exchange)
+        n_vox_rank = runner.n_owned * 512
+        step, pressure_time, stage_times = runner.step, runner.pressure_time, None
+
+        def timing_on():
+            runner.timing_on(args.steps)
 
     for _ in range(args.warmup):
         step()
@@ -272,6 +274,8 @@ def main():
                 "pressure_iterations": args.iterations,
                 "substep": "advect_vector + divergence + RB-SOR + gradient subtraction + advect_scalars(S=1)",
                 "algorithmic_bytes_per_voxel_substep": BYTES_PER_VOXEL_SUBSTEP - 600 + 12 * args.iterations,
+                "halo": None if world == 1 else {k: runner.info()[k] for k in ("boundary_leaves", "interior_leaves", "ghost_leaves", "peers", "sweeps_per_exchange",
+                                                                                "bytes_sent", "messages_sent", "exchanges")},
                 "parallelism": "single GPU" if world == 1 else (f"one domain in {world} contiguous leaf ranges, RCCL halo exchange" if args.partition
                                                                 else f"x-slab leaf partition over {world} GPUs, RCCL halo exchange"),
             },

@@ -32,6 +32,15 @@ class hns_field(C.Structure):
     _fields_ = [("name", C.c_char_p), ("ncomp", C.c_int), ("host", C.POINTER(C.c_float))]
 
 
+class hns_dist_stats(C.Structure):
+    _fields_ = [("world", C.c_int), ("rank", C.c_int), ("peers", C.c_int), ("sweeps_per_exchange", C.c_int),
+                ("boundary_leaves", C.c_uint64), ("interior_leaves", C.c_uint64), ("ghost_leaves", C.c_uint64),
+                ("region_voxels_sent", C.c_uint64 * 4), ("bytes_sent", C.c_uint64 * 4), ("messages_sent", C.c_uint64), ("exchanges", C.c_uint64)]
+
+
+HNS_DIST_PLAN_ONLY = 1
+
+
 class hns_combustion_params(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("expansionRate", "temperatureRelease", "buoyancyStrength", "ambientTemp", "vorticityScale", "factorScale")]
 
@@ -55,6 +64,7 @@ SIGNATURES = {
     "hns_grid_voxel_count": (_u64, [_vp]),
     "hns_grid_voxel_size": (_f, [_vp]),
     "hns_grid_set_active_leaves": (_i, [_vp, _u64]),
+    "hns_grid_set_active_range": (_i, [_vp, _u64, _u64]),
     "hns_grid_active_leaves": (_u64, [_vp]),
     "hns_grid_set_outside_element": (_i, [_vp, _u64]),
     "hns_grid_offsets": (_i, [_vp, _vp, _u64, _vp]),
@@ -96,6 +106,25 @@ SIGNATURES = {
     "hns_dev_enforce_collision_boundaries": (_i, [_vp, _fp, _fp, _f, _vp]),
     "hns_dev_pack_leaves": (_i, [_fp, _vp, _u64, _fp, _i, _vp]),
     "hns_dev_unpack_leaves": (_i, [_fp, _vp, _u64, _fp, _i, _vp]),
+    "hns_dist_create": (_vp, [_vp, _u64, _i, _i, _f, _i, _i, C.c_uint, _ip]),
+    "hns_dist_destroy": (None, [_vp]),
+    "hns_dist_unique_id": (_i, [_vp]),
+    "hns_dist_connect_rccl": (_i, [_vp, _vp]),
+    "hns_dist_connect_local": (_i, [C.POINTER(C.c_void_p), _i]),
+    "hns_dist_connect_loopback": (_i, [_vp]),
+    "hns_dist_owned_leaves": (_u64, [_vp]),
+    "hns_dist_first_owned_leaf": (_u64, [_vp]),
+    "hns_dist_info": (_i, [_vp, C.POINTER(hns_dist_stats)]),
+    "hns_dist_local_leaves": (_i, [_vp, _vp]),
+    "hns_dist_peer_rank": (_i, [_vp, _i]),
+    "hns_dist_peer_region": (_i, [_vp, _i, _i, _i, _vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "hns_dist_upload": (_i, [_vp, _vp, C.POINTER(C.c_void_p), _vp]),
+    "hns_dist_download": (_i, [_vp, _vp, C.POINTER(C.c_void_p), _vp, _vp]),
+    "hns_dist_core_substep": (_i, [_vp, _i, _f, _vp]),
+    "hns_dist_local_core_substep": (_i, [C.POINTER(C.c_void_p), _i, _i, _f, _vp]),
+    "hns_dist_timing": (_i, [_vp, _i]),
+    "hns_dist_pressure_time": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_longlong)]),
+    "hns_dist_synchronize": (_i, [_vp, _vp]),
     "hns_dev_time_rbgs": (_i, [_vp, _fp, _fp, _fp, _f, _f, _i, _i, C.POINTER(C.c_float), _vp]),
 }
 

@@ -172,6 +172,9 @@ class IndexGridHandle:
     def set_active_leaves(self, n: int) -> None:
         _raise(lib.hns_grid_set_active_leaves(self._ptr, int(n)))
 
+    def set_active_range(self, first: int, count: int) -> None:
+        _raise(lib.hns_grid_set_active_range(self._ptr, int(first), int(count)))
+
     def export_nanovdb(self) -> np.ndarray:
         """The grid as a NanoVDB ``NanoGrid<ValueOnIndex>`` buffer (uint8 array, 32-byte aligned), the reference's own
         index-grid format (HNanoSolver.cu:375-384)."""

@@ -71,7 +71,7 @@ __device__ __forceinline__ void ld_zpair(const v4i& r, unsigned lo, unsigned hi,
 __device__ __forceinline__ LeafCtx stage_leaf_base(const GridDev& g, int* s_nbr, int* s_base, int block, unsigned* s_b4 = nullptr) {
 	LeafCtx c;
 	const int pos = (int)launch_pos(g, (unsigned)block);
-	c.leaf = g.sched ? g.sched[pos] : pos;
+	c.leaf = g.sched ? g.sched[pos] : g.first + pos;
 	c.org = g.origins[c.leaf];
 	if (threadIdx.x < 27) {
 		const int nb = g.nbr27[c.leaf * 27 + threadIdx.x];

@@ -40,6 +40,7 @@ GridDev hns_grid::dev() const {
 	d.hash_mask = topo.hash_mask;
 	d.n_leaves = (int)topo.n_leaves;
 	d.n_active = (int)n_active;
+	d.first = (int)first_active;
 	d.oob = (int)outside_element;
 	d.rev = 0;
 	return d;

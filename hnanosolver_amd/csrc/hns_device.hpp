@@ -94,7 +94,7 @@ struct LeafCtx {
 
 __device__ __forceinline__ LeafCtx stage_leaf(const GridDev& g, int* s_nbr, int block) {
 	LeafCtx c;
-	c.leaf = g.sched ? g.sched[block] : block;
+	c.leaf = g.sched ? g.sched[block] : g.first + block;
 	c.org = g.origins[c.leaf];
 	if (threadIdx.x < 27) s_nbr[threadIdx.x] = g.nbr27[c.leaf * 27 + threadIdx.x];
 	__syncthreads();

@@ -1,0 +1,910 @@
+// hns_dist.hip -- the leaf-partitioned multi-GPU core substep (the reference is single-GPU, so this is new
+// design): one rank per GPU owns a contiguous range of the NanoVDB-ordered leaf list, keeps one layer of ghost leaves,
+// and refreshes exactly the ghost VOXELS the next kernels can read, over RCCL point-to-point (xGMI) on a communication
+// stream of its own, underneath the kernels that do not need them.
+//
+//   local leaf order   [ B: owned leaves some other rank mirrors | I: the other owned leaves | G: ghosts, grouped by owner ]
+//   launch ranges      B, I, B+I (owned) and B+I+G (all) are four active ranges over the same local leaf list
+//   a kernel           runs on B first; the regions of B the peers read are packed and handed to the communication
+//                      stream; the kernel then runs on I while the messages travel (a ghost is only ever needed by the
+//                      NEXT kernel)
+//   halo regions       per exchange the set of voxels of a ghost leaf within the stencil's reach of a voxel the receiver
+//                      owns: L1 distance 1 for u* (divergence) and the final p (gradient), 2k-1 for div and 2k for p when
+//                      the pressure loop exchanges every k-th sweep (a fused red+black sweep moves information two voxels
+//                      and the ghost leaves are swept locally in between), the whole leaf for the advection inputs
+//                      (back-traces reach up to a leaf away), and one voxel -- element 0 of global leaf 0 -- for the
+//                      mirror advect_scalars' out-of-domain taps read (reference Kernel.cu:133,192,225).
+//                      Both sides derive the same 512-bit masks from the global leaf list; nothing but payload is sent.
+//   transports         RCCL (ncclSend/ncclRecv in one group per exchange; one process per GPU), or "local": every rank of
+//                      the decomposition lives in this process on one device and a message is a device copy out of the
+//                      peer's send buffer -- the same plan, kernels, streams and events without a wire; used by the tests
+//                      (8 emulated ranks on one GPU) and to measure the per-rank overhead before any wire time.
+//
+// Owned results are bit-identical to the single-domain run: every exchange sits where the single-GPU code has a kernel
+// boundary that a stencil crosses, and a ghost voxel is never read beyond the depth its last refresh made valid.
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library itself is opened on first use (see Rccl below)
+
+#include <algorithm>
+#include <cstring>
+#include <initializer_list>
+#include <utility>
+
+#include "hns_device.hpp"
+
+#define HNS_TRY(call)                    \
+	do {                                 \
+		int rc__ = (call);               \
+		if (rc__ != HNS_OK) return rc__; \
+	} while (0)
+
+// RCCL is bound at run time, the first time a multi-process transport is asked for: libhns.so then carries no load-time
+// dependency on the 500 MB library (single-GPU users never touch it), and a process that already holds an RCCL -- PyTorch
+// ships its own librccl.so.1 -- keeps exactly one copy instead of two interposing each other.
+namespace {
+struct Rccl {
+	decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+	decltype(&ncclCommInitRank) CommInitRank = nullptr;
+	decltype(&ncclCommDestroy) CommDestroy = nullptr;
+	decltype(&ncclGroupStart) GroupStart = nullptr;
+	decltype(&ncclGroupEnd) GroupEnd = nullptr;
+	decltype(&ncclSend) Send = nullptr;
+	decltype(&ncclRecv) Recv = nullptr;
+	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	bool ok = false;
+};
+Rccl& rccl() {
+	static Rccl r = [] {
+		Rccl t;
+		void* h = nullptr;
+		for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"})
+			if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+		if (!h) return t;
+		t.GetUniqueId = (decltype(t.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+		t.CommInitRank = (decltype(t.CommInitRank))dlsym(h, "ncclCommInitRank");
+		t.CommDestroy = (decltype(t.CommDestroy))dlsym(h, "ncclCommDestroy");
+		t.GroupStart = (decltype(t.GroupStart))dlsym(h, "ncclGroupStart");
+		t.GroupEnd = (decltype(t.GroupEnd))dlsym(h, "ncclGroupEnd");
+		t.Send = (decltype(t.Send))dlsym(h, "ncclSend");
+		t.Recv = (decltype(t.Recv))dlsym(h, "ncclRecv");
+		t.GetErrorString = (decltype(t.GetErrorString))dlsym(h, "ncclGetErrorString");
+		t.ok = t.GetUniqueId && t.CommInitRank && t.CommDestroy && t.GroupStart && t.GroupEnd && t.Send && t.Recv && t.GetErrorString;
+		return t;
+	}();
+	return r;
+}
+int need_rccl(const char* who) {
+	if (rccl().ok) return HNS_OK;
+	hns::set_error("%s: librccl.so.1 could not be loaded: %s", who, dlerror() ? dlerror() : "symbols missing");
+	return HNS_ERR_RUNTIME;
+}
+}  // namespace
+
+#define HNS_NCCL(call)                                                                                         \
+	do {                                                                                                       \
+		ncclResult_t r__ = (call);                                                                             \
+		if (r__ != ncclSuccess) {                                                                              \
+			hns::set_error("%s failed: %s (%s:%d)", #call, rccl().GetErrorString(r__), __FILE__, __LINE__);    \
+			return HNS_ERR_HIP;                                                                                \
+		}                                                                                                      \
+	} while (0)
+
+namespace hns {
+
+// ---------------------------------------------------------------------------------------------------------------
+// masked pack / unpack: one wave per listed leaf, lane = z-row (x*8+y), 8-bit z-mask per row
+// ---------------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int wave_exclusive_scan(int v) {
+	int s = v;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const int t = __shfl_up(s, d, 64);
+		if ((int)threadIdx.x >= d) s += t;
+	}
+	return s - v;
+}
+
+// loopback transport only: stands in for the time a message spends on the wire (option "dist_wire_us")
+__global__ void k_wire_delay(long long ticks) {
+	const long long t0 = wall_clock64();  // constant 100 MHz clock
+	while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+template <int NCOMP, bool PACK>
+__global__ __launch_bounds__(64) void k_halo_copy(float* __restrict__ field, const int* __restrict__ leaf, const unsigned char* __restrict__ mask,
+                                                  const int* __restrict__ off, float* __restrict__ msg) {
+	const int i = blockIdx.x, l = threadIdx.x;
+	const unsigned m = mask[(size_t)i * 64 + l];
+	const int base = off[i] + wave_exclusive_scan(__popc(m));
+	float* f = field + ((size_t)leaf[i] * 512 + l * 8) * NCOMP;
+	float* q = msg + (size_t)base * NCOMP;
+	int c = 0;
+#pragma unroll
+	for (int z = 0; z < 8; ++z) {
+		if (m >> z & 1) {
+#pragma unroll
+			for (int k = 0; k < NCOMP; ++k) {
+				if (PACK)
+					q[c * NCOMP + k] = f[z * NCOMP + k];
+				else
+					f[z * NCOMP + k] = q[c * NCOMP + k];
+			}
+			++c;
+		}
+	}
+}
+
+}  // namespace hns
+
+using namespace hns;
+
+// ---------------------------------------------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------------------------------------------
+
+namespace {
+
+enum { X_ADV = 0, X_D1 = 1, X_DIV = 2, X_P = 3, X_COUNT = 4 };  // halo region types (see the file header)
+
+struct Mask512 {
+	unsigned char row[64];
+	void clear() { memset(row, 0, sizeof(row)); }
+	void fill() { memset(row, 0xFF, sizeof(row)); }
+	void operator|=(const Mask512& o) {
+		for (int i = 0; i < 64; ++i) row[i] |= o.row[i];
+	}
+	int count() const {
+		int c = 0;
+		for (int i = 0; i < 64; ++i) c += __builtin_popcount(row[i]);
+		return c;
+	}
+};
+
+// voxels of a leaf within L1 distance D of the neighbouring leaf in direction j = (dx+1)*9 + (dy+1)*3 + (dz+1)
+Mask512 reach_mask(int j, int D) {
+	const int d[3] = {j / 9 - 1, (j / 3) % 3 - 1, j % 3 - 1};
+	Mask512 m;
+	m.clear();
+	for (int x = 0; x < 8; ++x)
+		for (int y = 0; y < 8; ++y)
+			for (int z = 0; z < 8; ++z) {
+				const int v[3] = {x, y, z};
+				int dist = 0;
+				for (int a = 0; a < 3; ++a) dist += d[a] < 0 ? v[a] + 1 : (d[a] > 0 ? 8 - v[a] : 0);
+				if (dist <= D) m.row[x * 8 + y] |= (unsigned char)(1u << z);
+			}
+	return m;
+}
+
+struct Region {  // the voxels of some local leaves that travel in one exchange with one peer
+	std::vector<int> leaf;            // local leaf ids
+	std::vector<unsigned char> mask;  // 64 bytes per listed leaf
+	std::vector<int> off;             // voxel offset of each listed leaf in the message
+	int voxels = 0;
+	bool whole = false;  // every listed leaf travels whole: plain 16-byte copies instead of the masked kernel
+	int* d_leaf = nullptr;
+	unsigned char* d_mask = nullptr;
+	int* d_off = nullptr;
+};
+
+struct Peer {
+	int rank = -1;
+	Region send[X_COUNT], recv[X_COUNT];
+	float* sbuf[2] = {nullptr, nullptr};  // message buffers, alternating with every exchange
+	float* rbuf[2] = {nullptr, nullptr};
+	size_t sbuf_floats = 0, rbuf_floats = 0;
+};
+
+struct Pending {  // an exchange that has been posted and not yet consumed
+	bool active = false;
+	int type = 0, parity = 0;
+	std::vector<std::pair<float*, int>> fields;  // (device field, ncomp) in message order
+};
+
+}  // namespace
+
+struct hns_dist {
+	int world = 1, rank = 0, k = 4, n_scalars = 1;
+	float voxel_size = 1.0f;
+	int64_t n_global = 0;
+	int nB = 0, nI = 0, nG = 0;
+	std::vector<int64_t> local_global;  // global id of every local leaf, local order [B | I | G]
+	std::vector<int> owned_perm;        // position of local leaf l < nB+nI in the ascending-global-id list of owned leaves
+	std::vector<Peer> peers;
+	hns_grid *gB = nullptr, *gI = nullptr, *gO = nullptr, *gA = nullptr;
+	// device state over the local leaves
+	void* arena = nullptr;
+	size_t arena_bytes = 0;
+	int device = -1;
+	float *u = nullptr, *adv = nullptr, *div = nullptr, *p_a = nullptr, *p_b = nullptr, *p_result = nullptr, *stage = nullptr;
+	std::vector<float*> phi, phi_next;
+	void* tables = nullptr;  // region tables of every peer (one allocation)
+	int* d_perm = nullptr;
+	// streams and events
+	hipStream_t cs = nullptr;
+	hipEvent_t ev_post[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_ready = nullptr;
+	int parity = 0;
+	Pending pending;
+	bool phi_in_flight = false;  // the exchange of phi (and u) that opens the next substep has already been posted
+	bool u_ghosts_fresh = false;
+	// transport
+	ncclComm_t comm = nullptr;
+	std::vector<hns_dist*> local_ranks;  // "local" transport: every rank of the decomposition, in this process
+	bool loopback = false;               // timing-only transport: every message is answered out of this rank's own send buffer
+	// statistics of the last substep
+	uint64_t bytes_sent[X_COUNT] = {0, 0, 0, 0}, messages_sent = 0, exchanges = 0;
+	// hipEvent bracketing of the pressure loop (communication included)
+	bool timing = false;
+	std::vector<hipEvent_t> tev;
+	size_t tev_used = 0;
+	long long timed_sweeps = 0;
+};
+
+namespace {
+
+int build_plan(hns_dist* d, const int32_t* origins, int64_t n, int world, int rank) {
+	Topology topo;
+	HNS_TRY(topo.prepare(origins, n));
+	HNS_TRY(topo.build_tables());
+	std::vector<int64_t> bounds((size_t)world + 1);
+	for (int r = 0; r <= world; ++r) bounds[(size_t)r] = n * r / world;
+	auto owner = [&](int64_t l) { return (int)(std::upper_bound(bounds.begin(), bounds.end(), l) - bounds.begin()) - 1; };
+	const int64_t o0 = bounds[(size_t)rank], o1 = bounds[(size_t)rank + 1];
+	const int n_owned = (int)(o1 - o0);
+	const int owner0 = n ? owner(0) : rank;
+
+	Mask512 reach[27][X_COUNT];
+	const int depth[X_COUNT] = {24, 1, 2 * d->k - 1, 2 * d->k};  // X_ADV: the whole leaf
+	for (int j = 0; j < 27; ++j)
+		for (int t = 0; t < X_COUNT; ++t) reach[j][t] = reach_mask(j, depth[t]);
+
+	// one pass over the neighbour rows of the owned leaves gives both directions: owned leaf l with a neighbour nb owned by
+	// q is a ghost of q (reach from l towards nb), and nb is a ghost of mine (reach from nb towards l = opposite direction)
+	struct Entry {
+		Mask512 m[X_COUNT];
+	};
+	std::vector<std::vector<std::pair<int64_t, Entry>>> send_of((size_t)world), recv_of((size_t)world);  // per peer, sorted by global leaf id
+	auto entry = [&](std::vector<std::pair<int64_t, Entry>>& v, std::vector<int64_t>& keys, int64_t id) -> Entry& {
+		// `keys` mirrors the ids of `v`, both ascending: binary search, insert when new (the visiting order is nearly ascending)
+		auto it = std::lower_bound(keys.begin(), keys.end(), id);
+		const size_t pos = (size_t)(it - keys.begin());
+		if (it == keys.end() || *it != id) {
+			keys.insert(it, id);
+			Entry z;
+			for (int t = 0; t < X_COUNT; ++t) z.m[t].clear();
+			v.insert(v.begin() + (long)pos, std::make_pair(id, z));
+		}
+		return v[pos].second;
+	};
+	std::vector<std::vector<int64_t>> send_keys((size_t)world), recv_keys((size_t)world);
+	std::vector<char> is_boundary((size_t)n_owned, 0);
+	for (int64_t l = o0; l < o1; ++l) {
+		for (int j = 0; j < 27; ++j) {
+			if (j == 13) continue;
+			const int64_t nb = topo.nbr27[(size_t)l * 27 + (size_t)j];
+			if (nb < 0 || (nb >= o0 && nb < o1)) continue;
+			const int q = owner(nb);
+			Entry& s = entry(send_of[(size_t)q], send_keys[(size_t)q], l);
+			Entry& r = entry(recv_of[(size_t)q], recv_keys[(size_t)q], nb);
+			for (int t = 0; t < X_COUNT; ++t) {
+				s.m[t] |= reach[j][t];
+				r.m[t] |= reach[26 - j][t];
+			}
+			is_boundary[(size_t)(l - o0)] = 1;
+		}
+	}
+	if (world > 1 && n > 0) {  // the mirror of global element 0 (voxel 0 of global leaf 0), advection inputs only
+		if (owner0 == rank) {
+			for (int q = 0; q < world; ++q)
+				if (q != rank) entry(send_of[(size_t)q], send_keys[(size_t)q], 0).m[X_ADV].row[0] |= 1;
+			is_boundary[0] = 1;
+		} else {
+			entry(recv_of[(size_t)owner0], recv_keys[(size_t)owner0], 0).m[X_ADV].row[0] |= 1;
+		}
+	}
+
+	// local order [B | I | G]
+	d->local_global.clear();
+	std::vector<int> local_of_owned((size_t)n_owned, -1);
+	for (int pass = 0; pass < 2; ++pass)
+		for (int i = 0; i < n_owned; ++i)
+			if ((is_boundary[(size_t)i] != 0) == (pass == 0)) {
+				local_of_owned[(size_t)i] = (int)d->local_global.size();
+				d->local_global.push_back(o0 + i);
+			}
+	d->nB = 0;
+	for (char b : is_boundary) d->nB += b ? 1 : 0;
+	d->nI = n_owned - d->nB;
+	d->owned_perm.resize((size_t)n_owned);
+	for (int i = 0; i < n_owned; ++i) d->owned_perm[(size_t)local_of_owned[(size_t)i]] = i;
+	d->peers.clear();
+	for (int q = 0; q < world; ++q) {
+		if (q == rank || (send_of[(size_t)q].empty() && recv_of[(size_t)q].empty())) continue;
+		Peer p;
+		p.rank = q;
+		const int ghost_base = (int)d->local_global.size();
+		for (auto& e : recv_of[(size_t)q]) d->local_global.push_back(e.first);
+		for (int t = 0; t < X_COUNT; ++t) {
+			int k = 0;
+			for (auto& e : recv_of[(size_t)q]) {
+				const int c = e.second.m[t].count();
+				if (c) {
+					p.recv[t].leaf.push_back(ghost_base + k);
+					p.recv[t].mask.insert(p.recv[t].mask.end(), e.second.m[t].row, e.second.m[t].row + 64);
+					p.recv[t].off.push_back(p.recv[t].voxels);
+					p.recv[t].voxels += c;
+				}
+				++k;
+			}
+			for (auto& e : send_of[(size_t)q]) {
+				const int c = e.second.m[t].count();
+				if (c) {
+					p.send[t].leaf.push_back(local_of_owned[(size_t)(e.first - o0)]);
+					p.send[t].mask.insert(p.send[t].mask.end(), e.second.m[t].row, e.second.m[t].row + 64);
+					p.send[t].off.push_back(p.send[t].voxels);
+					p.send[t].voxels += c;
+				}
+			}
+		}
+		for (int t = 0; t < X_COUNT; ++t)
+			for (Region* r : {&p.send[t], &p.recv[t]}) r->whole = r->voxels == 512 * (int)r->leaf.size();
+		d->peers.push_back(std::move(p));
+	}
+	d->nG = (int)d->local_global.size() - n_owned;
+	return HNS_OK;
+}
+
+size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// create / destroy
+// ---------------------------------------------------------------------------------------------------------------
+
+extern "C" {
+
+void hns_dist_destroy(hns_dist* d) {
+	if (!d) return;
+	if (d->cs) (void)hipStreamSynchronize(d->cs);
+	if (d->comm) (void)rccl().CommDestroy(d->comm);
+	for (hipEvent_t e : d->tev) (void)hipEventDestroy(e);
+	if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
+	for (int i = 0; i < 2; ++i) {
+		if (d->ev_post[i]) (void)hipEventDestroy(d->ev_post[i]);
+		if (d->ev_done[i]) (void)hipEventDestroy(d->ev_done[i]);
+	}
+	if (d->cs) (void)hipStreamDestroy(d->cs);
+	for (hns_grid* g : {d->gB, d->gI, d->gO, d->gA})
+		if (g) hns_grid_destroy(g);
+	if (d->arena) hns_arena_put(d->arena, d->arena_bytes, d->device);
+	if (d->tables) (void)hipFree(d->tables);
+	delete d;
+}
+
+hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_leaves, int world, int rank, float voxel_size, int n_scalars,
+                          int sweeps_per_exchange, unsigned flags, int* err) {
+	int rc = HNS_OK;
+	hns_dist* d = nullptr;
+	auto bail = [&](int code) -> hns_dist* {
+		if (d) hns_dist_destroy(d);
+		if (err) *err = code;
+		return nullptr;
+	};
+	if ((!global_leaf_origins_xyz && n_leaves) || world < 1 || rank < 0 || rank >= world || n_scalars < 0 || n_scalars > 8 || voxel_size <= 0.0f)
+		return bail(fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_create: bad arguments"));
+	if (sweeps_per_exchange == 0) sweeps_per_exchange = 4;
+	if (sweeps_per_exchange < 1 || sweeps_per_exchange > 4)  // a ghost layer is one leaf = 8 voxels deep and a fused sweep consumes two
+		return bail(fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_create: sweeps_per_exchange must be 1..4"));
+	d = new hns_dist;
+	d->world = world, d->rank = rank, d->k = sweeps_per_exchange, d->n_scalars = n_scalars, d->voxel_size = voxel_size, d->n_global = (int64_t)n_leaves;
+	if ((rc = build_plan(d, global_leaf_origins_xyz, (int64_t)n_leaves, world, rank)) != HNS_OK) return bail(rc);
+	if (flags & HNS_DIST_PLAN_ONLY) {  // host-side plan for inspection (tests run it through a CPU engine); no device is touched
+		if (err) *err = HNS_OK;
+		return d;
+	}
+
+	// the four launch ranges over the local leaves
+	const int n_local = (int)d->local_global.size(), nO = d->nB + d->nI;
+	std::vector<int32_t> lo((size_t)n_local * 3);
+	for (int i = 0; i < n_local; ++i)
+		for (int a = 0; a < 3; ++a) lo[(size_t)i * 3 + a] = global_leaf_origins_xyz[(size_t)d->local_global[(size_t)i] * 3 + a];
+	hns_grid** gs[4] = {&d->gB, &d->gI, &d->gO, &d->gA};
+	const uint64_t first[4] = {0, (uint64_t)d->nB, 0, 0}, count[4] = {(uint64_t)d->nB, (uint64_t)d->nI, (uint64_t)nO, (uint64_t)n_local};
+	uint64_t outside = 0;
+	for (int i = 0; i < n_local; ++i)
+		if (d->local_global[(size_t)i] == 0) outside = (uint64_t)i * 512u;
+	for (int i = 0; i < 4; ++i) {
+		*gs[i] = hns_grid_create_from_leaves(lo.data(), (uint64_t)n_local, voxel_size, HNS_GRID_DEFAULT, &rc);
+		if (!*gs[i]) return bail(rc);
+		if ((rc = hns_grid_set_active_range(*gs[i], first[i], count[i])) != HNS_OK) return bail(rc);
+		if ((rc = hns_grid_set_outside_element(*gs[i], outside)) != HNS_OK) return bail(rc);
+	}
+	d->device = d->gA->device;
+
+	// device state: u, adv (Vec3f) | div, p_a, p_b | phi, phi_next per scalar | upload/download staging (Vec3f over the owned leaves)
+	{
+		const size_t unit = pad256(sizeof(float) * 512 * (size_t)std::max(n_local, 1));
+		const size_t units = 3 + 3 + 3 + 2 * (size_t)n_scalars + 3;
+		if ((rc = hns_arena_get(unit * units, d->device, &d->arena, &d->arena_bytes)) != HNS_OK) return bail(rc);
+		if (hipMemset(d->arena, 0, unit * units) != hipSuccess) return bail(fail(HNS_ERR_HIP, "hns_dist_create: clearing the field memory failed"));
+		char* q = (char*)d->arena;
+		auto take = [&](size_t k) {
+			float* r = (float*)q;
+			q += k * unit;
+			return r;
+		};
+		d->u = take(3), d->adv = take(3), d->div = take(1), d->p_a = take(1), d->p_b = take(1);
+		for (int s = 0; s < n_scalars; ++s) d->phi.push_back(take(1)), d->phi_next.push_back(take(1));
+		d->stage = take(3);
+		d->p_result = d->p_a;
+	}
+	// region tables and message buffers
+	{
+		size_t bytes = pad256(sizeof(int) * (size_t)std::max(nO, 1));
+		for (Peer& p : d->peers) {
+			for (int t = 0; t < X_COUNT; ++t)
+				for (Region* r : {&p.send[t], &p.recv[t]}) bytes += pad256(sizeof(int) * r->leaf.size()) + pad256(r->mask.size()) + pad256(sizeof(int) * r->off.size());
+			p.sbuf_floats = (size_t)p.send[X_ADV].voxels * (size_t)(3 + n_scalars);
+			p.rbuf_floats = (size_t)p.recv[X_ADV].voxels * (size_t)(3 + n_scalars);
+			for (int t = 1; t < X_COUNT; ++t) {  // every other message is one Vec3f or one float per voxel of a smaller region
+				p.sbuf_floats = std::max(p.sbuf_floats, (size_t)p.send[t].voxels * 3);
+				p.rbuf_floats = std::max(p.rbuf_floats, (size_t)p.recv[t].voxels * 3);
+			}
+			bytes += 2 * pad256(sizeof(float) * p.sbuf_floats) + 2 * pad256(sizeof(float) * p.rbuf_floats);
+		}
+		if (hipMalloc(&d->tables, bytes) != hipSuccess) return bail(fail(HNS_ERR_HIP, "hns_dist_create: allocating the halo tables failed"));
+		char* q = (char*)d->tables;
+		auto put = [&](const void* src, size_t n) -> void* {
+			void* r = q;
+			if (n && hipMemcpy(q, src, n, hipMemcpyHostToDevice) != hipSuccess) rc = fail(HNS_ERR_HIP, "hns_dist_create: uploading the halo tables failed");
+			q += pad256(n);
+			return r;
+		};
+		d->d_perm = (int*)put(d->owned_perm.data(), sizeof(int) * d->owned_perm.size());
+		if (d->owned_perm.empty()) q += 256;
+		for (Peer& p : d->peers) {
+			for (int t = 0; t < X_COUNT; ++t)
+				for (Region* r : {&p.send[t], &p.recv[t]}) {
+					r->d_leaf = (int*)put(r->leaf.data(), sizeof(int) * r->leaf.size());
+					r->d_mask = (unsigned char*)put(r->mask.data(), r->mask.size());
+					r->d_off = (int*)put(r->off.data(), sizeof(int) * r->off.size());
+				}
+			for (int i = 0; i < 2; ++i) {
+				p.sbuf[i] = (float*)q, q += pad256(sizeof(float) * p.sbuf_floats);
+				p.rbuf[i] = (float*)q, q += pad256(sizeof(float) * p.rbuf_floats);
+			}
+		}
+		if (rc != HNS_OK) return bail(rc);
+	}
+	{
+		// the communication stream outranks the compute stream: its short kernels (boundary leaves, pack, unpack) must not
+		// queue behind the thousands of waves of the interior kernel they run next to
+		int lo_prio = 0, hi_prio = 0;
+		(void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+		if (hipStreamCreateWithPriority(&d->cs, hipStreamNonBlocking, hi_prio) != hipSuccess) return bail(fail(HNS_ERR_HIP, "hns_dist_create: stream creation failed"));
+	}
+	for (int i = 0; i < 2; ++i)
+		if (hipEventCreateWithFlags(&d->ev_post[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ev_done[i], hipEventDisableTiming) != hipSuccess)
+			return bail(fail(HNS_ERR_HIP, "hns_dist_create: event creation failed"));
+	if (hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess) return bail(fail(HNS_ERR_HIP, "hns_dist_create: event creation failed"));
+	if (err) *err = HNS_OK;
+	return d;
+}
+
+int hns_dist_unique_id(void* out128) {
+	if (!out128) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_unique_id: null argument");
+	static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+	HNS_TRY(need_rccl("hns_dist_unique_id"));
+	ncclUniqueId id;
+	HNS_NCCL(rccl().GetUniqueId(&id));
+	memcpy(out128, &id, sizeof(id));
+	return HNS_OK;
+}
+
+int hns_dist_connect_rccl(hns_dist* d, const void* unique_id128) {
+	if (!d || !unique_id128) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_rccl: null argument");
+	if (!d->gA) return fail(HNS_ERR_NO_DEVICE, "hns_dist_connect_rccl: plan-only handle");
+	if (d->comm || !d->local_ranks.empty()) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_rccl: already connected");
+	HNS_TRY(need_rccl("hns_dist_connect_rccl"));
+	ncclUniqueId id;
+	memcpy(&id, unique_id128, sizeof(id));
+	HNS_NCCL(rccl().CommInitRank(&d->comm, d->world, id, d->rank));
+	return HNS_OK;
+}
+
+// Timing only: this rank alone on the device, every message answered with this rank's own payload (wrong data, right
+// sizes, same streams / events / kernels). What one rank costs next to the plain single-GPU substep, before any wire time.
+int hns_dist_connect_loopback(hns_dist* d) {
+	if (!d || !d->gA) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_loopback: bad handle");
+	if (d->comm || !d->local_ranks.empty()) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_loopback: already connected");
+	d->loopback = true;
+	return HNS_OK;
+}
+
+int hns_dist_connect_local(hns_dist* const* ranks, int world) {
+	if (!ranks || world < 1) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_local: bad arguments");
+	for (int r = 0; r < world; ++r)
+		if (!ranks[r] || !ranks[r]->gA || ranks[r]->world != world || ranks[r]->rank != r || ranks[r]->comm || ranks[r]->device != ranks[0]->device)
+			return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_local: ranks[r] must be rank r of this world, unconnected, all on one device");
+	for (int r = 0; r < world; ++r) ranks[r]->local_ranks.assign(ranks, ranks + world);
+	return HNS_OK;
+}
+
+// ---- plan queries (also on HNS_DIST_PLAN_ONLY handles) ----
+int hns_dist_local_leaves(const hns_dist* d, int64_t* out_global_ids) {
+	if (!d || !out_global_ids) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_local_leaves: null argument");
+	std::copy(d->local_global.begin(), d->local_global.end(), out_global_ids);
+	return HNS_OK;
+}
+
+int hns_dist_peer_rank(const hns_dist* d, int peer) { return d && peer >= 0 && peer < (int)d->peers.size() ? d->peers[(size_t)peer].rank : -1; }
+
+int hns_dist_peer_region(const hns_dist* d, int peer, int type, int is_send, int32_t* leaves, unsigned char* masks, uint64_t* n_leaves, uint64_t* n_voxels) {
+	if (!d || peer < 0 || peer >= (int)d->peers.size() || type < 0 || type >= X_COUNT) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_peer_region: bad arguments");
+	const Region& r = is_send ? d->peers[(size_t)peer].send[type] : d->peers[(size_t)peer].recv[type];
+	if (n_leaves) *n_leaves = r.leaf.size();
+	if (n_voxels) *n_voxels = (uint64_t)r.voxels;
+	if (leaves) std::copy(r.leaf.begin(), r.leaf.end(), leaves);
+	if (masks) std::copy(r.mask.begin(), r.mask.end(), masks);
+	return HNS_OK;
+}
+
+uint64_t hns_dist_owned_leaves(const hns_dist* d) { return d ? (uint64_t)(d->nB + d->nI) : 0; }
+uint64_t hns_dist_first_owned_leaf(const hns_dist* d) { return d && d->nB + d->nI ? (uint64_t)(d->n_global * d->rank / d->world) : 0; }
+
+int hns_dist_info(const hns_dist* d, hns_dist_stats* out) {
+	if (!d || !out) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_info: null argument");
+	memset(out, 0, sizeof(*out));
+	out->world = d->world, out->rank = d->rank, out->sweeps_per_exchange = d->k;
+	out->boundary_leaves = (uint64_t)d->nB, out->interior_leaves = (uint64_t)d->nI, out->ghost_leaves = (uint64_t)d->nG;
+	out->peers = (int)d->peers.size();
+	for (int t = 0; t < X_COUNT; ++t) {
+		out->bytes_sent[t] = d->bytes_sent[t];
+		for (const Peer& p : d->peers) out->region_voxels_sent[t] += (uint64_t)p.send[t].voxels;
+	}
+	out->messages_sent = d->messages_sent, out->exchanges = d->exchanges;
+	return HNS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// upload / download: host arrays over the OWNED leaves in ascending global order
+// ---------------------------------------------------------------------------------------------------------------
+
+static int drain(hns_dist* d, hipStream_t st) {
+	// a posted exchange whose data nobody will consume (new fields are coming): let it finish, then forget it
+	if (d->pending.active) {
+		HNS_HIP(hipStreamSynchronize(st));
+		HNS_HIP(hipStreamSynchronize(d->cs));
+		d->pending.active = false;
+	}
+	d->phi_in_flight = false;
+	d->u_ghosts_fresh = false;
+	return HNS_OK;
+}
+
+int hns_dist_upload(hns_dist* d, const float* vel3, const float* const* scalars, void* stream) {
+	if (!d || !vel3 || (d->n_scalars && !scalars)) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_upload: null argument");
+	if (!d->gA) return fail(HNS_ERR_NO_DEVICE, "hns_dist_upload: plan-only handle (there is no CPU fallback)");
+	hipStream_t st = (hipStream_t)stream;
+	HNS_TRY(drain(d, st));
+	const int nO = d->nB + d->nI;
+	if (nO == 0) return HNS_OK;
+	for (int f = -1; f < d->n_scalars; ++f) {
+		const int nc = f < 0 ? 3 : 1;
+		const float* src = f < 0 ? vel3 : scalars[f];
+		if (!src) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_upload: null field");
+		HNS_HIP(hipMemcpyAsync(d->stage, src, sizeof(float) * 512 * (size_t)nO * nc, hipMemcpyHostToDevice, st));
+		HNS_TRY(hns_dev_pack_leaves(d->stage, d->d_perm, (uint64_t)nO, f < 0 ? d->u : d->phi[(size_t)f], nc, st));  // field[local] = staged[perm[local]]
+	}
+	HNS_HIP(hipStreamSynchronize(st));
+	return HNS_OK;
+}
+
+int hns_dist_download(hns_dist* d, float* vel3, float* const* scalars, float* pressure, void* stream) {
+	if (!d) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_download: null argument");
+	if (!d->gA) return fail(HNS_ERR_NO_DEVICE, "hns_dist_download: plan-only handle");
+	hipStream_t st = (hipStream_t)stream;
+	const int nO = d->nB + d->nI;
+	if (nO == 0) return HNS_OK;
+	for (int f = -2; f < d->n_scalars; ++f) {
+		const int nc = f == -1 ? 3 : 1;
+		float* dst = f == -2 ? pressure : (f == -1 ? vel3 : (scalars ? scalars[f] : nullptr));
+		if (!dst) continue;
+		const float* src = f == -2 ? d->p_result : (f == -1 ? d->u : d->phi[(size_t)f]);
+		HNS_TRY(hns_dev_unpack_leaves(src, d->d_perm, (uint64_t)nO, d->stage, nc, st));  // staged[perm[local]] = field[local]
+		HNS_HIP(hipMemcpyAsync(dst, d->stage, sizeof(float) * 512 * (size_t)nO * nc, hipMemcpyDeviceToHost, st));
+		HNS_HIP(hipStreamSynchronize(st));
+	}
+	return HNS_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// exchange: post (pack, hand to the communication stream) / complete (wait, unpack)
+// ---------------------------------------------------------------------------------------------------------------
+
+namespace {
+
+int halo_copy(bool pack, float* field, int ncomp, const Region& r, float* msg, hipStream_t st) {
+	if (r.leaf.empty()) return HNS_OK;
+	if (r.whole) return pack ? hns_dev_pack_leaves(field, r.d_leaf, r.leaf.size(), msg, ncomp, st) : hns_dev_unpack_leaves(msg, r.d_leaf, r.leaf.size(), field, ncomp, st);
+	const dim3 grid((unsigned)r.leaf.size()), block(64);
+	if (ncomp == 3) {
+		if (pack)
+			hipLaunchKernelGGL((k_halo_copy<3, true>), grid, block, 0, st, field, r.d_leaf, r.d_mask, r.d_off, msg);
+		else
+			hipLaunchKernelGGL((k_halo_copy<3, false>), grid, block, 0, st, field, r.d_leaf, r.d_mask, r.d_off, msg);
+	} else {
+		if (pack)
+			hipLaunchKernelGGL((k_halo_copy<1, true>), grid, block, 0, st, field, r.d_leaf, r.d_mask, r.d_off, msg);
+		else
+			hipLaunchKernelGGL((k_halo_copy<1, false>), grid, block, 0, st, field, r.d_leaf, r.d_mask, r.d_off, msg);
+	}
+	return launch_status("hns_dist: halo pack/unpack");
+}
+
+size_t message_floats(const Pending& x, const Region& r) {
+	size_t c = 0;
+	for (auto& f : x.fields) c += (size_t)f.second;
+	return c * (size_t)r.voxels;
+}
+
+// received regions -> ghost voxels, on the communication stream; ev_done marks the end of the exchange
+int unpack(hns_dist* d, Pending& x) {
+	for (Peer& p : d->peers) {
+		float* msg = p.rbuf[x.parity];
+		for (auto& f : x.fields) {
+			HNS_TRY(halo_copy(false, f.first, f.second, p.recv[x.type], msg, d->cs));
+			msg += (size_t)f.second * (size_t)p.recv[x.type].voxels;
+		}
+	}
+	HNS_HIP(hipEventRecord(d->ev_done[x.parity], d->cs));
+	return HNS_OK;
+}
+
+// One exchange. post(): the compute stream `st` marks "everything the boundary kernel reads is ready", and the rank's
+// communication stream takes over the whole boundary side of the step: `boundary(cs)` runs the kernel on the boundary leaves,
+// the regions the peers read are packed, the messages travel, the received regions are unpacked into the ghost voxels. The
+// caller then launches the interior kernel on `st`, which runs concurrently with all of that (an interior leaf touches no
+// ghost and no ghost-facing leaf writes what it reads). complete(): `st` waits for the end of that chain.
+// RCCL: sends and receives are one group on the communication stream. Local: the peers pull at complete().
+template <class BoundaryFn>
+int post(hns_dist* d, int type, std::vector<std::pair<float*, int>> fields, hipStream_t st, BoundaryFn boundary) {
+	if (d->pending.active) return fail(HNS_ERR_RUNTIME, "hns_dist: an exchange is already in flight");
+	if (d->world == 1) return boundary(st);  // nobody to talk to: the boundary range is empty, keep everything on one stream
+	if (!d->comm && !d->loopback && d->local_ranks.empty())
+		return fail(HNS_ERR_RUNTIME, "hns_dist: not connected (call hns_dist_connect_rccl or hns_dist_connect_local first)");
+	Pending& x = d->pending;
+	x.active = true, x.type = type, x.parity = d->parity, x.fields = std::move(fields);
+	d->parity ^= 1;
+	HNS_HIP(hipEventRecord(d->ev_ready, st));
+	HNS_HIP(hipStreamWaitEvent(d->cs, d->ev_ready, 0));
+	HNS_TRY(boundary(d->cs));
+	for (Peer& p : d->peers) {
+		float* msg = p.sbuf[x.parity];
+		for (auto& f : x.fields) {
+			HNS_TRY(halo_copy(true, f.first, f.second, p.send[type], msg, d->cs));
+			msg += (size_t)f.second * (size_t)p.send[type].voxels;
+		}
+		const size_t fl = message_floats(x, p.send[type]);
+		if (fl) d->bytes_sent[type] += sizeof(float) * fl, ++d->messages_sent;
+	}
+	++d->exchanges;
+	if (d->comm) {
+		HNS_NCCL(rccl().GroupStart());
+		for (Peer& p : d->peers) {
+			const size_t ns = message_floats(x, p.send[type]), nr = message_floats(x, p.recv[type]);
+			if (ns) HNS_NCCL(rccl().Send(p.sbuf[x.parity], ns, ncclFloat, p.rank, d->comm, d->cs));
+			if (nr) HNS_NCCL(rccl().Recv(p.rbuf[x.parity], nr, ncclFloat, p.rank, d->comm, d->cs));
+		}
+		HNS_NCCL(rccl().GroupEnd());
+	} else if (d->loopback) {  // same streams, events and copy sizes as a real exchange, but the payload is this rank's own
+		if (const int us = options().dist_wire_us.load()) hipLaunchKernelGGL(k_wire_delay, dim3(1), dim3(1), 0, d->cs, (long long)us * 100);
+		for (Peer& p : d->peers) {
+			const size_t nr = std::min(message_floats(x, p.recv[type]), message_floats(x, p.send[type]));
+			if (nr) HNS_HIP(hipMemcpyAsync(p.rbuf[x.parity], p.sbuf[x.parity], sizeof(float) * nr, hipMemcpyDeviceToDevice, d->cs));
+		}
+	} else {
+		HNS_HIP(hipEventRecord(d->ev_post[x.parity], d->cs));  // packed: the peers may pull
+		return HNS_OK;
+	}
+	return unpack(d, x);
+}
+
+// Make the posted exchange's data visible in the ghost voxels before anything else runs on the compute stream.
+int complete(hns_dist* d, hipStream_t st) {
+	Pending& x = d->pending;
+	if (!x.active) return HNS_OK;
+	if (!d->comm && !d->loopback) {  // local transport: pull every peer's message out of its send buffer, once the peer has packed it
+		for (Peer& p : d->peers) {
+			// the peer packed this message into its buffer of the same parity when it posted the same exchange; it may already
+			// have posted the NEXT one (other parity) -- never the one after, which its own complete() of this one precedes
+			hns_dist* q = d->local_ranks[(size_t)p.rank];
+			const Peer* back = nullptr;
+			for (const Peer& c : q->peers)
+				if (c.rank == d->rank) back = &c;
+			const size_t nr = message_floats(x, p.recv[x.type]);
+			if (!nr) continue;
+			if (!back || message_floats(x, back->send[x.type]) != nr) return fail(HNS_ERR_RUNTIME, "hns_dist: send/receive plans of two ranks disagree");
+			HNS_HIP(hipStreamWaitEvent(d->cs, q->ev_post[x.parity], 0));
+			HNS_HIP(hipMemcpyAsync(p.rbuf[x.parity], back->sbuf[x.parity], sizeof(float) * nr, hipMemcpyDeviceToDevice, d->cs));
+		}
+		HNS_TRY(unpack(d, x));
+	}
+	HNS_HIP(hipStreamWaitEvent(st, d->ev_done[x.parity], 0));
+	x.active = false;
+	return HNS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the core substep as a sequence of phases; a phase ends where an exchange has been posted
+// ---------------------------------------------------------------------------------------------------------------
+
+float omega_compute(float vs) { return 2.0f / (1.0f + sinf(static_cast<float>(3.14159) * vs)); }  // reference HNanoSolver.cu:257
+
+struct Step {
+	hns_dist* d;
+	int iterations;
+	float dt;
+	hipStream_t st;
+	// pressure loop cursor
+	int it = 0;
+	float *src = nullptr, *dst = nullptr;
+
+	int n_phases() const {
+		const int blocks = (iterations + d->k - 1) / d->k;
+		return 1 + 1 + 1 + blocks + 1 + 1;  // open | advect_vector | divergence | pressure blocks | gradient | advect_scalars
+	}
+
+	int sweep(hns_grid* g, bool from_zero, hipStream_t s) const {
+		return hns_rbgs_iterate(g, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), 1, nullptr, s, from_zero);
+	}
+
+	int advect_scalars(hns_grid* g, float inv_dx, hipStream_t s) const {
+		if (!d->n_scalars || !g->n_active) return HNS_OK;
+		std::vector<const float*> in(d->phi.begin(), d->phi.end());
+		return hns_dev_advect_scalars(g, d->u, in.data(), d->phi_next.data(), d->n_scalars, nullptr, 0, dt, inv_dx, s);
+	}
+
+	int run(int ph) {
+		const float inv_dx = 1.0f / d->voxel_size;
+		const int blocks = (iterations + d->k - 1) / d->k;
+		typedef std::vector<std::pair<float*, int>> Fields;
+		hns_dist* D = d;
+		auto nothing = [](hipStream_t) { return HNS_OK; };
+		if (ph == 0) {  // the advection inputs: phi was posted by the previous substep unless new fields were uploaded
+			if (d->phi_in_flight) return HNS_OK;
+			Fields f;
+			if (!d->u_ghosts_fresh) f.emplace_back(d->u, 3);
+			for (float* p : d->phi) f.emplace_back(p, 1);
+			return post(d, X_ADV, f, st, nothing);
+		}
+		HNS_TRY(complete(d, st));
+		if (ph == 1) {
+			const float dtv = dt;
+			HNS_TRY(post(d, X_D1, Fields{{d->adv, 3}}, st, [=](hipStream_t s) { return hns_dev_advect_vector(D->gB, D->u, D->adv, nullptr, 0, dtv, inv_dx, s); }));
+			return hns_dev_advect_vector(d->gI, d->u, d->adv, nullptr, 0, dt, inv_dx, st);
+		}
+		if (ph == 2) {
+			HNS_TRY(post(d, X_DIV, Fields{{d->div, 1}}, st, [=](hipStream_t s) { return hns_dev_divergence(D->gB, D->adv, D->div, inv_dx, s); }));
+			return hns_dev_divergence(d->gI, d->adv, d->div, inv_dx, st);
+		}
+		if (ph < 3 + blocks) {  // one block of up to k sweeps; all but the last sweep the ghost leaves too
+			const int b = ph - 3;
+			if (b == 0) {
+				it = 0, src = d->p_a, dst = d->p_b;  // never warm-started (reference HNanoSolver.cu:113): the first sweep reads no p
+				if (d->timing && d->tev_used + 2 <= d->tev.size()) HNS_HIP(hipEventRecord(d->tev[d->tev_used], st));
+			}
+			const int n = std::min(d->k, iterations - it);
+			for (int j = 0; j < n - 1; ++j, ++it) {
+				HNS_TRY(sweep(d->gA, it == 0, st));
+				std::swap(src, dst);
+			}
+			const bool last = it + 1 == iterations, zero = it == 0;
+			HNS_TRY(post(d, last ? X_D1 : X_P, Fields{{dst, 1}}, st, [=](hipStream_t s) { return sweep(D->gB, zero, s); }));
+			HNS_TRY(sweep(d->gI, zero, st));
+			std::swap(src, dst);
+			++it;
+			if (last) d->p_result = src;
+			return HNS_OK;
+		}
+		if (ph == 3 + blocks) {
+			if (d->timing && d->tev_used + 2 <= d->tev.size()) {  // the timed region ends when the last refresh of p has landed (complete() above)
+				HNS_HIP(hipEventRecord(d->tev[d->tev_used + 1], st));
+				d->tev_used += 2;
+				d->timed_sweeps += iterations;
+			}
+			HNS_TRY(post(d, X_ADV, Fields{{d->u, 3}}, st,
+			             [=](hipStream_t s) { return hns_dev_subtract_pressure_gradient(D->gB, D->adv, D->p_result, D->u, nullptr, 0, inv_dx, s); }));
+			return hns_dev_subtract_pressure_gradient(d->gI, d->adv, d->p_result, d->u, nullptr, 0, inv_dx, st);
+		}
+		// last phase: advect the scalars, and already post them for the advection that opens the next substep
+		d->u_ghosts_fresh = true;
+		Fields f;
+		for (float* p : d->phi_next) f.emplace_back(p, 1);  // the boundary leaves' new values travel while the interior is advected
+		if (d->n_scalars) HNS_TRY(post(d, X_ADV, f, st, [=](hipStream_t s) { return advect_scalars(D->gB, inv_dx, s); }));
+		HNS_TRY(advect_scalars(d->gI, inv_dx, st));
+		std::swap(d->phi, d->phi_next);
+		d->phi_in_flight = d->n_scalars > 0 && d->world > 1;
+		return HNS_OK;
+	}
+};
+
+int check_step(const hns_dist* d, int iterations, float dt) {
+	if (!d) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_core_substep: null handle");
+	if (dt < 0.0f) return fail(HNS_ERR_INVALID_ARGUMENT, "dt (time step) cannot be negative.");
+	if (iterations <= 0) return fail(HNS_ERR_INVALID_ARGUMENT, "Number of pressure iterations must be positive.");
+	return HNS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// One core substep (advect_vector -> divergence -> iterations x RB-SOR -> gradient subtraction -> advect_scalars) of this
+// rank, asynchronous on `stream` (plus the rank's communication stream). RCCL transport, or world == 1.
+int hns_dist_core_substep(hns_dist* d, int iterations, float dt, void* stream) {
+	HNS_TRY(check_step(d, iterations, dt));
+	if (!d->gA) return fail(HNS_ERR_NO_DEVICE, "hns_dist_core_substep: plan-only handle (there is no CPU fallback)");
+	if (!d->local_ranks.empty() && d->world > 1) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_core_substep: locally connected ranks step together (hns_dist_local_core_substep)");
+	memset(d->bytes_sent, 0, sizeof(d->bytes_sent));
+	d->messages_sent = d->exchanges = 0;
+	Step s{d, iterations, dt, (hipStream_t)stream};
+	for (int ph = 0, n = s.n_phases(); ph < n; ++ph) HNS_TRY(s.run(ph));
+	return HNS_OK;
+}
+
+// The same for ranks connected with hns_dist_connect_local: all ranks advance phase by phase on `stream`.
+int hns_dist_local_core_substep(hns_dist* const* ranks, int world, int iterations, float dt, void* stream) {
+	if (!ranks || world < 1) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_local_core_substep: bad arguments");
+	std::vector<Step> steps;
+	for (int r = 0; r < world; ++r) {
+		HNS_TRY(check_step(ranks[r], iterations, dt));
+		if ((int)ranks[r]->local_ranks.size() != world) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_local_core_substep: ranks are not locally connected");
+		memset(ranks[r]->bytes_sent, 0, sizeof(ranks[r]->bytes_sent));
+		ranks[r]->messages_sent = ranks[r]->exchanges = 0;
+		steps.push_back(Step{ranks[r], iterations, dt, (hipStream_t)stream});
+	}
+	for (int ph = 0, n = steps[0].n_phases(); ph < n; ++ph)
+		for (Step& s : steps) HNS_TRY(s.run(ph));
+	return HNS_OK;
+}
+
+int hns_dist_timing(hns_dist* d, int max_solves) {
+	if (!d || max_solves < 0) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_timing: bad arguments");
+	while (d->tev.size() < (size_t)max_solves * 2) {
+		hipEvent_t e;
+		HNS_HIP(hipEventCreate(&e));
+		d->tev.push_back(e);
+	}
+	d->timing = max_solves > 0;
+	d->tev_used = 0;
+	d->timed_sweeps = 0;
+	return HNS_OK;
+}
+
+int hns_dist_pressure_time(hns_dist* d, float* total_ms, long long* sweeps) {
+	if (!d || !total_ms || !sweeps) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_pressure_time: null argument");
+	double tot = 0.0;
+	for (size_t i = 0; i + 1 < d->tev_used; i += 2) {
+		HNS_HIP(hipEventSynchronize(d->tev[i + 1]));
+		float ms = 0.0f;
+		HNS_HIP(hipEventElapsedTime(&ms, d->tev[i], d->tev[i + 1]));
+		tot += ms;
+	}
+	*total_ms = (float)tot;
+	*sweeps = d->timed_sweeps;
+	return HNS_OK;
+}
+
+int hns_dist_synchronize(hns_dist* d, void* stream) {
+	if (!d) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_synchronize: null handle");
+	HNS_HIP(hipStreamSynchronize((hipStream_t)stream));
+	HNS_HIP(hipStreamSynchronize(d->cs));
+	return HNS_OK;
+}
+
+}  // extern "C"

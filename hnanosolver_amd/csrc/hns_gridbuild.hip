@@ -77,11 +77,11 @@ __host__ __device__ inline int sched_leaf(int b, int n, bool linear) {
 
 // {leaf, nbr27[27]} per block in launch order: the kernels that work one leaf per workgroup read their whole
 // topology with one fetch.
-__global__ __launch_bounds__(256) void k_build_blk(const int* __restrict__ nbr27, int n_active, int linear, int* __restrict__ sched, int* __restrict__ blk) {
+__global__ __launch_bounds__(256) void k_build_blk(const int* __restrict__ nbr27, int first, int n_active, int linear, int* __restrict__ sched, int* __restrict__ blk) {
 	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	if (t >= (int64_t)n_active * 28) return;
 	const int b = (int)(t / 28), j = (int)(t % 28);
-	const int l = sched_leaf(b, n_active, linear != 0);
+	const int l = first + sched_leaf(b, n_active, linear != 0);
 	if (j == 0) {
 		blk[t] = l;
 		if (sched) sched[b] = l;
@@ -94,21 +94,21 @@ __global__ __launch_bounds__(256) void k_build_blk(const int* __restrict__ nbr27
 // their -z/+z neighbours; counting from the bottom of its run, an even leaf heads a wave and takes the leaf above it
 // as partner (none: the leaf travels alone), an odd leaf is that partner. The rule needs no ordering between leaves,
 // leaves the fewest possible lone leaves, and reproduces the aligned (0,1),(2,3).. pairs on a dense grid.
-__device__ __forceinline__ int pair_partner(const int* __restrict__ nbr27, int n_active, int l) {
+__device__ __forceinline__ int pair_partner(const int* __restrict__ nbr27, int first, int n_active, int l) {
 	int steps = 0;
 	for (int m = l;;) {
 		const int dn = nbr27[(size_t)m * 27 + 12];
-		if (dn < 0 || dn >= n_active) break;
+		if (dn < first || dn >= first + n_active) break;
 		m = dn;
 		++steps;
 	}
 	if (steps & 1) return -2;  // not a head
 	const int up = nbr27[(size_t)l * 27 + 14];
-	return (up >= 0 && up < n_active) ? up : -1;
+	return (up >= first && up < first + n_active) ? up : -1;
 }
 
 // pass 1: partner[b] for schedule position b, and the number of wave heads / lone leaves per 256-position block
-__global__ __launch_bounds__(256) void k_pair_heads(const int* __restrict__ nbr27, int n_active, int linear, int* __restrict__ partner, int* __restrict__ block_heads,
+__global__ __launch_bounds__(256) void k_pair_heads(const int* __restrict__ nbr27, int first, int n_active, int linear, int* __restrict__ partner, int* __restrict__ block_heads,
                                                     int* __restrict__ totals) {
 	__shared__ int s_cnt[2];
 	if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_pair_heads(const int* __restrict__ nbr2
 	const int b = blockIdx.x * 256 + threadIdx.x;
 	int p = -2;
 	if (b < n_active) {
-		p = pair_partner(nbr27, n_active, sched_leaf(b, n_active, linear != 0));
+		p = pair_partner(nbr27, first, n_active, first + sched_leaf(b, n_active, linear != 0));
 		partner[b] = p;
 	}
 	const unsigned long long heads = __ballot(p != -2), lone = __ballot(p == -1);
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(int* __restrict__ block_he
 }
 
 // pass 3: wave records {leaf0, nbr27, leaf1 or -1, nbr27} (56 ints) in schedule order of their head leaf
-__global__ __launch_bounds__(256) void k_write_pairs(const int* __restrict__ nbr27, int n_active, int linear, const int* __restrict__ partner,
+__global__ __launch_bounds__(256) void k_write_pairs(const int* __restrict__ nbr27, int first, int n_active, int linear, const int* __restrict__ partner,
                                                      const int* __restrict__ block_base, int* __restrict__ recs) {
 	__shared__ int s_wave[4];
 	const int b = blockIdx.x * 256 + threadIdx.x;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_write_pairs(const int* __restrict__ nbr
 	int pos = block_base[blockIdx.x] + __popcll(heads & ((1ull << lane) - 1ull));
 	for (int i = 0; i < w; ++i) pos += s_wave[i];
 	if (p == -2) return;
-	const int l = sched_leaf(b, n_active, linear != 0);
+	const int l = first + sched_leaf(b, n_active, linear != 0);
 	int* r = recs + (size_t)pos * 56;
 	r[0] = l;
 	r[28] = p;
@@ -192,7 +192,7 @@ int hns_grid_upload_schedule(hns_grid* g) {
 		for (auto& e : g->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);  // captured launches hold the old lists
 		g->graphs.clear();
 	}
-	const int n = (int)g->n_active;
+	const int n = (int)g->n_active, first = (int)g->first_active;
 	if (n == 0) return HNS_OK;
 	// XCD-chunked order wins by a wide margin while the sweep arrays fit the Infinity Cache and its neighbourhood (256^3:
 	// 40.6 vs 53.5 us per sweep, 320^3: 108 vs 114); far beyond it plain leaf order is a little better (384^3: 186.6 vs
@@ -207,13 +207,13 @@ int hns_grid_upload_schedule(hns_grid* g) {
 	int* totals = block_heads + n_blocks;
 	int h_totals[2] = {0, 0};
 	HNS_HIP(hipMemsetAsync(totals, 0, 2 * sizeof(int), 0));
-	k_build_blk<<<(unsigned)(((int64_t)n * 28 + 255) / 256), 256, 0, 0>>>(nbr27, n, linear, (int*)g->d_sched, (int*)g->d_blk);
-	k_pair_heads<<<n_blocks, 256, 0, 0>>>(nbr27, n, linear, partner, block_heads, totals);
+	k_build_blk<<<(unsigned)(((int64_t)n * 28 + 255) / 256), 256, 0, 0>>>(nbr27, first, n, linear, (int*)g->d_sched, (int*)g->d_blk);
+	k_pair_heads<<<n_blocks, 256, 0, 0>>>(nbr27, first, n, linear, partner, block_heads, totals);
 	k_scan_blocks<<<1, 1024, 0, 0>>>(block_heads, n_blocks);
 	HNS_HIP(hipMemcpy(h_totals, totals, sizeof(h_totals), hipMemcpyDeviceToHost));  // also the sync point for the launches above
 	g->n_pairs = (uint64_t)h_totals[0];
 	g->n_singles = (uint64_t)h_totals[1];
-	k_write_pairs<<<n_blocks, 256, 0, 0>>>(nbr27, n, linear, partner, block_heads, (int*)g->d_pairs);
+	k_write_pairs<<<n_blocks, 256, 0, 0>>>(nbr27, first, n, linear, partner, block_heads, (int*)g->d_pairs);
 	HNS_HIP(hipDeviceSynchronize());
 	return HNS_OK;
 }
@@ -311,7 +311,7 @@ extern "C" int hns_grid_launch_tables(const hns_grid* g, int32_t* sched, int32_t
 		if (g->d_sched)
 			HNS_HIP(hipMemcpy(sched, g->d_sched, sizeof(int32_t) * g->n_active, hipMemcpyDeviceToHost));
 		else
-			for (uint64_t b = 0; b < g->n_active; ++b) sched[b] = (int32_t)b;
+			for (uint64_t b = 0; b < g->n_active; ++b) sched[b] = (int32_t)(g->first_active + b);
 	}
 	if (wave_records && g->n_pairs) HNS_HIP(hipMemcpy(wave_records, g->d_pairs, sizeof(int32_t) * 56 * g->n_pairs, hipMemcpyDeviceToHost));
 	return HNS_OK;

@@ -37,6 +37,7 @@ struct Options {
 	std::atomic<int> graph{0};                 // "graph": replay the pressure loop as a hipGraph
 	std::atomic<int> cook_cache{1};            // "cook_cache": operator calls keep their device buffers with the grid
 	std::atomic<int> cook_pipeline{1};         // "cook_pipeline": hns_compute_sim overlaps transfers with the substep
+	std::atomic<int> dist_wire_us{0};          // "dist_wire_us": loopback transport only, emulated time on the wire per exchange
 	std::atomic<int> sor_block{0};             // "sor_block": 0 = auto, N = leaf pairs per workgroup of the blocked SOR kernel
 };
 Options& options();
@@ -73,6 +74,7 @@ struct GridDev {
 	uint32_t hash_mask;
 	int n_leaves;
 	int n_active;
+	int first;  // first active leaf: kernels update leaves [first, first + n_active)
 	int oob;  // element read by advect_scalars for out-of-domain taps (0 on an unpartitioned grid)
 	int rev;  // 1: walk the launch order backwards (rows of eight workgroups reversed, see k_rbgs_pair)
 };
@@ -101,7 +103,8 @@ struct hns_sim;
 struct hns_grid {
 	hns::Topology topo;
 	float voxel_size = 1.0f;
-	uint64_t n_active = 0;
+	uint64_t n_active = 0;      // kernels update leaves [first_active, first_active + n_active) and only read the others
+	uint64_t first_active = 0;
 	uint64_t outside_element = 0;
 	bool on_device = false;
 	int device = -1;

@@ -773,7 +773,8 @@ static int rbgs_form(const hns_grid* g, int opt) {
 	if (opt == kRbgsColor || opt == kRbgsWave) return opt;
 	if (!g->d_pairs) return kRbgsWave;
 	if (opt == kRbgsPair) return kRbgsPair;
-	if (g->n_active <= 1024 || (g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs)) return kRbgsWave;
+	// (<= 2048: also the boundary range of a multi-GPU rank, a few thousand leaves swept next to the interior launch)
+	if (g->n_active <= 2048 || (g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs)) return kRbgsWave;
 	return kRbgsPair;
 }
 

@@ -148,6 +148,7 @@ const OptionDesc kOptions[] = {
     {"cook_cache", &Options::cook_cache, kWordsBool},
     {"cook_pipeline", &Options::cook_pipeline, kWordsBool},
     {"sor_block", &Options::sor_block, nullptr},
+    {"dist_wire_us", &Options::dist_wire_us, nullptr},
 };
 const Options kDefaults;
 }  // namespace
@@ -313,11 +314,19 @@ uint64_t hns_grid_voxel_count(const hns_grid* g) { return g ? (uint64_t)g->topo.
 float hns_grid_voxel_size(const hns_grid* g) { return g ? g->voxel_size : 0.0f; }
 uint64_t hns_grid_active_leaves(const hns_grid* g) { return g ? g->n_active : 0; }
 
+int hns_grid_set_active_range(hns_grid* g, uint64_t first, uint64_t count) {
+	if (!g) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_set_active_range: null grid");
+	if (first > (uint64_t)g->topo.n_leaves || count > (uint64_t)g->topo.n_leaves - first)
+		return fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_set_active_range: range beyond the grid's leaves");
+	g->first_active = count ? first : 0;
+	g->n_active = count;
+	return g->on_device ? hns_grid_upload_schedule(g) : HNS_OK;
+}
+
 int hns_grid_set_active_leaves(hns_grid* g, uint64_t n_active) {
 	if (!g) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_set_active_leaves: null grid");
 	if (n_active > (uint64_t)g->topo.n_leaves) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_set_active_leaves: more active leaves than leaves");
-	g->n_active = n_active;
-	return g->on_device ? hns_grid_upload_schedule(g) : HNS_OK;
+	return hns_grid_set_active_range(g, 0, n_active);
 }
 
 int hns_grid_set_outside_element(hns_grid* g, uint64_t element_index) {

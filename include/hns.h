@@ -69,7 +69,8 @@ int hns_trim_memory(void);
  *   "graph"         0 | 1 (replay the pressure loop as a hipGraph)
  *   "cook_cache"    1 | 0 (operator calls keep their device buffers with the grid)
  *   "cook_pipeline" 1 | 0 (hns_compute_sim overlaps its transfers with the substep)
- *   "sor_block"     0 = auto | N leaf pairs per workgroup of the SOR kernel */
+ *   "sor_block"     0 = auto | N leaf pairs per workgroup of the SOR kernel
+ *   "dist_wire_us"  N: the loopback transport of hns_dist holds every exchange N microseconds (emulated wire time) */
 int hns_set_option(const char* name, const char* value);
 const char* hns_get_option(const char* name); /* current value as a word; NULL for an unknown name */
 
@@ -97,6 +98,10 @@ float hns_grid_voxel_size(const hns_grid*);
 /* Kernels update leaves [0, n_active) only; leaves [n_active, leaf_count) are ghosts that are read but never written
  * (multi-GPU halo leaves). Default n_active = leaf_count. */
 int hns_grid_set_active_leaves(hns_grid*, uint64_t n_active);
+/* The same for any contiguous range: kernels update leaves [first, first + count). The multi-GPU driver orders a rank's
+ * leaves [boundary | interior | ghosts] and sweeps the boundary leaves first, so that their halo is on the wire while the
+ * interior is being computed. */
+int hns_grid_set_active_range(hns_grid*, uint64_t first, uint64_t count);
 uint64_t hns_grid_active_leaves(const hns_grid*);
 /* advect_scalars reads ELEMENT 0 of each array for taps outside the domain (reference Kernel.cu:133,192,225). On a
  * leaf-partitioned rank "element 0" of the global arrays lives at another local index (the ghost copy of global leaf 0):
@@ -226,6 +231,64 @@ int hns_dev_enforce_collision_boundaries(hns_grid*, float* vel3, const float* sd
  * 3 = Vec3f field) between a field and a packed buffer. leaf_ids is a DEVICE array of n leaf indices. */
 int hns_dev_pack_leaves(const float* field, const int32_t* leaf_ids, uint64_t n, float* packed, int ncomp, void* stream);
 int hns_dev_unpack_leaves(const float* packed, const int32_t* leaf_ids, uint64_t n, float* field, int ncomp, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Leaf-partitioned multi-GPU core substep (new: the reference is single-GPU). One hns_dist per rank = per GPU.      */
+/* Rank r owns leaves [n*r/world, n*(r+1)/world) of the global leaf list (NanoVDB order: x-slabs for box domains), */
+/* keeps one layer of ghost leaves and refreshes exactly the ghost voxels the next kernel can read (hns_dist.hip). */
+/* Owned results are bit-identical to the single-domain hns_sim_core_substep.                                      */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+typedef struct hns_dist hns_dist;
+
+typedef struct {
+	int world, rank, peers, sweeps_per_exchange;
+	uint64_t boundary_leaves, interior_leaves, ghost_leaves; /* local leaf order: [boundary | interior | ghosts] */
+	/* per halo region type {advection inputs (whole leaves + the element-0 mirror), L1 reach 1, div (2k-1), p (2k)}: */
+	uint64_t region_voxels_sent[4]; /* voxels this rank sends per exchange of that type (a property of the plan)   */
+	uint64_t bytes_sent[4];         /* payload bytes this rank sent during the last substep                          */
+	uint64_t messages_sent, exchanges; /* point-to-point messages / exchange rounds of the last substep              */
+} hns_dist_stats;
+
+/* sweeps_per_exchange (1..4, 0 = default 4): the pressure loop refreshes the ghosts of p after every k-th fused sweep and
+ * sweeps the ghost leaves locally in between. n_scalars float fields are advected (the metric's core substep uses 1). */
+#define HNS_DIST_DEFAULT 0u
+#define HNS_DIST_PLAN_ONLY 1u /* build the partition plan on the host only (inspection / CPU tests); compute calls then fail */
+hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_leaves, int world, int rank, float voxel_size, int n_scalars,
+                          int sweeps_per_exchange, unsigned flags, int* err);
+void hns_dist_destroy(hns_dist*);
+/* Transport, RCCL over xGMI (one process per GPU): rank 0 calls hns_dist_unique_id and hands the 128 bytes to every rank
+ * by any means (torch.distributed broadcast, MPI, a file); every rank then calls hns_dist_connect_rccl (collective). */
+int hns_dist_unique_id(void* out128);
+int hns_dist_connect_rccl(hns_dist*, const void* unique_id128);
+/* Transport, local: all `world` ranks live in this process on ONE device; a message is a device copy out of the peer's
+ * send buffer. Same plan, kernels, streams and events as the RCCL path (tests; per-rank overhead without a wire). */
+int hns_dist_connect_local(hns_dist* const* ranks, int world);
+/* Transport, loopback (TIMING ONLY, results are meaningless): this rank alone, every message answered with the rank's own
+ * payload of the same size. Measures what one rank costs next to the single-GPU substep before any wire time. */
+int hns_dist_connect_loopback(hns_dist*);
+uint64_t hns_dist_owned_leaves(const hns_dist*);
+uint64_t hns_dist_first_owned_leaf(const hns_dist*); /* global id of the first owned leaf; owned leaves are contiguous */
+int hns_dist_info(const hns_dist*, hns_dist_stats* out);
+/* The plan (also on PLAN_ONLY handles): global id of every local leaf in local order [boundary | interior | ghosts]; the
+ * rank of peer i (-1 beyond the last); and per peer, halo region type (0..3 as in hns_dist_stats) and direction the
+ * local leaves whose voxels travel plus a 64-byte mask each (byte x*8+y, bit z). Any output pointer may be NULL. */
+int hns_dist_local_leaves(const hns_dist*, int64_t* out_global_ids);
+int hns_dist_peer_rank(const hns_dist*, int peer);
+int hns_dist_peer_region(const hns_dist*, int peer, int type, int is_send, int32_t* leaves, unsigned char* masks, uint64_t* n_leaves, uint64_t* n_voxels);
+/* Host arrays over the OWNED leaves in ascending global order (vel3: 512*3 floats per leaf, each scalar 512 per leaf).
+ * Collective in effect: every rank uploads before the next substep (the first exchange then carries the new fields).
+ * Synchronous. download: any pointer may be NULL; `pressure` receives the last solve's p. */
+int hns_dist_upload(hns_dist*, const float* vel3, const float* const* scalars, void* stream);
+int hns_dist_download(hns_dist*, float* vel3, float* const* scalars, float* pressure, void* stream);
+/* One core substep of this rank, asynchronous on `stream` and on the rank's communication stream (RCCL transport, or world 1). */
+int hns_dist_core_substep(hns_dist*, int iterations, float dt, void* stream);
+/* The same for locally connected ranks: all of them advance together, phase by phase, on `stream`. */
+int hns_dist_local_core_substep(hns_dist* const* ranks, int world, int iterations, float dt, void* stream);
+/* hipEvent bracketing of the pressure loops (halo exchanges included), as hns_sim_timing / hns_sim_pressure_time. */
+int hns_dist_timing(hns_dist*, int max_solves);
+int hns_dist_pressure_time(hns_dist*, float* total_ms, long long* sweeps);
+int hns_dist_synchronize(hns_dist*, void* stream); /* waits for `stream` and the communication stream */
 
 /* Timing helper: runs `iterations` fused RB-SOR iterations `reps` times on `stream`, bracketing each launch group with
  * hipEvents on that stream, and returns the mean milliseconds per fused-iteration launch. */

@@ -1,28 +1,31 @@
 #!/usr/bin/env python3
-"""Cost of being one rank of a multi-GPU slab run, measured on ONE GPU: rank 0 of a 2-slab 256^3-per-rank domain with its
-halo exchange looped back through device copies (no RCCL, everything else -- ghost leaves, ghost sweeps, pack kernels,
-Python driver -- as in bench.py --gpus 2). Prints ms per substep next to the plain single-GPU substep, i.e. an upper
-bound on the weak-scaling efficiency before any wire time."""
+"""Cost of being one rank of a multi-GPU run before any wire time, measured on ONE GPU with the local transport of
+hns_dist (every rank in this process, a message = a device copy out of the peer's send buffer; plan, launch ranges, pack /
+unpack kernels, communication stream and events exactly as with RCCL).
+
+  argv: config (256 | 128 | plume1024 ...)  world  [sweeps_per_exchange]   [--partition: split ONE config domain]
+
+Weak scaling (default): `world` slabs of the config stacked along x. All ranks share the device, so the device time of a
+lockstep substep is compared with world x the plain single-GPU substep of one slab: their ratio is the per-rank overhead
+(ghost sweeps, split launches, pack/unpack, copies). Host enqueue time per rank per substep is measured separately."""
+import json
 import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from hnanosolver_amd import api, device as D, dist as HD, fields  # noqa: E402
 
-config = sys.argv[1] if len(sys.argv) > 1 else "256"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+config = args[0] if args else "256"
+world = int(args[1]) if len(args) > 1 else 2
+k = int(args[2]) if len(args) > 2 else 0
+partition = "--partition" in sys.argv
 iters, dt = 50, 1.0 / 24.0
 origins, R = fields.config_leaves(config)
 vs = 1.0 / R
-
-f = fields.synthetic_fields(origins, R)
-grid = api.create_grid_from_leaves(origins, vs)
-sim = D.Sim(grid, ["density"])
-sim.upload({"vel": f["vel"], "density": f["density"]})
-st = D.current_stream()
 
 
 def timed(fn, n=10, warm=3):
@@ -36,33 +39,57 @@ def timed(fn, n=10, warm=3):
     return 1e3 * (time.perf_counter() - t0) / n
 
 
+f = fields.synthetic_fields(origins, R)
+grid = api.create_grid_from_leaves(origins, vs)
+sim = D.Sim(grid, ["density"])
+sim.upload({"vel": f["vel"], "density": f["density"]})
+st = D.current_stream()
 single = timed(lambda: sim.core_substep(iters, dt, vs, st))
+sim.close()
 
-runner = HD.SlabBench(origins, R, 0, 2, iters, dt)
-halo = runner.solver.halo
-counts = {"exchanges": 0}
-
-
-def loopback(fields_, mirror=True):
-    sends, recvs = halo.pack_sends(fields_, mirror), halo.recv_targets(fields_, mirror)
-    for q, dst in recvs.items():
-        src = sends[q]
-        n = min(src.numel(), dst.numel())
-        dst.view(-1)[:n].copy_(src.view(-1)[:n])
-    halo.finish(fields_, mirror)
-    counts["exchanges"] += 1
-
-
-halo.exchange = loopback
-rank = timed(runner.step)
-per_step = counts["exchanges"] / 13
-# host-only cost of the driver: same calls, GPU work excluded by timing the enqueue phase only
+glob = origins if partition else HD.slab_domain(origins, R, world)
+ranks = [HD.DistRank(glob, world, r, vs, n_scalars=1, sweeps_per_exchange=k) for r in range(world)]
+HD.DistRank.connect_local(ranks)
+for d in ranks:
+    own = glob[d.first_owned:d.first_owned + d.n_owned].copy()
+    if not partition:
+        own[:, 0] %= R
+    g = fields.synthetic_fields(own, R)
+    d.upload(g["vel"], [g["density"]])
+# one rank alone, its messages looped back to itself (wrong data, right sizes): the production structure of one GPU's work
+lone_rank = 0 if world < 3 else world // 2  # a rank with neighbours on both sides where there is one
+lone = HD.DistRank(glob, world, lone_rank, vs, n_scalars=1, sweeps_per_exchange=k)
+lone.connect_loopback()
+own = glob[lone.first_owned:lone.first_owned + lone.n_owned].copy()
+if not partition:
+    own[:, 0] %= R
+g = fields.synthetic_fields(own, R)
+lone.upload(g["vel"], [g["density"]])
+alone = timed(lambda: lone.core_substep(iters, dt, st))
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(5):
-    runner.step()
-enqueue = 1e3 * (time.perf_counter() - t0) / 5
+    lone.core_substep(iters, dt, st)
+alone_enqueue = 1e3 * (time.perf_counter() - t0) / 5
+lone.synchronize(st)
+alone_info = lone.info()
+lone.close()
+lock = timed(lambda: HD.DistRank.local_core_substep(ranks, iters, dt, st))
 torch.cuda.synchronize()
-print({"config": config, "single_gpu_ms": round(single, 3), "rank_of_2_loopback_ms": round(rank, 3), "host_enqueue_ms": round(enqueue, 3),
-       "exchanges_per_substep": round(per_step, 1), "ghost_leaves": int(runner.plan.n_local - runner.plan.n_owned), "owned_leaves": int(runner.plan.n_owned),
-       "efficiency_upper_bound": round(single / rank, 3)})
+t0 = time.perf_counter()
+for _ in range(5):
+    HD.DistRank.local_core_substep(ranks, iters, dt, st)
+enqueue = 1e3 * (time.perf_counter() - t0) / 5 / world
+torch.cuda.synchronize()
+info = [d.info() for d in ranks]
+work = single if partition else world * single
+print(json.dumps({
+    "config": config, "world": world, "partition": partition, "sweeps_per_exchange": info[0]["sweeps_per_exchange"],
+    "single_gpu_substep_ms": round(single, 3), "all_ranks_lockstep_ms": round(lock, 3), "same_work_on_one_grid_ms": round(work, 3),
+    "lockstep_overhead": round(lock / work - 1.0, 4), "lockstep_host_enqueue_ms_per_rank_per_substep": round(enqueue, 3),
+    "one_rank_loopback": {"rank": lone_rank, "owned_leaves": alone_info["boundary_leaves"] + alone_info["interior_leaves"], "substep_ms": round(alone, 3),
+                          "host_enqueue_ms": round(alone_enqueue, 3),
+                          "overhead_vs_single_gpu_per_leaf": round((alone / (alone_info["boundary_leaves"] + alone_info["interior_leaves"])) / (single / len(origins) * (world if partition else 1)) - 1.0, 4)},
+    "rank0": {x: info[0][x] for x in ("boundary_leaves", "interior_leaves", "ghost_leaves", "peers", "exchanges", "messages_sent", "bytes_sent")},
+    "max_bytes_sent_per_rank_per_substep": max(sum(i["bytes_sent"].values()) for i in info),
+}))

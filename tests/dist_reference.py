@@ -1,0 +1,159 @@
+"""TEST INFRASTRUCTURE: a CPU walk through the native multi-GPU plan.
+
+`ReferenceRank` executes the phases of hns_dist.hip's core substep (same order, same launch ranges [boundary | interior |
+ghosts], same halo regions -- taken from the library's own plan, DistRank(plan_only=True)) with the ORACLE as the compute
+engine and torch.distributed (gloo) as the wire. It exists to prove, without a GPU, that the plan's regions and exchange
+points are sufficient: owned results must be bit-identical to the single-domain oracle run. The HIP path is tied to the
+same single-domain answer by tests/test_dist_gpu.py.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from hnanosolver_amd import dist as HD
+
+X_ADV, X_D1, X_DIV, X_P = 0, 1, 2, 3
+
+
+class ReferenceRank:
+    def __init__(self, global_origins, world, rank, voxel_size, n_scalars, k, group=None, poison=None):
+        from oracle_lib import OracleGrid
+
+        self.plan = HD.DistRank(global_origins, world, rank, voxel_size, n_scalars, k, plan_only=True)
+        self.world, self.rank, self.k, self.group = world, rank, self.plan.info()["sweeps_per_exchange"], group
+        info = self.plan.info()
+        self.nB, self.nI, self.nG = info["boundary_leaves"], info["interior_leaves"], info["ghost_leaves"]
+        self.local_global = self.plan.local_leaves()
+        self.peers = self.plan.peers()
+        lo = np.ascontiguousarray(np.asarray(global_origins, dtype=np.int32).reshape(-1, 3)[self.local_global])
+        self.G = OracleGrid(lo)
+        z = np.flatnonzero(self.local_global == 0)
+        self.G.set_outside_element(int(z[0]) * 512 if len(z) else 0)
+        n = len(self.local_global) * 512
+        fill = 0.0 if poison is None else poison  # poison: ghosts start with garbage that the exchanges must repair
+        self.u = np.full((n, 3), fill, dtype=np.float32)
+        self.adv = np.zeros((n, 3), dtype=np.float32)
+        self.div, self.p_a, self.p_b = (np.zeros(n, dtype=np.float32) for _ in range(3))
+        self.phi = [np.full(n, fill, dtype=np.float32) for _ in range(n_scalars)]
+        self.phi_next = [np.zeros(n, dtype=np.float32) for _ in range(n_scalars)]
+        self.vs = float(np.float32(voxel_size))
+        self.inv_dx = float(np.float32(1.0) / np.float32(voxel_size))
+        self.omega = HD.omega_compute(voxel_size)
+        self.pending = None
+        self.phi_in_flight = self.u_fresh = False
+        self.bytes_sent = 0
+        self.ranges = {"B": (0, self.nB), "I": (self.nB, self.nB + self.nI), "A": (0, len(self.local_global))}
+
+    def load_owned(self, vel, scalars):
+        """owned leaves in ascending global order -> local order [B | I]"""
+        first = int(self.local_global[: self.nB + self.nI].min()) if self.nB + self.nI else 0
+        for l in range(self.nB + self.nI):
+            src = int(self.local_global[l]) - first
+            self.u[l * 512:(l + 1) * 512] = vel[src * 512:(src + 1) * 512]
+            for s, a in zip(self.phi, scalars):
+                s[l * 512:(l + 1) * 512] = a[src * 512:(src + 1) * 512]
+
+    def owned(self, a):
+        """local [B | I] -> ascending global order"""
+        n = self.nB + self.nI
+        order = np.argsort(self.local_global[:n], kind="stable")
+        return np.concatenate([a[l * 512:(l + 1) * 512] for l in order]) if n else a[:0]
+
+    def _put(self, dst, full, rng):
+        a, b = self.ranges[rng]
+        dst[a * 512:b * 512] = full[a * 512:b * 512]
+
+    # ---- exchange ----
+    def post(self, typ, fields):
+        import torch
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return
+        assert self.pending is None
+        reqs, recvs = [], []
+        for p in self.peers:
+            s, r = p.send[typ], p.recv[typ]
+            comps = sum(f.shape[1] if f.ndim == 2 else 1 for f in fields)
+            if s.voxels:
+                idx = s.voxel_index()
+                msg = torch.from_numpy(np.concatenate([np.ascontiguousarray(f.reshape(len(f), -1)[idx]).reshape(-1) for f in fields]))
+                self.bytes_sent += msg.numel() * 4
+                reqs.append(dist.isend(msg, p.rank, group=self.group))
+            if r.voxels:
+                buf = torch.empty(r.voxels * comps, dtype=torch.float32)
+                reqs.append(dist.irecv(buf, p.rank, group=self.group))
+                recvs.append((r, buf))
+        self.pending = (reqs, recvs, fields)
+
+    def complete(self):
+        if self.pending is None:
+            return
+        reqs, recvs, fields = self.pending
+        for q in reqs:
+            q.wait()
+        for r, buf in recvs:
+            idx, pos = r.voxel_index(), 0
+            b = buf.numpy()
+            for f in fields:
+                c = f.shape[1] if f.ndim == 2 else 1
+                f.reshape(len(f), -1)[idx] = b[pos:pos + c * r.voxels].reshape(r.voxels, c)
+                pos += c * r.voxels
+        self.pending = None
+
+    # ---- kernels on a launch range ----
+    def sweep(self, src, dst, rng):
+        p = src.copy()
+        self.G.rbgs(self.div, p, self.vs, 0, self.omega)
+        self.G.rbgs(self.div, p, self.vs, 1, self.omega)
+        self._put(dst, p, rng)
+
+    def core_substep(self, iterations, dt):
+        G, k = self.G, self.k
+        if not self.phi_in_flight:
+            self.post(X_ADV, ([] if self.u_fresh else [self.u]) + self.phi)
+        self.complete()
+        adv = G.advect_vector(self.u, dt, self.inv_dx)
+        self._put(self.adv, adv, "B")
+        self.post(X_D1, [self.adv])
+        self._put(self.adv, adv, "I")
+        self.complete()
+        div = G.divergence(self.adv, self.inv_dx)
+        self._put(self.div, div, "B")
+        self.post(X_DIV, [self.div])
+        self._put(self.div, div, "I")
+        self.complete()
+        self.p_a[:] = 0.0
+        src, dst, it = self.p_a, self.p_b, 0
+        while it < iterations:
+            n = min(k, iterations - it)
+            for _ in range(n - 1):
+                self.sweep(src, dst, "A")
+                src, dst = dst, src
+                it += 1
+            last = it + 1 == iterations
+            p = src.copy()
+            G.rbgs(self.div, p, self.vs, 0, self.omega)
+            G.rbgs(self.div, p, self.vs, 1, self.omega)
+            self._put(dst, p, "B")
+            self.post(X_D1 if last else X_P, [dst])
+            self._put(dst, p, "I")
+            src, dst = dst, src
+            it += 1
+            self.complete()
+        self.p = src
+        u = G.subtract_pressure_gradient(self.adv, self.p, self.inv_dx)
+        self._put(self.u, u, "B")
+        self.post(X_ADV, [self.u])
+        self._put(self.u, u, "I")
+        self.complete()
+        self.u_fresh = True
+        if self.phi:
+            out = G.advect_scalars(self.u, self.phi, dt, self.inv_dx)
+            for d, o in zip(self.phi_next, out):
+                self._put(d, o, "B")
+            self.post(X_ADV, self.phi_next)
+            for d, o in zip(self.phi_next, out):
+                self._put(d, o, "I")
+            self.phi, self.phi_next = self.phi_next, self.phi
+            self.phi_in_flight = self.world > 1

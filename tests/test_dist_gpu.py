@@ -1,6 +1,8 @@
-"""GPU check of the multi-rank building blocks on ONE device: the HIP engine with ghost leaves (n_active, outside
-element, pack kernel) driven in lockstep for 2 and 3 emulated ranks, exchanging through in-process tensor copies.
-Owned results must be bit-identical to the single-grid device run (which the other GPU tests tie to the oracle)."""
+"""The native multi-GPU path (csrc/hns_dist.hip) on ONE device: every rank of a decomposition lives in this process and a
+message is a device copy out of the peer's send buffer (hns_dist_connect_local) -- same plan, launch ranges, pack/unpack
+kernels, communication stream and events as the RCCL transport. Owned results must be bit-identical to the single-grid
+device run (which tests/test_fullsize_gpu.py ties to the oracle), including BASELINE.json configs[4]: the 1024^3-extent
+plume split into 8 leaf ranges."""
 import numpy as np
 import pytest
 
@@ -10,138 +12,144 @@ from hnanosolver_amd import fields
 pytestmark = pytest.mark.gpu
 
 
-def lockstep_exchange(solvers, field_lists):
-    """What HaloExchanger.exchange does over the wire, done with device copies between the emulated ranks."""
-    sends = [s.halo.pack_sends(fl) for s, fl in zip(solvers, field_lists)]
-    recvs = [s.halo.recv_targets(fl) for s, fl in zip(solvers, field_lists)]
-    for r, rv in enumerate(recvs):
-        for q, dst in rv.items():
-            dst.copy_(sends[q][r])
-    for s, fl in zip(solvers, field_lists):
-        s.halo.finish(fl)
-
-
-@pytest.mark.parametrize("name,world", [("dense32", 2), ("plume", 3)])
-def test_emulated_ranks_match_single_grid(name, world):
-    import torch
-
+def single_grid(origins, R, names, iters, substeps, dt=1.0 / 24.0):
     from hnanosolver_amd import api, device as D
 
-    if name == "dense32":
-        origins, R = fields.dense_leaves(32), 32
-    else:
-        origins, R = fields.plume_leaves(8, 1.5, 0.35), 64
     f = fields.synthetic_fields(origins, R)
-    vs, dt, iters = 1.0 / R, 1.0 / 24.0, 7
-
-    # single grid on the device
-    grid = api.create_grid_from_leaves(origins, vs)
-    sim = D.Sim(grid, ["density", "temperature"])
-    arrays = {"vel": f["vel"].copy(), "density": f["density"].copy(), "temperature": f["temperature"].copy()}
+    grid = api.create_grid_from_leaves(origins, 1.0 / R)
+    sim = D.Sim(grid, names)
+    arrays = {"vel": f["vel"].copy(), **{n: f[n].copy() for n in names}}
     sim.upload(arrays)
-    for _ in range(2):
-        sim.core_substep(iters, dt, vs, D.current_stream())
+    for _ in range(substeps):
+        sim.core_substep(iters, dt, 1.0 / R, D.current_stream())
     sim.download(arrays)
-
-    solvers = []
-    for r in range(world):
-        plan = HD.make_plan(origins, world, r)
-        eng = HD.HipEngine(plan.local_origins, plan.n_owned, vs)
-        sol = HD.DistributedSolver(plan, eng, vs, n_scalars=2)
-        loc = np.concatenate([plan.owned_global, plan.ghost_global])
-        sel = (loc[:, None] * 512 + np.arange(512)[None, :]).reshape(-1)
-        vel, den, tem = f["vel"][sel].copy(), f["density"][sel].copy(), f["temperature"][sel].copy()
-        g0 = plan.n_owned * 512
-        vel[g0:], den[g0:], tem[g0:] = 9.0, -1.0, 4.0  # stale ghosts: the first exchange must repair them
-        sol.load_local(vel, [den, tem])
-        solvers.append(sol)
-
-    for _ in range(2):  # DistributedSolver.core_substep, stage by stage, all ranks in lockstep
-        lockstep_exchange(solvers, [[s.u] + s.phi for s in solvers])
-        for s in solvers:
-            s.e.advect_vector(s.u, s.adv, dt, s.inv_dx)
-        lockstep_exchange(solvers, [[s.adv] for s in solvers])
-        for s in solvers:
-            s.e.divergence(s.adv, s.div, s.inv_dx)
-        lockstep_exchange(solvers, [[s.div] for s in solvers])
-        for s in solvers:
-            s.p_a.zero_()
-            s.p_b.zero_()
-            s._src, s._dst = s.p_a, s.p_b
-        for _it in range(iters):
-            exch = (_it + 1) % HD.DistributedSolver.SWEEPS_PER_EXCHANGE == 0 or _it + 1 == iters
-            for s in solvers:
-                s.e.rbgs_iteration(s.div, s._src, s._dst, s.vs, s.omega, include_ghosts=not exch)
-            if exch:
-                lockstep_exchange(solvers, [[s._dst] for s in solvers])
-            for s in solvers:
-                s._src, s._dst = s._dst, s._src
-        for s in solvers:
-            s.p = s._src
-            s.e.subtract_pressure_gradient(s.adv, s.p, s.u, s.inv_dx)
-        lockstep_exchange(solvers, [[s.u] for s in solvers])
-        for s in solvers:
-            s.e.advect_scalars(s.u, s.phi, s.phi_next, dt, s.inv_dx)
-            s.phi, s.phi_next = s.phi_next, s.phi
-    torch.cuda.synchronize()
-    for s in solvers:
-        own = s.plan.owned_global
-        sel = (own[:, None] * 512 + np.arange(512)[None, :]).reshape(-1)
-        u = s.owned(s.u).cpu().numpy()
-        assert np.array_equal(u, arrays["vel"][sel]), f"rank {s.plan.rank} velocity"
-        assert np.array_equal(s.owned(s.phi[0]).cpu().numpy(), arrays["density"][sel]), f"rank {s.plan.rank} density"
-        assert np.array_equal(s.owned(s.phi[1]).cpu().numpy(), arrays["temperature"][sel]), f"rank {s.plan.rank} temperature"
+    return f, arrays
 
 
-def test_world_size_one_solver_equals_sim():
+def run_local(origins, R, world, k, names, iters, substeps, dt=1.0 / 24.0):
     import torch
 
-    from hnanosolver_amd import api, device as D
+    f = fields.synthetic_fields(origins, R)
+    ranks = [HD.DistRank(origins, world, r, 1.0 / R, n_scalars=len(names), sweeps_per_exchange=k) for r in range(world)]
+    HD.DistRank.connect_local(ranks)
+    b = HD.partition_bounds(len(origins), world)
+    for r, d in enumerate(ranks):
+        sl = slice(b[r] * 512, b[r + 1] * 512)
+        d.upload(f["vel"][sl], [f[n][sl] for n in names])
+    stream = int(torch.cuda.current_stream().cuda_stream)
+    for _ in range(substeps):
+        HD.DistRank.local_core_substep(ranks, iters, dt, stream)
+    for d in ranks:
+        d.synchronize(stream)
+    return ranks, b
+
+
+def check(ranks, b, want, names):
+    for r, d in enumerate(ranks):
+        got = d.download()
+        sl = slice(b[r] * 512, b[r + 1] * 512)
+        assert np.array_equal(got["vel"], want["vel"][sl]), f"rank {r} velocity"
+        for n, a in zip(names, got["scalars"]):
+            assert np.array_equal(a, want[n][sl]), f"rank {r} {n}"
+
+
+def scattered_leaves():
+    rng = np.random.default_rng(5)
+    lat = np.stack(np.meshgrid(*[np.arange(-6, 6)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    o = (lat[rng.random(len(lat)) < 0.5] * 8).astype(np.int32)
+    return np.ascontiguousarray(o[fields.nanovdb_order(o)])
+
+
+@pytest.mark.parametrize("name,world,k", [("dense32", 2, 4), ("plume", 3, 2), ("scattered", 5, 1), ("plume", 8, 3), ("dense32", 4, 0)])
+def test_local_ranks_match_single_grid(name, world, k):
+    origins, R = {"dense32": (fields.dense_leaves(32), 32), "plume": (fields.plume_leaves(8, 1.5, 0.35), 64), "scattered": (scattered_leaves(), 96)}[name]
+    names, iters, substeps = ["density", "temperature"], 7, 2
+    _, want = single_grid(origins, R, names, iters, substeps)
+    ranks, b = run_local(origins, R, world, k, names, iters, substeps)
+    check(ranks, b, want, names)
+    info = [d.info() for d in ranks]
+    assert all(i["sweeps_per_exchange"] == (k or 4) for i in info)
+    assert sum(i["boundary_leaves"] + i["interior_leaves"] for i in info) == len(origins)
+    assert all(sum(i["bytes_sent"].values()) > 0 for i in info if i["peers"])
+
+
+def test_plume1024_in_8_ranges_matches_single_grid():
+    """BASELINE.json configs[4]: the 1024^3-extent sparse plume (65,944 leaves) as the 8-GPU decomposition -- 8 contiguous
+    leaf ranges, each with its ghost layer, boundary-first launch ranges and voxel-granular halo messages -- emulated on one
+    device, 50 iterations, against the single-grid run of the same substep."""
+    origins, R = fields.config_leaves("plume1024")
+    names, iters = ["density"], 50
+    _, want = single_grid(origins, R, names, iters, 1)
+    ranks, b = run_local(origins, R, 8, 0, names, iters, 1)
+    check(ranks, b, want, names)
+    info = [d.info() for d in ranks]
+    assert max(i["peers"] for i in info) <= 7 and min(i["boundary_leaves"] for i in info) > 0
+    # payload accounting: the pressure loop dominates; with k = 4 that is 12 refreshes of depth 8 plus the final depth-1 one
+    for i in info:
+        assert i["exchanges"] == 1 + 1 + 1 + 13 + 1 + 1
+        assert i["bytes_sent"]["p"] == 12 * 4 * i["region_voxels_sent"]["p"]
+
+
+def test_new_fields_between_substeps_and_many_substeps():
+    """upload after a substep (the scalars already posted for the next substep are dropped), then more substeps"""
+    origins, R = fields.plume_leaves(8, 1.5, 0.35), 64
+    names, iters = ["density"], 5
+    _, want = single_grid(origins, R, names, iters, 3)
+    ranks, b = run_local(origins, R, 3, 2, names, iters, 2)  # two substeps on fields that are then replaced
+    import torch
+
+    f = fields.synthetic_fields(origins, R)
+    for r, d in enumerate(ranks):
+        sl = slice(b[r] * 512, b[r + 1] * 512)
+        d.upload(f["vel"][sl], [f["density"][sl]])
+    stream = int(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        HD.DistRank.local_core_substep(ranks, iters, 1.0 / 24.0, stream)
+    for d in ranks:
+        d.synchronize(stream)
+    check(ranks, b, want, names)
+
+
+def test_world_size_one_equals_sim():
+    import torch
 
     origins, R = fields.dense_leaves(32), 32
-    f = fields.synthetic_fields(origins, R)
-    vs, dt, iters = 1.0 / R, 1.0 / 24.0, 5
-    plan = HD.make_plan(origins, 1, 0)
-    sol = HD.DistributedSolver(plan, HD.HipEngine(plan.local_origins, plan.n_owned, vs), vs, n_scalars=1)
-    sol.load_local(f["vel"], [f["density"]])
-    sol.core_substep(iters, dt)
-    grid = api.create_grid_from_leaves(origins, vs)
-    sim = D.Sim(grid, ["density"])
-    arrays = {"vel": f["vel"].copy(), "density": f["density"].copy()}
-    sim.upload(arrays)
-    sim.core_substep(iters, dt, vs, D.current_stream())
-    sim.download(arrays)
-    torch.cuda.synchronize()
-    assert np.array_equal(sol.u.cpu().numpy(), arrays["vel"])
-    assert np.array_equal(sol.phi[0].cpu().numpy(), arrays["density"])
-
-
-def test_slab_bench_driver_single_rank():
-    """bench.py's multi-GPU driver, exercised with world = 1 (its halo exchange is then a no-op)."""
-    import torch
-
-    b = HD.SlabBench(fields.dense_leaves(32), 32, 0, 1, 5, 1.0 / 24.0)
-    b.step()
-    b.timing_on()
-    b.step()
-    b.step()
-    ms, launches = b.pressure_time()
-    assert launches == 10 and ms > 0.0
-    torch.cuda.synchronize()
-    assert torch.isfinite(b.solver.u).all()
-
-
-def test_partitioned_bench_driver_matches_the_slab_driver_at_world_one():
-    """bench.py --partition splits ONE domain across the ranks (BASELINE.json's 1024^3-extent configuration); with one
-    rank both drivers run the same substeps on the same leaves."""
-    import torch
-
-    o = fields.plume_leaves(8, 1.0, 0.3)
-    a = HD.SlabBench(o, 64, 0, 1, 6, 1.0 / 24.0)
-    b = HD.SlabBench(o, 64, 0, 1, 6, 1.0 / 24.0, partition=True)
+    names, iters = ["density"], 5
+    f, want = single_grid(origins, R, names, iters, 2)
+    d = HD.DistRank(origins, 1, 0, 1.0 / R, n_scalars=1)
+    d.upload(f["vel"], [f["density"]])
+    stream = int(torch.cuda.current_stream().cuda_stream)
     for _ in range(2):
-        a.step()
-        b.step()
-    torch.cuda.synchronize()
-    assert torch.equal(a.solver.u, b.solver.u) and torch.equal(a.solver.phi[0], b.solver.phi[0])
-    assert b.plan.n_owned == len(o)
+        d.core_substep(iters, 1.0 / 24.0, stream)
+    d.synchronize(stream)
+    got = d.download(pressure=True)
+    assert np.array_equal(got["vel"], want["vel"]) and np.array_equal(got["scalars"][0], want["density"])
+    assert np.isfinite(got["pressure"]).all() and got["pressure"].any()
+    i = d.info()
+    assert i["peers"] == 0 and i["ghost_leaves"] == 0 and i["boundary_leaves"] == 0
+
+
+def test_unconnected_ranks_refuse_to_step():
+    import hnanosolver_amd as H
+
+    origins = fields.dense_leaves(16)
+    d = HD.DistRank(origins, 2, 0, 1.0 / 16)
+    f = fields.synthetic_fields(origins[: d.n_owned], 16)
+    d.upload(f["vel"], [f["density"]])
+    with pytest.raises(H.HNSError):
+        d.core_substep(3, 1.0 / 24.0)
+
+
+@pytest.mark.parametrize("partition", [False, True])
+def test_bench_driver_single_rank(partition):
+    """bench.py's multi-GPU driver with world = 1 (no peers): runs, times its pressure loop, equals the single grid."""
+    o, R = fields.plume_leaves(8, 1.0, 0.3), 64
+    b = HD.SlabBench(o, R, 0, 1, 6, 1.0 / 24.0, partition=partition)
+    b.step()
+    b.timing_on(4)
+    b.step()
+    ms, sweeps = b.pressure_time()
+    assert sweeps == 6 and ms > 0.0
+    _, want = single_grid(o, R, ["density"], 6, 2)
+    got = b.rank_obj.download()
+    assert np.array_equal(got["vel"], want["vel"]) and np.array_equal(got["scalars"][0], want["density"])
