@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "libhns.so")
+# HNS_LIBRARY: another build of the same library (A/B measurements of kernel variants, profiles/micro/exp)
+_LIB_PATH = os.environ.get("HNS_LIBRARY") or os.path.join(_HERE, "lib", "libhns.so")
 
 HNS_OK = 0
 HNS_ERR_INVALID_ARGUMENT = -1
@@ -74,6 +75,7 @@ SIGNATURES = {
     "hns_grid_matches": (_i, [_vp, _vp, _u64, C.c_uint]),
     "hns_grid_export_nanovdb": (_i, [_vp, _vp, _u64, _vp]),
     "hns_grid_launch_tables": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "hns_grid_tile_tables": (_i, [_vp, _vp, _vp, _vp, _vp, _ip, _ip]),
     "hns_compute_sim": (_i, [_vp, C.POINTER(hns_field), _i, _i, _f, _f, C.POINTER(hns_combustion_params), _i, _vp]),
     "hns_advect_index_grid": (_i, [_vp, C.POINTER(hns_field), _i, _f, _f, _vp]),
     "hns_advect_index_grid_velocity": (_i, [_vp, C.POINTER(hns_field), _i, _f, _f, _vp]),

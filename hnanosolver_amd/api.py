@@ -169,6 +169,15 @@ class IndexGridHandle:
         _raise(lib.hns_grid_coords(self._ptr, out.ctypes.data))
         return out
 
+    def tile_tables(self):
+        """(groups [n_groups, tile_y*tile_z], rest [n_rest], (tile_y, tile_z)): the blocked SOR kernel's record groups"""
+        ng, nr, ty, tz = C.c_uint64(0), C.c_uint64(0), C.c_int(0), C.c_int(0)
+        _raise(lib.hns_grid_tile_tables(self._ptr, None, None, C.byref(ng), C.byref(nr), C.byref(ty), C.byref(tz)))
+        groups = np.zeros((ng.value, ty.value * tz.value), dtype=np.int32)
+        rest = np.zeros(nr.value, dtype=np.int32)
+        _raise(lib.hns_grid_tile_tables(self._ptr, groups.ctypes.data, rest.ctypes.data, None, None, None, None))
+        return groups, rest, (ty.value, tz.value)
+
     def set_active_leaves(self, n: int) -> None:
         _raise(lib.hns_grid_set_active_leaves(self._ptr, int(n)))
 

@@ -25,13 +25,14 @@ inline int fail(int code, const char* msg) {
 // ---- options (hns_set_option) -------------------------------------------------------------------------------------
 // Alternative kernel forms and data-movement strategies kept for A/B measurement and as cross-checks of the default one.
 // Every entry point reads the current value when it is called, so a test or benchmark can switch forms between calls.
-enum { kRbgsAuto = 0, kRbgsColor = 1, kRbgsWave = 2, kRbgsPair = 3, kRbgsResident = 4 };
+enum { kRbgsAuto = 0, kRbgsColor = 1, kRbgsWave = 2, kRbgsPair = 3, kRbgsResident = 4, kRbgsTile = 5 };
 enum { kScheduleAuto = 0, kScheduleLinear = 1, kScheduleChunk = 2 };
 struct Options {
-	std::atomic<int> rbgs{kRbgsAuto};          // "rbgs": auto | color | wave | pair | resident
+	std::atomic<int> rbgs{kRbgsAuto};          // "rbgs": auto | color | wave | pair | resident | tile
 	std::atomic<int> advect_generic{0};        // "advect": auto | generic (64-bit addressed kernels)
 	std::atomic<int> stencil_block{0};         // "stencil": auto | block (512-thread divergence / gradient)
 	std::atomic<int> schedule{kScheduleAuto};  // "schedule": auto | linear | chunk (read when launch tables are built)
+	std::atomic<int> schedule_segment{0};      // "schedule_segment": leaves per XCD segment of the launch order, 0 = by size
 	std::atomic<int> alternate{1};             // "alternate": odd SOR sweeps walk the records backwards
 	std::atomic<int> rev{1};                   // "rev": divergence / advect_scalars walk the leaves backwards
 	std::atomic<int> graph{0};                 // "graph": replay the pressure loop as a hipGraph
@@ -100,6 +101,14 @@ struct RbgsGraph {
 
 struct hns_sim;
 
+namespace hns {
+#ifndef HNS_TILE_Y  // (overridable for A/B builds: profiles/micro/exp/build.sh)
+#define HNS_TILE_Y 2
+#define HNS_TILE_Z 2
+#endif
+constexpr int kTileY = HNS_TILE_Y, kTileZ = HNS_TILE_Z;  // wave records per workgroup of the blocked SOR kernel: y x z (powers of two)
+}
+
 struct hns_grid {
 	hns::Topology topo;
 	float voxel_size = 1.0f;
@@ -120,6 +129,12 @@ struct hns_grid {
 	void* d_arena = nullptr;      // the one device allocation all of the above are slices of (arena pool, hns_api.hip)
 	size_t arena_bytes = 0;
 	uint64_t n_pairs = 0, n_singles = 0;  // waves to launch / how many of them carry a lone leaf
+	// blocked SOR kernel: complete kTileY x kTileZ groups of wave records (record indices, kTileY*kTileZ per group) and the
+	// records outside them; built by hns_grid_build_tiles
+	void* d_tile_groups = nullptr;
+	void* d_tile_rest = nullptr;
+	void* d_tile_mem = nullptr;
+	uint64_t n_tile_groups = 0, n_tile_rest = 0;
 	std::vector<hns::RbgsGraph> graphs;  // cached hipGraph replays of the pressure loop (dropped when the schedule changes)
 	void* cap_stream = nullptr;          // private capture stream
 	std::mutex graph_mutex;              // guards graphs / cap_stream
@@ -147,4 +162,5 @@ extern "C" __attribute__((visibility("hidden"))) void hns_arena_put(void* p, siz
 int hns_grid_upload(hns_grid* g);           // device build of every table from topo.origins
 void hns_grid_free_device(hns_grid* g);
 int hns_grid_upload_schedule(hns_grid* g);  // launch-order tables for the current n_active
+int hns_grid_build_tiles(hns_grid* g);      // tile groups of the blocked SOR kernel for the current wave records
 int hns_grid_host_tables(const hns_grid* g);  // make topo.nbr27 / topo.hash valid on the host

@@ -393,9 +393,9 @@ struct PairLaneCtx {
 	int ew, ea, eb;
 };
 
-__device__ __forceinline__ PairLaneCtx pair_lane_ctx() {
+__device__ __forceinline__ PairLaneCtx pair_lane_ctx(int lane) {
 	PairLaneCtx c;
-	c.l = threadIdx.x;
+	c.l = lane;
 	c.x = c.l >> 3, c.y = c.l & 7;
 	c.par = (c.x + c.y) & 1;  // false: even z red, true: odd z red (both leaves: their z origins differ by 8)
 	c.w = c.l >> 5;
@@ -409,20 +409,35 @@ __device__ __forceinline__ PairLaneCtx pair_lane_ctx() {
 	return c;
 }
 
+// Blocked form (k_rbgs_tile): which faces of this wave's record belong to another wave of the same workgroup (its index in
+// the workgroup, -1 = nobody: the halo comes from memory as in the one-wave form). Wave-uniform.
+struct TileNbr {
+	int ym, yp, zm, zp;
+	bool zm_single;  // the wave below carries a lone leaf: its top leaf is its tile 0
+};
+
 // issue every global load of one pair (no waits here: the values are consumed in pair_compute).
 // ZERO: p_in is known to be 0 everywhere (first iteration of a solve, which is never warm-started: HNanoSolver.cu:113),
-// so none of it is read; only div is.
-template <bool ZERO>
+// so none of it is read; only div is. TILED: faces listed in `nb` are not loaded at all.
+template <bool ZERO, bool TILED>
 __device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __restrict__ rec, const float* __restrict__ div,
-                                            const float* __restrict__ p_in) {
+                                            const float* __restrict__ p_in, const TileNbr& nb) {
 	PairIn in;
 	// record: {leaf0, nbr27 of leaf0, leaf1, nbr27 of leaf1}; leaf1 is the +z neighbour of leaf0
 	in.leaf0 = __builtin_amdgcn_readfirstlane(rec[0]);
 	in.leaf1 = __builtin_amdgcn_readfirstlane(rec[28]);
 	const bool single = in.leaf1 < 0;
 	// below the lower leaf / above the top leaf (the top leaf is leaf0 itself when it travels alone)
-	const int n_zm = __builtin_amdgcn_readfirstlane(rec[1 + 12]);
-	const int n_zp = __builtin_amdgcn_readfirstlane(single ? rec[1 + 14] : rec[28 + 1 + 14]);
+#if defined(HNS_EXP) && (HNS_EXP & 16)
+	const int n_zm = -1, n_zp = -1;
+#elif defined(HNS_EXP) && (HNS_EXP & 32)  // z halo read out of the wave's OWN leaves: same access pattern, no foreign lines
+	const int n_zm = in.leaf0, n_zp = single ? in.leaf0 : in.leaf1;
+#else
+	// (TILED: a face shared inside the workgroup counts as absent here -- the loads stay branch-free, hit the always-hot
+	// leaf 0 and are discarded; the real values arrive through LDS in pair_compute)
+	const int n_zm = (TILED && nb.zm >= 0) ? -1 : __builtin_amdgcn_readfirstlane(rec[1 + 12]);
+	const int n_zp = (TILED && nb.zp >= 0) ? -1 : __builtin_amdgcn_readfirstlane(single ? rec[1 + 14] : rec[28 + 1 + 14]);
+#endif
 	const int l = c.l;
 	const RowP zero_row = {{v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}}};
 	in.D0 = glb_rowp(div, in.leaf0, l), in.D1 = glb_rowp(div, in.leaf1, l);
@@ -431,6 +446,10 @@ __device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __r
 		in.zlo = in.zhi = make_float2(0.0f, 0.0f);
 	} else {
 		in.P0 = glb_rowp(p_in, in.leaf0, l), in.P1 = glb_rowp(p_in, in.leaf1, l);
+#if defined(HNS_EXP) && (HNS_EXP & 128)  // own rows first, halo only once they have landed (are the neighbours' lines in L2 by then?)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+#endif
 		in.zlo = *reinterpret_cast<const float2*>(p_in + (size_t)(n_zm < 0 ? 0 : n_zm) * 512 + l * 8 + 6);
 		in.zhi = *reinterpret_cast<const float2*>(p_in + (size_t)(n_zp < 0 ? 0 : n_zp) * 512 + l * 8);
 		if (n_zm < 0) in.zlo = make_float2(0.0f, 0.0f);
@@ -454,20 +473,33 @@ __device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __r
 	const int nf1 = f == 0 ? b0 : (f == 1 ? b1 : (f == 2 ? b2 : b3));
 	const int ne0 = f == 0 ? c0 : (f == 1 ? c1 : (f == 2 ? c2 : c3));
 	const int ne1 = f == 0 ? d0 : (f == 1 ? d1 : (f == 2 ? d2 : d3));
-	const int n_f = c.w ? (single ? -1 : nf1) : nf0;
+	// a y-face row of a neighbour inside the workgroup is that wave's own row: nothing to load or recompute (absent, as above)
+	const bool shared_duty = TILED && ((f == 2 && nb.ym >= 0) || (f == 3 && nb.yp >= 0));
+	const int n_f = shared_duty ? -1 : (c.w ? (single ? -1 : nf1) : nf0);
+#ifdef HNS_EXP  // timing experiments only (profiles/micro/exp): pretend some halo sources are absent; results are wrong
+	const int own_leaf = c.w ? (single ? in.leaf0 : in.leaf1) : in.leaf0;
+	const int n_f_p = ((HNS_EXP & 1) && f < 2) || ((HNS_EXP & 4) && f >= 2) ? -1 : (((HNS_EXP & 64) && f >= 2) ? own_leaf : n_f);
+	const int n_f_d = ((HNS_EXP & 2) && f < 2) || ((HNS_EXP & 8) && f >= 2) ? -1 : (((HNS_EXP & 64) && f >= 2) ? own_leaf : n_f);
+#else
+	const int n_f_p = n_f, n_f_d = n_f;
+#endif
 	const int srcA = f == 0 ? 56 + i : (f == 1 ? i : (f == 2 ? i * 8 + 7 : i * 8));
 	const int srcB = f == 0 ? 48 + i : (f == 1 ? 8 + i : (f == 2 ? i * 8 + 6 : i * 8 + 1));
 	in.f_ok = n_f >= 0;
-	in.HD = glb_rowp(div, n_f, srcA);
+	in.HD = glb_rowp(div, n_f_d, srcA);
 	if (ZERO) {
 		in.HA = in.HB = in.ER = zero_row;
 		in.e_val = 0.0f;
 		return in;
 	}
-	in.HA = glb_rowp(p_in, n_f, srcA);
-	in.HB = glb_rowp(p_in, n_f, srcB);
+	in.HA = glb_rowp(p_in, n_f_p, srcA);
+	in.HB = glb_rowp(p_in, n_f_p, srcB);
 	// the halo row's own z-neighbour outside the pair: z=-1 for the lower leaf, z=8 for the upper leaf
-	const int n_e = c.w ? ne1 : ne0;
+#ifdef HNS_EXP
+	const int n_e = (((HNS_EXP & 1) && f < 2) || ((HNS_EXP & 4) && f >= 2)) ? -1 : (c.w ? ne1 : ne0);
+#else
+	const int n_e = shared_duty ? -1 : (c.w ? ne1 : ne0);
+#endif
 	const float ev = p_in[(size_t)(n_e < 0 ? 0 : n_e) * 512 + srcA * 8 + (c.w ? 0 : 7)];
 	in.e_val = n_e < 0 ? 0.0f : ev;
 	// edge rows along z (lanes 0..7): tile rows (-1,-1), (-1,8), (8,-1), (8,8) of each leaf
@@ -476,22 +508,44 @@ __device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __r
 	return in;
 }
 
-// stage, red sweep, black sweep, store: one full iteration for one pair from registers `in`
-__device__ __forceinline__ void pair_compute(PairTile& S, const PairLaneCtx& c, const PairIn& in, float* __restrict__ p_out, const float dx2,
-                                             const float omega) {
+// stage, red sweep, black sweep, store: one full iteration for one pair from registers `in`.
+// TILED (k_rbgs_tile): `tiles` holds one tile per wave of the workgroup, S = tiles[own]. A face listed in `nb` is read out
+// of the neighbouring wave's tile -- its staged rows before the red sweep, its updated rows after it -- instead of being
+// loaded and recomputed here: the same values (a wave's recomputed halo reds ARE the neighbour's own reds), so the same bits.
+template <bool TILED>
+__device__ __forceinline__ void pair_compute(PairTile* tiles, PairTile& S, const PairLaneCtx& c, PairIn in, const TileNbr& nb, float* __restrict__ p_out,
+                                             const float dx2, const float omega) {
 	const int l = c.l, w = c.w, I = c.I;
 	const bool par = c.par;
 	const bool single = in.leaf1 < 0;  // wave-uniform
+	// lateral -y / +y rows of the own rows: the neighbouring wave's rows (x,7) / (x,0) where that face is shared
+	const bool red_ym = TILED && c.y == 0 && nb.ym >= 0, red_yp = TILED && c.y == 7 && nb.yp >= 0;
+	const PairTile& Tym = red_ym ? tiles[nb.ym] : S;
+	const PairTile& Typ = red_yp ? tiles[nb.yp] : S;
+	const int R_ym = red_ym ? I + 7 : c.R_ym, R_yp = red_yp ? I - 7 : c.R_yp;
 	// ---- stage ----
 	pt_put(S, 0, I, in.P0);
 	pt_put(S, 1, I, in.P1);
-	S.ZM[I] = in.zlo.y;
-	S.ZP[I] = in.zhi.x;
+	// p just below / above the pair, per row: from memory, or written here by the wave below / above when that face is shared
+	if (!TILED || nb.zm < 0) S.ZM[I] = in.zlo.y;
+	if (!TILED || nb.zp < 0) S.ZP[I] = in.zhi.x;
+	if (TILED && nb.zp >= 0) tiles[nb.zp].ZM[I] = single ? in.P0.q[3].y : in.P1.q[3].y;
+	if (TILED && nb.zm >= 0) tiles[nb.zm].ZP[I] = in.P0.q[0].x;
 	pt_put(S, w, c.RA, in.HA);
 	pt_put(S, w, c.RB, in.HB);
 	(w ? S.ZP : S.ZM)[c.RA] = in.e_val;
 	if (l < 8) pt_put(S, c.ew, 81 + c.ea * 2 + c.eb, in.ER);
 	__syncthreads();
+	if (TILED) {  // p just outside the pair along z, from the waves below / above
+		if (nb.zm >= 0) {
+			const float4 t = tiles[nb.zm].HI[nb.zm_single ? 0 : 1][I];
+			in.zlo = make_float2(t.z, t.w);
+		}
+		if (nb.zp >= 0) {
+			const float4 t = tiles[nb.zp].LO[0][I];
+			in.zhi = make_float2(t.x, t.y);
+		}
+	}
 
 	// ---- phase R ----
 	RowP hnew, c0, c1;
@@ -504,38 +558,43 @@ __device__ __forceinline__ void pair_compute(PairTile& S, const PairLaneCtx& c, 
 		hnew = row_sweep(hxp, hxm, hyp, hym, in.HA, below, above, in.HD, dx2, omega, !c.hpar, in.f_ok);
 	}
 	{
-		const RowP xm = pt_row(S, 0, c.R_xm), xp = pt_row(S, 0, c.R_xp), ym = pt_row(S, 0, c.R_ym), yp = pt_row(S, 0, c.R_yp);
+		const RowP xm = pt_row(S, 0, c.R_xm), xp = pt_row(S, 0, c.R_xp), ym = pt_row(Tym, 0, R_ym), yp = pt_row(Typ, 0, R_yp);
 		c0 = row_sweep(xp, xm, yp, ym, in.P0, in.zlo.y, single ? in.zhi.x : in.P1.q[0].x, in.D0, dx2, omega, !par, true);
 	}
 	{
-		const RowP xm = pt_row(S, 1, c.R_xm), xp = pt_row(S, 1, c.R_xp), ym = pt_row(S, 1, c.R_ym), yp = pt_row(S, 1, c.R_yp);
+		const RowP xm = pt_row(S, 1, c.R_xm), xp = pt_row(S, 1, c.R_xp), ym = pt_row(Tym, 1, R_ym), yp = pt_row(Typ, 1, R_yp);
 		c1 = row_sweep(xp, xm, yp, ym, in.P1, in.P0.q[3].y, in.zhi.x, in.D1, dx2, omega, !par, !single);
 	}
 	{
 		// z-halo red voxel: (x,y,-1) under leaf0 when par, else (x,y,8) over leaf1
 		const float* ZA = par ? S.ZM : S.ZP;
-		zc = sor_update(ZA[c.R_xp], ZA[c.R_xm], ZA[c.R_yp], ZA[c.R_ym], par ? in.P0.q[0].x : in.zhi.y, par ? in.zlo.x : (single ? in.P0.q[3].y : in.P1.q[3].y), in.d_zh,
+		const float zyp = (par ? Typ.ZM : Typ.ZP)[R_yp], zym = (par ? Tym.ZM : Tym.ZP)[R_ym];  // (the neighbouring wave's row across a shared y face)
+		zc = sor_update(ZA[c.R_xp], ZA[c.R_xm], zyp, zym, par ? in.P0.q[0].x : in.zhi.y, par ? in.zlo.x : (single ? in.P0.q[3].y : in.P1.q[3].y), in.d_zh,
 		                par ? in.zlo.y : in.zhi.x, dx2, omega);
 	}
 	// values just outside each row after the red sweep
-	const float below0 = (par && in.zh_ok) ? zc : in.zlo.y;
-	const float above1 = (!par && in.zh_ok) ? zc : in.zhi.x;
+	float below0 = (par && in.zh_ok) ? zc : in.zlo.y;
+	float above1 = (!par && in.zh_ok) ? zc : in.zhi.x;
 	__syncthreads();  // phase-R reads complete before the rows are overwritten
 	pt_put(S, 0, I, c0);
 	pt_put(S, 1, I, c1);
 	pt_put(S, w, c.RA, hnew);
 	__syncthreads();
+	if (TILED) {  // ... which inside the workgroup are the neighbouring waves' freshly swept rows
+		if (nb.zm >= 0) below0 = tiles[nb.zm].HI[nb.zm_single ? 0 : 1][I].w;
+		if (nb.zp >= 0) above1 = tiles[nb.zp].LO[0][I].x;
+	}
 
 	// ---- phase B ----
 	{
-		const RowP xm = pt_row(S, 0, c.R_xm), xp = pt_row(S, 0, c.R_xp), ym = pt_row(S, 0, c.R_ym), yp = pt_row(S, 0, c.R_yp);
+		const RowP xm = pt_row(S, 0, c.R_xm), xp = pt_row(S, 0, c.R_xp), ym = pt_row(Tym, 0, R_ym), yp = pt_row(Typ, 0, R_yp);
 		const RowP o = row_sweep(xp, xm, yp, ym, c0, below0, single ? above1 : c1.q[0].x, in.D0, dx2, omega, par, true);
 		float4* q = reinterpret_cast<float4*>(p_out + (size_t)in.leaf0 * 512 + l * 8);
 		q[0] = make_float4(o.q[0].x, o.q[0].y, o.q[1].x, o.q[1].y);
 		q[1] = make_float4(o.q[2].x, o.q[2].y, o.q[3].x, o.q[3].y);
 	}
 	if (!single) {
-		const RowP xm = pt_row(S, 1, c.R_xm), xp = pt_row(S, 1, c.R_xp), ym = pt_row(S, 1, c.R_ym), yp = pt_row(S, 1, c.R_yp);
+		const RowP xm = pt_row(S, 1, c.R_xm), xp = pt_row(S, 1, c.R_xp), ym = pt_row(Tym, 1, R_ym), yp = pt_row(Typ, 1, R_yp);
 		const RowP o = row_sweep(xp, xm, yp, ym, c1, c0.q[3].y, above1, in.D1, dx2, omega, par, true);
 		float4* q = reinterpret_cast<float4*>(p_out + (size_t)in.leaf1 * 512 + l * 8);
 		q[0] = make_float4(o.q[0].x, o.q[0].y, o.q[1].x, o.q[1].y);
@@ -545,11 +604,12 @@ __device__ __forceinline__ void pair_compute(PairTile& S, const PairLaneCtx& c, 
 
 // `last`: index of the last record when this sweep walks the list backwards (odd sweeps of a solve), else -1. Beyond the
 // Infinity Cache a sweep ends with the tail of the arrays cached; the next one starts there.
+// `list` (optional): the records to sweep, by index (the records the blocked kernel leaves over); null = all, in order.
 template <bool ZERO>
-__global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs, const float* __restrict__ div, const float* __restrict__ p_in,
-                                                  float* __restrict__ p_out, const float dx2, const float omega, const int last) {
+__global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs, const int* __restrict__ list, const float* __restrict__ div,
+                                                  const float* __restrict__ p_in, float* __restrict__ p_out, const float dx2, const float omega, const int last) {
 	__shared__ __attribute__((aligned(16))) PairTile S;
-	const PairLaneCtx c = pair_lane_ctx();
+	const PairLaneCtx c = pair_lane_ctx(threadIdx.x);
 	// backwards = rows of eight records in reverse order, the position inside a row kept: workgroup b still lands on XCD
 	// b % 8, whose L2 holds that chunk's leaves from the previous sweep when the grid is small enough (128^3: all of it)
 	unsigned rec = blockIdx.x;
@@ -557,10 +617,67 @@ __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs,
 		const unsigned rows = ((unsigned)last + 1u) >> 3;
 		if ((rec >> 3) < rows) rec = ((rows - 1u - (rec >> 3)) << 3) | (rec & 7u);
 	}
-	const PairIn in = pair_load<ZERO>(c, pairs + (size_t)rec * 56, div, p_in);
-	pair_compute(S, c, in, p_out, dx2, omega);
+	if (list) rec = (unsigned)list[rec];
+	const TileNbr nb = {-1, -1, -1, -1, false};
+	const PairIn in = pair_load<ZERO, false>(c, pairs + (size_t)rec * 56, div, p_in, nb);
+	pair_compute<false>(&S, S, c, in, nb, p_out, dx2, omega);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// red-black SOR, blocked form: kTileY x kTileZ wave records per workgroup, shared faces through LDS
+// ---------------------------------------------------------------------------------------------------------------
+//
+// What bounds k_rbgs_pair once the sweep arrays leave the Infinity Cache is not the 12 B/voxel it must move but the halo: the
+// y faces (64-byte pieces) and z faces (8-byte pieces at a 32-byte stride, i.e. every line of the neighbouring leaf) of
+// leaves whose own wave runs elsewhere on the chip (measured with the halo sources switched off one by one,
+// profiles/micro/exp: 512^3 433 us -> 377 without the y faces, 361 without the z faces, 275 without any halo). Here the
+// wave records that are each other's y / z neighbours form one workgroup (groups built on the device, hns_gridbuild.hip:
+// k_group_assign) and a face between two of them never touches memory: before the red sweep a wave reads the neighbour's
+// staged rows out of its LDS tile, after it the neighbour's updated rows -- exactly the values it would otherwise load and
+// recompute. Outer faces of the group, and all x faces (contiguous 256-byte rows, cheap), work as in the one-wave form.
+template <bool ZERO>
+__global__ __launch_bounds__(64 * kTileY * kTileZ) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_rbgs_tile(const int* __restrict__ pairs, const int* __restrict__ groups, const float* __restrict__ div,
+                                                                    const float* __restrict__ p_in, float* __restrict__ p_out, const float dx2, const float omega,
+                                                                    const int last) {
+	constexpr int W = kTileY * kTileZ;
+	__shared__ __attribute__((aligned(16))) PairTile S[W];
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // slot a * kTileZ + c of this wave in the group
+	const PairLaneCtx c = pair_lane_ctx(threadIdx.x & 63);
+	unsigned grp = blockIdx.x;
+	if (last >= 0) {
+		const unsigned rows = ((unsigned)last + 1u) >> 3;
+		if ((grp >> 3) < rows) grp = ((rows - 1u - (grp >> 3)) << 3) | (grp & 7u);
+	}
+	const int* __restrict__ members = groups + (size_t)grp * W;
+	const int* __restrict__ rec = pairs + (size_t)members[wv] * 56;
+	const int a = wv / kTileZ, cz = wv % kTileZ;
+	const int leaf1 = rec[28];
+	const bool single = leaf1 < 0;
+	// a face is shared only if the slot next door holds exactly the neighbouring leaves (the grouping goes by coordinates
+	// alone: z-runs that pair up differently, or a lone leaf beside a pair, sit in the right slots without being neighbours)
+	TileNbr nb = {-1, -1, -1, -1, false};
+	if (a > 0) {
+		const int* q = pairs + (size_t)members[wv - kTileZ] * 56;
+		if (q[0] == rec[1 + 10] && (single ? q[28] < 0 : q[28] == rec[29 + 10])) nb.ym = wv - kTileZ;
+	}
+	if (a + 1 < kTileY) {
+		const int* q = pairs + (size_t)members[wv + kTileZ] * 56;
+		if (q[0] == rec[1 + 16] && (single ? q[28] < 0 : q[28] == rec[29 + 16])) nb.yp = wv + kTileZ;
+	}
+	if (cz > 0) {
+		const int* q = pairs + (size_t)members[wv - 1] * 56;
+		const int top = q[28] < 0 ? q[0] : q[28];
+		if (top == rec[1 + 12]) nb.zm = wv - 1, nb.zm_single = q[28] < 0;
+	}
+	if (cz + 1 < kTileZ) {
+		const int* q = pairs + (size_t)members[wv + 1] * 56;
+		if (q[0] == (single ? rec[1 + 14] : rec[29 + 14])) nb.zp = wv + 1;
+	}
+	nb.ym = __builtin_amdgcn_readfirstlane(nb.ym), nb.yp = __builtin_amdgcn_readfirstlane(nb.yp);
+	nb.zm = __builtin_amdgcn_readfirstlane(nb.zm), nb.zp = __builtin_amdgcn_readfirstlane(nb.zp);
+	const PairIn in = pair_load<ZERO, true>(c, rec, div, p_in, nb);
+	pair_compute<true>(S, S[wv], c, in, nb, p_out, dx2, omega);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // subtractPressureGradient (reference Kernel.cu:765-829 / :694-762)
@@ -773,8 +890,12 @@ static int rbgs_form(const hns_grid* g, int opt) {
 	if (opt == kRbgsColor || opt == kRbgsWave) return opt;
 	if (!g->d_pairs) return kRbgsWave;
 	if (opt == kRbgsPair) return kRbgsPair;
+	if (opt == kRbgsTile) return g->d_tile_groups ? kRbgsTile : kRbgsPair;
 	// (<= 2048: also the boundary range of a multi-GPU rank, a few thousand leaves swept next to the interior launch)
 	if (g->n_active <= 2048 || (g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs)) return kRbgsWave;
+	// far beyond the Infinity Cache the halo of leaves swept elsewhere on the chip is what costs: blocked form where most
+	// records sit in complete groups (512^3: 428 -> 379 us per sweep; no gain on the ragged 66k-leaf plume, none in cache)
+	if (g->n_active > 100000 && g->d_tile_groups && g->n_tile_groups * (uint64_t)(kTileY * kTileZ) * 10 >= g->n_pairs * 9) return kRbgsTile;
 	return kRbgsPair;
 }
 
@@ -790,11 +911,24 @@ static int launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* di
 		hipLaunchKernelGGL(k_rbgs_color, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, dst, dx2, omega, 1);
 	} else if (form == kRbgsWave) {
 		hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_active), dim3(64), 0, st, gd, div, src, dst, dx2, omega);
+	} else if (form == kRbgsTile) {
+		// complete groups through the blocked kernel, the records outside them through the one-wave kernel (disjoint leaves, both
+		// read src and write dst: any order)
+		const dim3 tb(64 * kTileY * kTileZ);
+		const int* recs = (const int*)g->d_pairs;
+		const int glast = backwards ? (int)g->n_tile_groups - 1 : -1, rlast = backwards ? (int)g->n_tile_rest - 1 : -1;
+		if (src_is_zero) {
+			if (g->n_tile_groups) hipLaunchKernelGGL(k_rbgs_tile<true>, dim3((unsigned)g->n_tile_groups), tb, 0, st, recs, (const int*)g->d_tile_groups, div, src, dst, dx2, omega, glast);
+			if (g->n_tile_rest) hipLaunchKernelGGL(k_rbgs_pair<true>, dim3((unsigned)g->n_tile_rest), dim3(64), 0, st, recs, (const int*)g->d_tile_rest, div, src, dst, dx2, omega, rlast);
+		} else {
+			if (g->n_tile_groups) hipLaunchKernelGGL(k_rbgs_tile<false>, dim3((unsigned)g->n_tile_groups), tb, 0, st, recs, (const int*)g->d_tile_groups, div, src, dst, dx2, omega, glast);
+			if (g->n_tile_rest) hipLaunchKernelGGL(k_rbgs_pair<false>, dim3((unsigned)g->n_tile_rest), dim3(64), 0, st, recs, (const int*)g->d_tile_rest, div, src, dst, dx2, omega, rlast);
+		}
 	} else if (src_is_zero) {
-		hipLaunchKernelGGL(k_rbgs_pair<true>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, src, dst, dx2, omega, last);
+		hipLaunchKernelGGL(k_rbgs_pair<true>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, (const int*)nullptr, div, src, dst, dx2, omega, last);
 	} else {
 		// one launch: the record list holds the z-adjacent pairs and, as {leaf, nbr27, -1, ...}, the leaves that found no partner
-		hipLaunchKernelGGL(k_rbgs_pair<false>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, div, src, dst, dx2, omega, last);
+		hipLaunchKernelGGL(k_rbgs_pair<false>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, (const int*)nullptr, div, src, dst, dx2, omega, last);
 	}
 	return HNS_OK;
 }
@@ -820,7 +954,7 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 	const float dx2 = dx * dx;  // Kernel.cu:608
 	const GridDev gd = g->dev();
 	const int form = rbgs_form(g, options().rbgs.load());
-	if (from_zero && form != kRbgsPair) {  // the other forms read their input: give them the zeros
+	if (from_zero && form != kRbgsPair && form != kRbgsTile) {  // the other forms read their input: give them the zeros
 		HNS_HIP(hipMemsetAsync(p_a, 0, sizeof(float) * 512 * (size_t)g->topo.n_leaves, (hipStream_t)stream));
 		from_zero = false;
 	}

@@ -60,10 +60,12 @@ int hns_trim_memory(void);
  * (all of them produce the same bits; tests/test_kernel_variants_gpu.py). Process-wide, read by every entry point when it
  * is called. value = NULL restores the default. Names and values:
  *   "rbgs"          auto | color (two launches per iteration) | wave (one wave per leaf) | pair (one wave per z-adjacent leaf
- *                   pair) | resident (whole pressure loop in one launch, small grids)
+ *                   pair) | tile (y / z neighbouring pairs share a workgroup and their faces) | resident (whole pressure
+ *                   loop in one launch, small grids)
  *   "advect"        auto | generic (64-bit addressed advection kernels)
  *   "stencil"       auto | block (512-thread divergence and gradient kernels)
  *   "schedule"      auto | linear | chunk (workgroup -> leaf order; takes effect when a grid's launch tables are next built)
+ *   "schedule_segment" N leaves per XCD segment of the launch order under "schedule" = auto (0 = by grid size)
  *   "alternate"     1 | 0 (odd SOR sweeps walk the wave records backwards)
  *   "rev"           1 | 0 (divergence and advect_scalars walk the leaves backwards)
  *   "graph"         0 | 1 (replay the pressure loop as a hipGraph)
@@ -127,6 +129,10 @@ int hns_grid_export_nanovdb(const hns_grid*, void* buffer, uint64_t capacity, ui
 /* Copies of the device-built launch tables (inspection / tests; any argument may be NULL): sched = n_active leaf ids in
  * workgroup order; wave_records = n_waves x 56 int32 {leaf0, nbr27[27], leaf1 or -1, nbr27[27]} read by the SOR kernel. */
 int hns_grid_launch_tables(const hns_grid*, int32_t* sched, int32_t* wave_records, uint64_t* n_waves, uint64_t* n_lone);
+/* The blocked SOR kernel's groups: n_groups x (tile_y * tile_z) wave-record indices (slot a * tile_z + c: record whose first
+ * leaf has (y/8) mod tile_y = a, (z/16) mod tile_z = c, all in one aligned window) and the n_rest records outside complete
+ * groups, swept by the one-wave kernel. Any argument may be NULL. */
+int hns_grid_tile_tables(const hns_grid*, int32_t* groups, int32_t* rest, uint64_t* n_groups, uint64_t* n_rest, int* tile_y, int* tile_z);
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Drop-in operators (host pointers in, results in place, synchronous)                                           */

@@ -85,6 +85,55 @@ def test_device_tables_match_host_builder(name):
     host.reset()
 
 
+def expected_sched_segments(n, seg):
+    """launch order with XCD segments of `seg` leaves: whole rows of eight segments, the remainder one chunk per XCD"""
+    body = (n // (8 * seg)) * 8 * seg
+    b = np.arange(body)
+    x, i = b % 8, b // 8
+    head = ((i // seg) * 8 + x) * seg + i % seg
+    return np.concatenate([head, body + expected_sched(n - body)]).astype(np.int32)
+
+
+@pytest.mark.parametrize("seg", [1, 16, 100])
+def test_segment_schedule(seg):
+    import hnanosolver_amd as H
+
+    origins = fields.plume_leaves(32, 2.5, 0.22)
+    H.set_option("schedule_segment", seg)
+    try:
+        g = api.create_grid_from_leaves(origins, 0.1)
+    finally:
+        H.set_option("schedule_segment", None)
+    n = len(origins)
+    sched, recs, lone = g.launch_tables()
+    assert np.array_equal(np.sort(sched), np.arange(n))
+    assert np.array_equal(sched, expected_sched_segments(n, seg))
+    exp_recs, exp_lone = expected_waves(g.neighbor_table(), n, sched)
+    assert np.array_equal(recs, exp_recs) and lone == exp_lone
+    g.reset()
+
+
+@pytest.mark.parametrize("name", ["dense64", "plume", "scattered_dense", "single"])
+def test_tile_groups(name):
+    """Blocked SOR kernel: every wave record is in exactly one complete group or in the rest list; a group's members sit in
+    the slots their first leaf's coordinates dictate, inside one aligned window, at one x."""
+    origins = LEAF_SETS[name]()
+    g = api.create_grid_from_leaves(origins, 0.1)
+    _, recs, _ = g.launch_tables()
+    groups, rest, (ty, tz) = g.tile_tables()
+    assert np.array_equal(np.sort(np.concatenate([groups.reshape(-1), rest])), np.arange(len(recs)))
+    o = origins[recs[:, 0]]
+    for grp in groups:
+        og = o[grp]
+        assert len(set(og[:, 0].tolist())) == 1
+        for s, oo in enumerate(og):
+            assert (oo[1] >> 3) % ty == s // tz and (oo[2] >> 4) % tz == s % tz
+        assert len({(oo[1] >> 3) // ty for oo in og}) == 1 and len({(oo[2] >> 4) // tz for oo in og}) == 1
+    if name == "dense64":
+        assert len(rest) == 0 and len(groups) * ty * tz == len(recs)
+    g.reset()
+
+
 def test_active_prefix_rebuilds_launch_tables():
     origins = fields.plume_leaves(8, 1.0, 0.3)
     g = api.create_grid_from_leaves(origins, 0.1)

@@ -48,7 +48,7 @@ class FusedSorKernels(HipKernels):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["auto", "wave", "pair"])
+@pytest.mark.parametrize("form", ["auto", "wave", "pair", "tile"])
 def test_fused_sor_forms_known_sweep(form):
     """the closed-form two-iteration answer through the production (fused) SOR kernels"""
     import hnanosolver_amd as H

@@ -49,6 +49,7 @@ VARIANTS = {
     "sor_wave_per_leaf": {"rbgs": "wave"},
     "sor_wave_per_leaf_pair": {"rbgs": "pair"},  # the production form at scale; small grids default to one wave per leaf
     "sor_resident": {"rbgs": "resident"},  # whole pressure loop in one launch
+    "sor_blocked": {"rbgs": "tile"},  # wave records that are y / z neighbours share a workgroup and their faces
     "sor_graph_replay": {"graph": "1"},
     "schedule_linear": {"schedule": "linear"},
     "sor_one_direction": {"alternate": "0", "rbgs": "pair"},
