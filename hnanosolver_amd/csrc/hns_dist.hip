@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <initializer_list>
 #include <utility>
 
@@ -223,6 +224,7 @@ struct hns_dist {
 	int* d_perm = nullptr;
 	// streams and events
 	hipStream_t cs = nullptr;
+	std::shared_ptr<void> cs_owner;  // keeps `cs` alive: locally connected ranks all use ONE communication stream (see connect_local)
 	hipEvent_t ev_post[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_ready = nullptr;
 	int parity = 0;
 	Pending pending;
@@ -375,7 +377,7 @@ void hns_dist_destroy(hns_dist* d) {
 		if (d->ev_post[i]) (void)hipEventDestroy(d->ev_post[i]);
 		if (d->ev_done[i]) (void)hipEventDestroy(d->ev_done[i]);
 	}
-	if (d->cs) (void)hipStreamDestroy(d->cs);
+	d->cs_owner.reset();  // destroys the stream with its last user
 	for (hns_grid* g : {d->gB, d->gI, d->gO, d->gA})
 		if (g) hns_grid_destroy(g);
 	if (d->arena) hns_arena_put(d->arena, d->arena_bytes, d->device);
@@ -484,6 +486,7 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 		int lo_prio = 0, hi_prio = 0;
 		(void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
 		if (hipStreamCreateWithPriority(&d->cs, hipStreamNonBlocking, hi_prio) != hipSuccess) return bail(fail(HNS_ERR_HIP, "hns_dist_create: stream creation failed"));
+		d->cs_owner = std::shared_ptr<void>((void*)d->cs, [](void* s) { (void)hipStreamDestroy((hipStream_t)s); });
 	}
 	for (int i = 0; i < 2; ++i)
 		if (hipEventCreateWithFlags(&d->ev_post[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ev_done[i], hipEventDisableTiming) != hipSuccess)
@@ -528,7 +531,18 @@ int hns_dist_connect_local(hns_dist* const* ranks, int world) {
 	for (int r = 0; r < world; ++r)
 		if (!ranks[r] || !ranks[r]->gA || ranks[r]->world != world || ranks[r]->rank != r || ranks[r]->comm || ranks[r]->device != ranks[0]->device)
 			return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_local: ranks[r] must be rank r of this world, unconnected, all on one device");
-	for (int r = 0; r < world; ++r) ranks[r]->local_ranks.assign(ranks, ranks + world);
+	// One communication stream for all of them. The runtime multiplexes streams onto a handful of hardware queues, and a
+	// wait packet blocks everything behind it in its queue: with one communication stream per emulated rank (nine streams in
+	// an 8-rank test) waits of unrelated streams ended up behind one another and the device stalled for minutes at a time.
+	// Two streams -- the caller's and this one -- cannot alias. (One process per GPU, the RCCL case, has two streams anyway.)
+	for (int r = 0; r < world; ++r) {
+		if (r > 0) {
+			HNS_HIP(hipStreamSynchronize(ranks[r]->cs));
+			ranks[r]->cs = ranks[0]->cs;
+			ranks[r]->cs_owner = ranks[0]->cs_owner;
+		}
+		ranks[r]->local_ranks.assign(ranks, ranks + world);
+	}
 	return HNS_OK;
 }
 
