@@ -76,6 +76,10 @@ SIGNATURES = {
     "hns_grid_export_nanovdb": (_i, [_vp, _vp, _u64, _vp]),
     "hns_grid_launch_tables": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "hns_grid_tile_tables": (_i, [_vp, _vp, _vp, _vp, _vp, _ip, _ip]),
+    "hns_gather_leaves": (_i, [_vp, _u64, _vp, _u64, _vp, _i, _i, _vp]),
+    "hns_scatter_leaves": (_i, [_vp, _u64, _i, C.POINTER(C.c_void_p)]),
+    "hns_dilate_leaves": (_i, [_vp, _u64, _vp, _i, _vp, _u64, C.POINTER(C.c_uint64)]),
+    "hns_union_leaves": (_i, [_vp, _u64, _vp, _u64, _vp, _u64, C.POINTER(C.c_uint64)]),
     "hns_compute_sim": (_i, [_vp, C.POINTER(hns_field), _i, _i, _f, _f, C.POINTER(hns_combustion_params), _i, _vp]),
     "hns_advect_index_grid": (_i, [_vp, C.POINTER(hns_field), _i, _f, _f, _vp]),
     "hns_advect_index_grid_velocity": (_i, [_vp, C.POINTER(hns_field), _i, _f, _f, _vp]),

@@ -135,6 +135,29 @@ int hns_grid_launch_tables(const hns_grid*, int32_t* sched, int32_t* wave_record
 int hns_grid_tile_tables(const hns_grid*, int32_t* groups, int32_t* rest, uint64_t* n_groups, uint64_t* n_rest, int* tile_y, int* tile_z);
 
 /* ------------------------------------------------------------------------------------------------------------ */
+/* Either side of the path, without OpenVDB (host code; PARITY UNPINNED: OpenVDB is absent from the build image).   */
+/* What HNS::IndexGridBuilder (src/Utils/GridBuilder.hpp:87-216) and the domain dilation of the HNanoSolver SOP      */
+/* (src/SOP/HNanoSolver/SOP_HNanoSolver.cpp:186-199) do to OpenVDB trees, over raw 8^3 leaf buffers: a leaf is its     */
+/* 8-aligned origin, an optional 512-bit active mask (byte x*8+y, bit z) and 512 values in x<<6|y<<3|z order.          */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+#define HNS_FILL_ZERO 0 /* float / Vec3f sources: a domain leaf the source lacks reads 0 (GridBuilder.hpp:125-129,147-151) */
+#define HNS_FILL_SDF 1  /* SDF sources: filled with BYTES 0x01, i.e. 2.4e-38f, as memset(..., 1, ...) does (:108) */
+/* IndexGridBuilder::build: out[i] = the source leaf at domain_origins[i] (512*ncomp floats), or the fill. Tiles of the
+ * source are ignored, as in the reference (only leaves are probed). */
+int hns_gather_leaves(const int32_t* domain_origins, uint64_t n_domain, const int32_t* src_origins, uint64_t n_src, const float* src_values, int ncomp, int fill,
+                      float* out);
+/* IndexGridBuilder::writeIndexGrid: every domain leaf receives all of its 512 values (:198-211). */
+int hns_scatter_leaves(const float* flat, uint64_t n_domain, int ncomp, float* const* leaf_buffers);
+/* dilateVoxels(padding, NN_FACE_EDGE_VERTEX, IGNORE_TILES) of a leaf set, as a leaf set in OpenVDB leaf order: every leaf
+ * with an active voxel (active_masks: n x 64 bytes, NULL = all active) within `padding_voxels` of its box. out_origins may
+ * be NULL to query *n_out. */
+int hns_dilate_leaves(const int32_t* origins, uint64_t n, const unsigned char* active_masks, int padding_voxels, int32_t* out_origins, uint64_t capacity,
+                      uint64_t* n_out);
+/* topologyUnion of two leaf sets, in OpenVDB leaf order, duplicates removed. */
+int hns_union_leaves(const int32_t* a, uint64_t na, const int32_t* b, uint64_t nb, int32_t* out_origins, uint64_t capacity, uint64_t* n_out);
+
+/* ------------------------------------------------------------------------------------------------------------ */
 /* Drop-in operators (host pointers in, results in place, synchronous)                                           */
 /* ------------------------------------------------------------------------------------------------------------ */
 

@@ -7,6 +7,6 @@ for m in "$@"; do
   case "$m" in *:*) name="${m%%:*}"; flags="$(echo "${m#*:}" | tr ',' ' ')";; esac
   out=../../profiles/micro/exp/libhns_$name.so
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -I../../include $flags -x hip \
-     hns_topology.cpp hns_nanovdb.cpp hns_gridbuild.hip hns_advect.hip hns_pressure.hip hns_pointwise.hip hns_api.hip hns_dist.hip -shared -pthread -ldl -o $out &
+     hns_topology.cpp hns_nanovdb.cpp hns_leafio.cpp hns_gridbuild.hip hns_advect.hip hns_pressure.hip hns_pointwise.hip hns_api.hip hns_dist.hip -shared -pthread -ldl -o $out &
 done
 wait

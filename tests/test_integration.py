@@ -1,0 +1,158 @@
+"""SURVEY.md 8f-2 / 8f-3 as far as this image allows: the reference-side binding (integration/hns_shim.hpp, the template
+bodies of integration/hns_shim.cpp) compiled against this repo's container twin; the SOP operator tables
+(integration/sop_operators.h) against the reference's own .ds text when the checkout is present; and the OpenVDB-free
+gather / scatter / dilation (hns_leafio.cpp, PARITY UNPINNED) against brute force."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from hnanosolver_amd import _lib, fields, leafio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/src/SOP"
+
+
+def build_shim_check(tmp_path):
+    exe = str(tmp_path / "shim_check")
+    libdir = os.path.dirname(_lib.library_path())
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "integration"),
+           "-I" + os.path.join(ROOT, "hnanosolver_amd", "host"), os.path.join(ROOT, "tests", "cpp", "shim_check.cpp"), "-L" + libdir, "-lhns", "-Wl,-rpath," + libdir, "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_reference_side_shim_compiles_against_the_container_interface(tmp_path):
+    build_shim_check(tmp_path)
+
+
+def operator_table(tmp_path):
+    src = tmp_path / "ops.c"
+    src.write_text('#include "sop_operators.h"\n#include <stdio.h>\nint main(void) {\n  printf("[");\n'
+                   '  for (int i = 0; i < HNS_SOP_OPERATOR_COUNT; ++i) {\n    const hns_sop_operator* o = &hns_sop_operators[i];\n'
+                   '    printf("%s{\\"type\\": \\"%s\\", \\"label\\": \\"%s\\", \\"min\\": %d, \\"max\\": %d, \\"parms\\": [", i ? "," : "", o->type_name, o->label, o->min_inputs, o->max_inputs);\n'
+                   '    for (int k = 0; k < o->n_parms; ++k) printf("%s[\\"%s\\", \\"%s\\", \\"%s\\"]", k ? "," : "", o->parms[k].name, o->parms[k].label, o->parms[k].type);\n'
+                   '    printf("]}");\n  }\n  printf("]\\n");\n  return 0;\n}\n')
+    exe = str(tmp_path / "ops")
+    b = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "integration"), str(src), "-o", exe], capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr
+    return json.loads(subprocess.run([exe], capture_output=True, text=True, check=True).stdout)
+
+
+def test_operator_tables(tmp_path):
+    ops = operator_table(tmp_path)
+    assert [o["type"] for o in ops] == ["hnanosolver", "hnanoadvect", "hnanoadvectvelocity", "hnanoprojectnondivergent", "hnanofromgrid"]
+    assert [(o["min"], o["max"]) for o in ops] == [(2, 3), (2, 2), (1, 1), (1, 1), (2, 2)]
+    assert [p[0] for p in ops[0]["parms"]] == ["timestep", "padding", "iterations", "expansion_rate", "temperature_gain", "buoyancy_strength", "ambient_temp",
+                                                 "vorticity", "factor_scale"]
+    if not os.path.isdir(REF):
+        return
+    # with the reference checkout at hand: type name, label, input counts and every parm (name, label, type) equal its .ds text
+    files = {"hnanosolver": "HNanoSolver/SOP_HNanoSolver.cpp", "hnanoadvect": "Advection/SOP_VDBAdvect.cpp",
+             "hnanoadvectvelocity": "VelocityAdvection/SOP_VDBAdvectVelocity.cpp", "hnanoprojectnondivergent": "ProjectNonDivergent/SOP_VDBProjectNonDivergent.cpp",
+             "hnanofromgrid": "ReadWrite/SOP_VDBFromGrid.cpp"}
+    for o in ops:
+        text = open(os.path.join(REF, files[o["type"]])).read()
+        m = re.search(r'new OP_Operator\("(\w+)",\s*"(\w+)",[^;]*?(\d+),\s*(\d+),\s*nullptr', text, re.S)
+        assert (m.group(1), m.group(2), int(m.group(3)), int(m.group(4))) == (o["type"], o["label"], o["min"], o["max"])
+        parms = re.findall(r'parm\s*\{\s*name\s+"(\w+)"\s*label\s+"([^"]+)"\s*type\s+(\w+)', text)
+        assert [list(p) for p in parms] == o["parms"], o["type"]
+
+
+def random_leaves(seed, n=40, span=4):
+    rng = np.random.default_rng(seed)
+    return np.unique(rng.integers(-span, span, size=(n, 3)), axis=0).astype(np.int32) * 8
+
+
+def test_gather_fills_and_scatter():
+    dom = random_leaves(1)
+    dom = dom[fields.nanovdb_order(dom)]
+    src = dom[::2].copy()
+    rng = np.random.default_rng(2)
+    for ncomp in (1, 3):
+        vals = rng.standard_normal((len(src) * 512, ncomp)).astype(np.float32)
+        for fill, byte in ((leafio.FILL_ZERO, 0), (leafio.FILL_SDF, 1)):
+            out = leafio.gather_leaves(dom, src, vals, ncomp, fill).reshape(len(dom), 512 * ncomp)
+            assert np.array_equal(out[::2], vals.reshape(len(src), -1))
+            missing = out[1::2].view(np.uint8)
+            assert (missing == byte).all()  # SDF sources: bytes 0x01 (memset(..., 1, ...), GridBuilder.hpp:108), not 1.0f
+        flat = leafio.gather_leaves(dom, src, vals, ncomp)
+        bufs = leafio.scatter_leaves(flat, len(dom), ncomp)
+        assert np.array_equal(np.concatenate(bufs), flat.reshape(-1))
+    sdf = leafio.gather_leaves(dom, src[:0], np.zeros(0, dtype=np.float32), 1, leafio.FILL_SDF)
+    assert np.all(sdf == np.frombuffer(b"\x01\x01\x01\x01", dtype=np.float32)[0]) and 0 < sdf[0] < 1e-37
+
+
+@pytest.mark.parametrize("padding", [0, 1, 3, 8, 9])
+def test_dilation_against_brute_force(padding):
+    rng = np.random.default_rng(padding)
+    o = random_leaves(10 + padding, n=12, span=3)
+    masks = (rng.random((len(o), 512)) < 0.02)
+    masks[0] = False  # a leaf with no active voxel contributes nothing
+    packed = np.packbits(masks.reshape(len(o), 64, 8), axis=2, bitorder="little").reshape(len(o), 64)
+    got = leafio.dilate_leaves(o, padding, packed)
+    n = np.arange(512)
+    local = np.stack([n >> 6, (n >> 3) & 7, n & 7], -1)
+    vox = np.concatenate([o[i] + local[masks[i]] for i in range(len(o))]).astype(np.int64)
+    want = set()
+    for d in np.stack(np.meshgrid(*[np.arange(-padding, padding + 1)] * 3, indexing="ij"), -1).reshape(-1, 3):
+        want |= set(map(tuple, ((vox + d) >> 3 << 3).tolist()))
+    assert set(map(tuple, got.tolist())) == want and len(got) == len(want)
+    assert np.array_equal(got, got[fields.nanovdb_order(got)])  # OpenVDB / NanoVDB leaf order
+    dense = leafio.dilate_leaves(o, padding)  # no masks: every voxel active
+    lo = set()
+    for c in o.tolist():
+        for d in np.stack(np.meshgrid(*[np.arange(-((padding + 7) // 8), (padding + 7) // 8 + 1)] * 3, indexing="ij"), -1).reshape(-1, 3):
+            lo.add((c[0] + 8 * d[0], c[1] + 8 * d[1], c[2] + 8 * d[2]))
+    assert set(map(tuple, dense.tolist())) == lo
+
+
+def test_union_and_the_solver_domain_recipe():
+    """SOP_HNanoSolver.cpp:186-199: velocity topology, dilated by `padding`, united with the SDF topology -> the index grid"""
+    from hnanosolver_amd import api
+
+    vel_leaves = fields.plume_leaves(8, 1.0, 0.3)
+    sdf_leaves = np.array([[0, 0, 0], [64, 64, 64], [-8, 0, 0]], dtype=np.int32)
+    dom = leafio.union_leaves(leafio.dilate_leaves(vel_leaves, 2), sdf_leaves)
+    assert len(np.unique(dom, axis=0)) == len(dom) and np.array_equal(dom, dom[fields.nanovdb_order(dom)])
+    have = set(map(tuple, dom.tolist()))
+    assert set(map(tuple, vel_leaves.tolist())) <= have and set(map(tuple, sdf_leaves.tolist())) <= have
+    g = api.create_grid_from_leaves(dom, 0.1, _lib.HNS_GRID_HOST_ONLY)  # and it is a valid leaf-dense domain for the solver
+    assert g.leaf_count() == len(dom)
+    with pytest.raises(_lib.HNSError):
+        leafio.dilate_leaves(np.array([[1, 0, 0]], dtype=np.int32), 1)
+
+
+@pytest.mark.gpu
+def test_reference_side_shim_runs_and_matches_the_python_path(tmp_path):
+    from hnanosolver_amd import api
+
+    exe = build_shim_check(tmp_path)
+    R = 32
+    r = subprocess.run([exe, str(R)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    nums = [[float(x) for x in re.findall(r"[-+]?\d\.\d+e[-+]\d+", line)] for line in r.stdout.strip().split("\n")]
+    # the program lists its leaves in plain x, y, z loops (any leaf order is a valid layout: the caller's order defines it)
+    c = fields.leaves_to_coords(np.stack(np.meshgrid(*[np.arange(R // 8) * 8] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.int32))
+    d = api.GridIndexedData()
+    d.allocateCoords(len(c))
+    d.pCoords()[:] = c
+    q = (((c[:, 0] * 7 + c[:, 1] * 3 + c[:, 2]) % 13).astype(np.float32) / np.float32(13.0)).astype(np.float32)
+    for name, v in (("density", q), ("temperature", np.float32(23.0) + np.float32(10.0) * q), ("fuel", np.float32(0.1) * q), ("waste", 0 * q), ("flame", 0 * q)):
+        d.addValueBlock(name, d.FLOAT)
+        d.pValues(name)[:] = v
+    d.addValueBlock("vel", d.VEC3F)
+    d.pValues("vel")[:] = np.stack([np.float32(0.5) * q - np.float32(0.2), np.float32(0.3) * q, np.float32(0.1) - np.float32(0.4) * q], -1)
+    h = api.IndexGridHandle()
+    api.CreateIndexGrid(d, h, 1.0 / R)
+    api.Compute_Sim(d, h, 5, 1.0 / 24.0, 1.0 / R, api.CombustionParams(0, 0, 0, 0, 0, 0), False)
+
+    def checksum(a):
+        a = np.asarray(a, dtype=np.float64).reshape(-1)
+        return float((a * (1 + np.arange(a.size) % 7)).sum())
+
+    assert np.isclose(nums[0][0], checksum(d.pValues("vel")), rtol=1e-12, atol=0) and np.isclose(nums[0][1], checksum(d.pValues("density")), rtol=1e-12, atol=0)
