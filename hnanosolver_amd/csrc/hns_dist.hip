@@ -200,6 +200,7 @@ struct Peer {
 struct Pending {  // an exchange that has been posted and not yet consumed
 	bool active = false;
 	int type = 0, parity = 0;
+	hipStream_t stream = nullptr;  // where its boundary kernel, packing, transfer and unpacking run
 	std::vector<std::pair<float*, int>> fields;  // (device field, ncomp) in message order
 };
 
@@ -233,6 +234,7 @@ struct hns_dist {
 	// transport
 	ncclComm_t comm = nullptr;
 	std::vector<hns_dist*> local_ranks;  // "local" transport: every rank of the decomposition, in this process
+	bool single_stream = false;          // local transport: no communication stream, everything in host order on the caller's stream
 	bool loopback = false;               // timing-only transport: every message is answered out of this rank's own send buffer
 	// statistics of the last substep
 	uint64_t bytes_sent[X_COUNT] = {0, 0, 0, 0}, messages_sent = 0, exchanges = 0;
@@ -480,20 +482,24 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 		}
 		if (rc != HNS_OK) return bail(rc);
 	}
-	{
-		// the communication stream outranks the compute stream: its short kernels (boundary leaves, pack, unpack) must not
-		// queue behind the thousands of waves of the interior kernel they run next to
-		int lo_prio = 0, hi_prio = 0;
-		(void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
-		if (hipStreamCreateWithPriority(&d->cs, hipStreamNonBlocking, hi_prio) != hipSuccess) return bail(fail(HNS_ERR_HIP, "hns_dist_create: stream creation failed"));
-		d->cs_owner = std::shared_ptr<void>((void*)d->cs, [](void* s) { (void)hipStreamDestroy((hipStream_t)s); });
-	}
 	for (int i = 0; i < 2; ++i)
 		if (hipEventCreateWithFlags(&d->ev_post[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ev_done[i], hipEventDisableTiming) != hipSuccess)
 			return bail(fail(HNS_ERR_HIP, "hns_dist_create: event creation failed"));
 	if (hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess) return bail(fail(HNS_ERR_HIP, "hns_dist_create: event creation failed"));
 	if (err) *err = HNS_OK;
 	return d;
+}
+
+// The communication stream exists only where a second stream is used: RCCL and loopback transports. It outranks the compute
+// stream: its short kernels (boundary leaves, pack, unpack) must not queue behind the thousands of waves of the interior
+// kernel they run next to.
+static int ensure_comm_stream(hns_dist* d) {
+	if (d->cs) return HNS_OK;
+	int lo_prio = 0, hi_prio = 0;
+	(void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+	HNS_HIP(hipStreamCreateWithPriority(&d->cs, hipStreamNonBlocking, hi_prio));
+	d->cs_owner = std::shared_ptr<void>((void*)d->cs, [](void* s) { (void)hipStreamDestroy((hipStream_t)s); });
+	return HNS_OK;
 }
 
 int hns_dist_unique_id(void* out128) {
@@ -511,6 +517,7 @@ int hns_dist_connect_rccl(hns_dist* d, const void* unique_id128) {
 	if (!d->gA) return fail(HNS_ERR_NO_DEVICE, "hns_dist_connect_rccl: plan-only handle");
 	if (d->comm || !d->local_ranks.empty()) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_rccl: already connected");
 	HNS_TRY(need_rccl("hns_dist_connect_rccl"));
+	HNS_TRY(ensure_comm_stream(d));
 	ncclUniqueId id;
 	memcpy(&id, unique_id128, sizeof(id));
 	HNS_NCCL(rccl().CommInitRank(&d->comm, d->world, id, d->rank));
@@ -522,6 +529,7 @@ int hns_dist_connect_rccl(hns_dist* d, const void* unique_id128) {
 int hns_dist_connect_loopback(hns_dist* d) {
 	if (!d || !d->gA) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_loopback: bad handle");
 	if (d->comm || !d->local_ranks.empty()) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_loopback: already connected");
+	HNS_TRY(ensure_comm_stream(d));
 	d->loopback = true;
 	return HNS_OK;
 }
@@ -531,16 +539,13 @@ int hns_dist_connect_local(hns_dist* const* ranks, int world) {
 	for (int r = 0; r < world; ++r)
 		if (!ranks[r] || !ranks[r]->gA || ranks[r]->world != world || ranks[r]->rank != r || ranks[r]->comm || ranks[r]->device != ranks[0]->device)
 			return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_local: ranks[r] must be rank r of this world, unconnected, all on one device");
-	// One communication stream for all of them. The runtime multiplexes streams onto a handful of hardware queues, and a
-	// wait packet blocks everything behind it in its queue: with one communication stream per emulated rank (nine streams in
-	// an 8-rank test) waits of unrelated streams ended up behind one another and the device stalled for minutes at a time.
-	// Two streams -- the caller's and this one -- cannot alias. (One process per GPU, the RCCL case, has two streams anyway.)
+	// Locally connected ranks run EVERYTHING on the caller's stream, boundary kernels and messages included. With a
+	// communication stream per emulated rank (nine streams in an 8-rank test) the runtime multiplexed them onto its handful of
+	// hardware queues and the device stalled for minutes at a time, sporadically even with one shared communication stream;
+	// a single stream in host order cannot. The plan, launch ranges, kernels, pack / unpack and message buffers are the ones
+	// the RCCL path uses; its two-stream overlap is exercised by the loopback transport (one rank, two streams).
 	for (int r = 0; r < world; ++r) {
-		if (r > 0) {
-			HNS_HIP(hipStreamSynchronize(ranks[r]->cs));
-			ranks[r]->cs = ranks[0]->cs;
-			ranks[r]->cs_owner = ranks[0]->cs_owner;
-		}
+		ranks[r]->single_stream = true;
 		ranks[r]->local_ranks.assign(ranks, ranks + world);
 	}
 	return HNS_OK;
@@ -590,7 +595,7 @@ static int drain(hns_dist* d, hipStream_t st) {
 	// a posted exchange whose data nobody will consume (new fields are coming): let it finish, then forget it
 	if (d->pending.active) {
 		HNS_HIP(hipStreamSynchronize(st));
-		HNS_HIP(hipStreamSynchronize(d->cs));
+		if (d->cs) HNS_HIP(hipStreamSynchronize(d->cs));
 		d->pending.active = false;
 	}
 	d->phi_in_flight = false;
@@ -671,11 +676,11 @@ int unpack(hns_dist* d, Pending& x) {
 	for (Peer& p : d->peers) {
 		float* msg = p.rbuf[x.parity];
 		for (auto& f : x.fields) {
-			HNS_TRY(halo_copy(false, f.first, f.second, p.recv[x.type], msg, d->cs));
+			HNS_TRY(halo_copy(false, f.first, f.second, p.recv[x.type], msg, x.stream));
 			msg += (size_t)f.second * (size_t)p.recv[x.type].voxels;
 		}
 	}
-	HNS_HIP(hipEventRecord(d->ev_done[x.parity], d->cs));
+	if (!d->single_stream) HNS_HIP(hipEventRecord(d->ev_done[x.parity], x.stream));
 	return HNS_OK;
 }
 
@@ -694,13 +699,17 @@ int post(hns_dist* d, int type, std::vector<std::pair<float*, int>> fields, hipS
 	Pending& x = d->pending;
 	x.active = true, x.type = type, x.parity = d->parity, x.fields = std::move(fields);
 	d->parity ^= 1;
-	HNS_HIP(hipEventRecord(d->ev_ready, st));
-	HNS_HIP(hipStreamWaitEvent(d->cs, d->ev_ready, 0));
-	HNS_TRY(boundary(d->cs));
+	const hipStream_t cs = d->single_stream ? st : d->cs;
+	x.stream = cs;
+	if (!d->single_stream) {
+		HNS_HIP(hipEventRecord(d->ev_ready, st));
+		HNS_HIP(hipStreamWaitEvent(cs, d->ev_ready, 0));
+	}
+	HNS_TRY(boundary(cs));
 	for (Peer& p : d->peers) {
 		float* msg = p.sbuf[x.parity];
 		for (auto& f : x.fields) {
-			HNS_TRY(halo_copy(true, f.first, f.second, p.send[type], msg, d->cs));
+			HNS_TRY(halo_copy(true, f.first, f.second, p.send[type], msg, cs));
 			msg += (size_t)f.second * (size_t)p.send[type].voxels;
 		}
 		const size_t fl = message_floats(x, p.send[type]);
@@ -711,18 +720,18 @@ int post(hns_dist* d, int type, std::vector<std::pair<float*, int>> fields, hipS
 		HNS_NCCL(rccl().GroupStart());
 		for (Peer& p : d->peers) {
 			const size_t ns = message_floats(x, p.send[type]), nr = message_floats(x, p.recv[type]);
-			if (ns) HNS_NCCL(rccl().Send(p.sbuf[x.parity], ns, ncclFloat, p.rank, d->comm, d->cs));
-			if (nr) HNS_NCCL(rccl().Recv(p.rbuf[x.parity], nr, ncclFloat, p.rank, d->comm, d->cs));
+			if (ns) HNS_NCCL(rccl().Send(p.sbuf[x.parity], ns, ncclFloat, p.rank, d->comm, cs));
+			if (nr) HNS_NCCL(rccl().Recv(p.rbuf[x.parity], nr, ncclFloat, p.rank, d->comm, cs));
 		}
 		HNS_NCCL(rccl().GroupEnd());
 	} else if (d->loopback) {  // same streams, events and copy sizes as a real exchange, but the payload is this rank's own
-		if (const int us = options().dist_wire_us.load()) hipLaunchKernelGGL(k_wire_delay, dim3(1), dim3(1), 0, d->cs, (long long)us * 100);
+		if (const int us = options().dist_wire_us.load()) hipLaunchKernelGGL(k_wire_delay, dim3(1), dim3(1), 0, cs, (long long)us * 100);
 		for (Peer& p : d->peers) {
 			const size_t nr = std::min(message_floats(x, p.recv[type]), message_floats(x, p.send[type]));
-			if (nr) HNS_HIP(hipMemcpyAsync(p.rbuf[x.parity], p.sbuf[x.parity], sizeof(float) * nr, hipMemcpyDeviceToDevice, d->cs));
+			if (nr) HNS_HIP(hipMemcpyAsync(p.rbuf[x.parity], p.sbuf[x.parity], sizeof(float) * nr, hipMemcpyDeviceToDevice, cs));
 		}
 	} else {
-		HNS_HIP(hipEventRecord(d->ev_post[x.parity], d->cs));  // packed: the peers may pull
+		if (!d->single_stream) HNS_HIP(hipEventRecord(d->ev_post[x.parity], cs));  // packed: the peers may pull
 		return HNS_OK;
 	}
 	return unpack(d, x);
@@ -743,12 +752,12 @@ int complete(hns_dist* d, hipStream_t st) {
 			const size_t nr = message_floats(x, p.recv[x.type]);
 			if (!nr) continue;
 			if (!back || message_floats(x, back->send[x.type]) != nr) return fail(HNS_ERR_RUNTIME, "hns_dist: send/receive plans of two ranks disagree");
-			HNS_HIP(hipStreamWaitEvent(d->cs, q->ev_post[x.parity], 0));
-			HNS_HIP(hipMemcpyAsync(p.rbuf[x.parity], back->sbuf[x.parity], sizeof(float) * nr, hipMemcpyDeviceToDevice, d->cs));
+			if (!d->single_stream) HNS_HIP(hipStreamWaitEvent(x.stream, q->ev_post[x.parity], 0));
+			HNS_HIP(hipMemcpyAsync(p.rbuf[x.parity], back->sbuf[x.parity], sizeof(float) * nr, hipMemcpyDeviceToDevice, x.stream));
 		}
 		HNS_TRY(unpack(d, x));
 	}
-	HNS_HIP(hipStreamWaitEvent(st, d->ev_done[x.parity], 0));
+	if (!d->single_stream) HNS_HIP(hipStreamWaitEvent(st, d->ev_done[x.parity], 0));
 	x.active = false;
 	return HNS_OK;
 }
@@ -917,7 +926,7 @@ int hns_dist_pressure_time(hns_dist* d, float* total_ms, long long* sweeps) {
 int hns_dist_synchronize(hns_dist* d, void* stream) {
 	if (!d) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_synchronize: null handle");
 	HNS_HIP(hipStreamSynchronize((hipStream_t)stream));
-	HNS_HIP(hipStreamSynchronize(d->cs));
+	if (d->cs) HNS_HIP(hipStreamSynchronize(d->cs));
 	return HNS_OK;
 }
 

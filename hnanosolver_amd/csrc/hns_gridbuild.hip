@@ -202,9 +202,13 @@ __global__ __launch_bounds__(256) void k_write_pairs(const int* __restrict__ nbr
 // window -- the head leaf at z = window start, or 8 above it when the z-runs pair up on odd leaf positions. Records whose
 // window has no such leader, and groups with a missing member, are swept by the one-wave kernel instead.
 
-__global__ __launch_bounds__(256) void k_head_index(const int* __restrict__ recs, int n_pairs, int* __restrict__ head_of_leaf) {
+__global__ __launch_bounds__(256) void k_head_index(const int* __restrict__ recs, int n_pairs, int* __restrict__ head_of_leaf, int* __restrict__ wave_of_leaf) {
 	const int p = blockIdx.x * 256 + threadIdx.x;
-	if (p < n_pairs) head_of_leaf[recs[(size_t)p * 56]] = p;
+	if (p >= n_pairs) return;
+	const int l0 = recs[(size_t)p * 56], l1 = recs[(size_t)p * 56 + 28];
+	head_of_leaf[l0] = p;
+	wave_of_leaf[l0] = p;  // which wave record sweeps a leaf (the resident SOR kernel's waves wait for their neighbours' records)
+	if (l1 >= 0) wave_of_leaf[l1] = p;
 }
 
 __global__ __launch_bounds__(256) void k_group_assign(GridDev g, const int* __restrict__ recs, int n_pairs, const int* __restrict__ head_of_leaf, int wy, int wz,
@@ -330,7 +334,8 @@ int hns_grid_build_tiles(hns_grid* g) {
 	HNS_HIP(hipMemsetAsync(members, 0xFF, sizeof(int) * (size_t)np * w, 0));
 	HNS_HIP(hipMemsetAsync(totals, 0, 2 * sizeof(int), 0));
 	const int* recs = (const int*)g->d_pairs;
-	k_head_index<<<nb, 256, 0, 0>>>(recs, np, head_of_leaf);
+	HNS_HIP(hipMemsetAsync(g->d_wave_of_leaf, 0xFF, sizeof(int) * (size_t)nl, 0));
+	k_head_index<<<nb, 256, 0, 0>>>(recs, np, head_of_leaf, (int*)g->d_wave_of_leaf);
 	k_group_assign<<<nb, 256, 0, 0>>>(g->dev(), recs, np, head_of_leaf, kTileY, kTileZ, leader, members);
 	k_group_flags<<<nb, 256, 0, 0>>>(leader, members, np, w, lead_flag, rest_flag);
 	k_flag_counts<<<nb, 256, 0, 0>>>(lead_flag, np, counts);
@@ -363,7 +368,7 @@ int hns_grid_upload(hns_grid* g) {
 	const size_t n_blocks = (nl + 255) / 256;
 	auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
 	const size_t tw = (size_t)kTileY * kTileZ;
-	const size_t sz[10] = {pad(16 * nl),                        // origins (int4)
+	const size_t sz[12] = {pad(16 * nl),                        // origins (int4)
 	                       pad(4 * 27 * nl),                    // nbr27
 	                       pad(4 * (hash_size + 1)),            // hash + the duplicate-origin status word
 	                       pad(4 * nl),                         // sched
@@ -372,13 +377,16 @@ int hns_grid_upload(hns_grid* g) {
 	                       pad(4 * (nl + n_blocks + 2)),        // schedule-build scratch
 	                       pad(4 * nl),                         // tile groups: every record in at most one group
 	                       pad(4 * nl),                         // records outside complete groups
-	                       pad(4 * (nl * (5 + tw) + n_blocks + 2))};  // tile-build scratch (hns_grid_build_tiles)
+	                       pad(4 * (nl * (5 + tw) + n_blocks + 2)),  // tile-build scratch (hns_grid_build_tiles)
+	                       pad(4 * nl),                         // wave record of every leaf
+	                       pad(4 * (nl + 1))};                  // resident SOR kernel: progress flag per wave record + one give-up word
 	size_t total = 0;
 	for (size_t s : sz) total += s;
 	HNS_TRY_RC(hns_arena_get(total, g->device, &g->d_arena, &g->arena_bytes));
 	char* q = (char*)g->d_arena;
-	void** slot[10] = {&g->d_origins, &g->d_nbr27, &g->d_hash, &g->d_sched_mem, &g->d_blk, &g->d_pairs, &g->d_scratch, &g->d_tile_groups, &g->d_tile_rest, &g->d_tile_mem};
-	for (int i = 0; i < 10; ++i) {
+	void** slot[12] = {&g->d_origins, &g->d_nbr27, &g->d_hash, &g->d_sched_mem, &g->d_blk, &g->d_pairs, &g->d_scratch, &g->d_tile_groups, &g->d_tile_rest, &g->d_tile_mem,
+	                   &g->d_wave_of_leaf, &g->d_flags};
+	for (int i = 0; i < 12; ++i) {
 		*slot[i] = q;
 		q += sz[i];
 	}
@@ -432,7 +440,9 @@ void hns_grid_free_device(hns_grid* g) {
 	g->d_arena = nullptr;
 	g->arena_bytes = 0;
 	g->d_origins = g->d_nbr27 = g->d_hash = g->d_sched = g->d_sched_mem = g->d_blk = g->d_pairs = g->d_scratch = nullptr;
-	g->d_tile_groups = g->d_tile_rest = g->d_tile_mem = nullptr;
+	g->d_tile_groups = g->d_tile_rest = g->d_tile_mem = g->d_wave_of_leaf = g->d_flags = nullptr;
+	if (g->h_status) (void)hipHostFree(g->h_status);
+	g->h_status = nullptr;
 	g->n_tile_groups = g->n_tile_rest = 0;
 	g->on_device = false;
 }

@@ -135,6 +135,12 @@ struct hns_grid {
 	void* d_tile_rest = nullptr;
 	void* d_tile_mem = nullptr;
 	uint64_t n_tile_groups = 0, n_tile_rest = 0;
+	// resident SOR kernel (whole pressure loop in one launch): wave record of every leaf, one progress flag per wave record, and
+	// a host-visible word a wave raises when it gives up waiting (hns_pressure.hip: k_rbgs_resident)
+	void* d_wave_of_leaf = nullptr;
+	void* d_flags = nullptr;
+	int* h_status = nullptr;
+	int resident_capacity = -1;  // wave records the chip can hold at once (-1: not asked yet)
 	std::vector<hns::RbgsGraph> graphs;  // cached hipGraph replays of the pressure loop (dropped when the schedule changes)
 	void* cap_stream = nullptr;          // private capture stream
 	std::mutex graph_mutex;              // guards graphs / cap_stream

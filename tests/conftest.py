@@ -11,6 +11,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("HNS_TEST_DUMP"):  # diagnosis aid: Python stacks of all threads every N seconds while a test runs
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["HNS_TEST_DUMP"]), repeat=True, file=sys.stderr)
 
 
 @pytest.fixture(scope="session", autouse=True)

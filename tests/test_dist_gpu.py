@@ -129,6 +129,31 @@ def test_world_size_one_equals_sim():
     assert i["peers"] == 0 and i["ghost_leaves"] == 0 and i["boundary_leaves"] == 0
 
 
+def test_loopback_transport_two_stream_structure_terminates_and_repeats():
+    """The RCCL path's structure -- boundary kernels, pack, transfer, unpack on a communication stream under the interior
+    kernels, events both ways -- with every message answered out of the rank's own send buffer (TIMING transport: the values
+    are meaningless, but the run must terminate, be finite and repeat bit for bit)."""
+    import torch
+
+    origins, R = fields.dense_leaves(64), 64
+    f = fields.synthetic_fields(origins[: len(origins) // 2], R)
+    outs = []
+    for _ in range(2):
+        d = HD.DistRank(origins, 2, 0, 1.0 / R, n_scalars=1, sweeps_per_exchange=2)
+        d.connect_loopback()
+        d.upload(f["vel"], [f["density"]])
+        stream = int(torch.cuda.current_stream().cuda_stream)
+        for _s in range(3):
+            d.core_substep(9, 1.0 / 24.0, stream)
+        d.synchronize(stream)
+        got = d.download()
+        assert np.isfinite(got["vel"]).all() and np.isfinite(got["scalars"][0]).all()
+        outs.append(got)
+        assert d.info()["exchanges"] == 1 + 1 + 5 + 1 + 1  # (the scalars of the next substep were already in flight)
+        d.close()
+    assert np.array_equal(outs[0]["vel"], outs[1]["vel"]) and np.array_equal(outs[0]["scalars"][0], outs[1]["scalars"][0])
+
+
 def test_unconnected_ranks_refuse_to_step():
     import hnanosolver_amd as H
 

@@ -155,4 +155,5 @@ def test_reference_side_shim_runs_and_matches_the_python_path(tmp_path):
         a = np.asarray(a, dtype=np.float64).reshape(-1)
         return float((a * (1 + np.arange(a.size) % 7)).sum())
 
-    assert np.isclose(nums[0][0], checksum(d.pValues("vel")), rtol=1e-12, atol=0) and np.isclose(nums[0][1], checksum(d.pValues("density")), rtol=1e-12, atol=0)
+    # (the program prints ten significant digits of position-weighted sums over 100k values: any differing value shows)
+    assert np.isclose(nums[0][0], checksum(d.pValues("vel")), rtol=2e-9, atol=0) and np.isclose(nums[0][1], checksum(d.pValues("density")), rtol=2e-9, atol=0)
