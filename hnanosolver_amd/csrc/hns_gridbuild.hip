@@ -312,12 +312,17 @@ int hns_grid_upload_schedule(hns_grid* g) {
 	g->n_singles = (uint64_t)h_totals[1];
 	k_write_pairs<<<n_blocks, 256, 0, 0>>>(nbr27, first, n, linear, partner, block_heads, (int*)g->d_pairs);
 	HNS_HIP(hipDeviceSynchronize());
-	return hns_grid_build_tiles(g);
+	g->tiles_built = false;  // built when a solve first asks for the blocked or resident form (most grids never do)
+	g->n_tile_groups = g->n_tile_rest = 0;
+	return HNS_OK;
 }
 
 // Tile groups of the blocked SOR kernel for the current wave records (see k_group_assign). Tables live in the grid's arena:
 // d_tile_groups = n_tile_groups x kTileWaves record indices, d_tile_rest = the n_tile_rest records outside complete groups.
 int hns_grid_build_tiles(hns_grid* g) {
+	std::lock_guard<std::mutex> lock(g->graph_mutex);  // cooks from several host threads may share the grid
+	if (g->tiles_built) return HNS_OK;
+	g->tiles_built = true;
 	g->n_tile_groups = g->n_tile_rest = 0;
 	const int np = (int)g->n_pairs, nl = (int)g->topo.n_leaves, w = kTileY * kTileZ;
 	if (np == 0 || !g->d_tile_mem) return HNS_OK;
@@ -451,6 +456,7 @@ void hns_grid_free_device(hns_grid* g) {
 extern "C" int hns_grid_tile_tables(const hns_grid* g, int32_t* groups, int32_t* rest, uint64_t* n_groups, uint64_t* n_rest, int* tile_y, int* tile_z) {
 	if (!g) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_tile_tables: null grid");
 	if (!g->on_device) return fail(HNS_ERR_NO_DEVICE, "hns_grid_tile_tables: grid has no device tables (HNS_GRID_HOST_ONLY)");
+	if (int rc = hns_grid_build_tiles(const_cast<hns_grid*>(g))) return rc;
 	if (n_groups) *n_groups = g->n_tile_groups;
 	if (n_rest) *n_rest = g->n_tile_rest;
 	if (tile_y) *tile_y = kTileY;

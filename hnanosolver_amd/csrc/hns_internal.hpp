@@ -135,6 +135,7 @@ struct hns_grid {
 	void* d_tile_rest = nullptr;
 	void* d_tile_mem = nullptr;
 	uint64_t n_tile_groups = 0, n_tile_rest = 0;
+	bool tiles_built = false;  // d_tile_* / d_wave_of_leaf are filled on first use (hns_grid_build_tiles)
 	// resident SOR kernel (whole pressure loop in one launch): wave record of every leaf, one progress flag per wave record, and
 	// a host-visible word a wave raises when it gives up waiting (hns_pressure.hip: k_rbgs_resident)
 	void* d_wave_of_leaf = nullptr;

@@ -1046,17 +1046,18 @@ int hns_dev_rbgs_color(hns_grid* g, const float* div, float* p, float dx, float 
 // One leaf per wave is the better choice for SMALL IRREGULAR grids, which are latency-bound (twice as many, shorter waves;
 // no half-empty pair waves): measured on the 3.9k-leaf plume 9.0 vs 11.9 us per iteration; and for grids of a few hundred
 // leaves, which cannot fill 256 CUs with one wave per pair.
-static int rbgs_form(const hns_grid* g, int opt) {
+static int rbgs_form(hns_grid* g, int opt) {
 	if (opt == kRbgsColor || opt == kRbgsWave) return opt;
 	if (!g->d_pairs) return kRbgsWave;
 	if (opt == kRbgsPair) return kRbgsPair;
-	if (opt == kRbgsTile) return g->d_tile_groups ? kRbgsTile : kRbgsPair;
+	if (opt == kRbgsTile) return (hns_grid_build_tiles(g) == HNS_OK && g->d_tile_groups) ? kRbgsTile : kRbgsPair;
 	if (opt == kRbgsResident) return kRbgsPair;  // (the resident form is a property of a whole solve: hns_rbgs_iterate decides)
 	// (<= 2048: also the boundary range of a multi-GPU rank, a few thousand leaves swept next to the interior launch)
 	if (g->n_active <= 2048 || (g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs)) return kRbgsWave;
 	// far beyond the Infinity Cache the halo of leaves swept elsewhere on the chip is what costs: blocked form where most
 	// records sit in complete groups (512^3: 428 -> 379 us per sweep; no gain on the ragged 66k-leaf plume, none in cache)
-	if (g->n_active > 100000 && g->d_tile_groups && g->n_tile_groups * (uint64_t)(kTileY * kTileZ) * 10 >= g->n_pairs * 9) return kRbgsTile;
+	if (g->n_active > 100000 && hns_grid_build_tiles(g) == HNS_OK && g->d_tile_groups && g->n_tile_groups * (uint64_t)(kTileY * kTileZ) * 10 >= g->n_pairs * 9)
+		return kRbgsTile;
 	return kRbgsPair;
 }
 
@@ -1124,7 +1125,7 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 		// where a kernel boundary costs 1.7 us), as MI355X_MICROARCH.md's hand-off price list predicts. Kept as the measured answer
 		// to "one launch for the whole loop", bit-identical (tests/test_resident_gpu.py).
 		const bool wanted = opt == kRbgsResident;
-		if (wanted && iterations >= 2 && g->d_pairs && g->d_wave_of_leaf && g->n_pairs > 0 && !options().graph.load()) {
+		if (wanted && iterations >= 2 && g->d_pairs && g->n_pairs > 0 && !options().graph.load() && hns_grid_build_tiles(g) == HNS_OK && g->d_wave_of_leaf) {
 			if (g->resident_capacity < 0) {
 				int per_cu = 0, cus = 0;
 				hipDeviceProp_t prop;

@@ -12,6 +12,11 @@ rm -rf $out && mkdir -p $out
 cd $root
 python3 bench.py > $out/bench_256.json 2> $out/bench_256.err
 for c in 128 64 plume plume1024; do python3 bench.py --config $c --no-cpu-baseline > $out/bench_$c.json 2>> $out/bench_other.err; done
+python3 bench.py --config 512 --steps 5 --no-cpu-baseline > $out/bench_512.json 2>> $out/bench_other.err
+# one rank of a multi-GPU run before any wire time (local / loopback transports of hns_dist), and against emulated wire time
+for a in "256 2 4" "256 2 2" "128 2 4" "plume1024 8 4 --partition"; do python3 profiles/micro/dist_overhead.py $a >> $out/dist_overhead.jsonl 2>> $out/bench_other.err; done
+for w in 0 10 20 40; do python3 profiles/micro/dist_profile.py rank 4 $w 2>> $out/bench_other.err | tail -1 >> $out/dist_wire_sweep.txt; done
+python3 profiles/micro/sor_sizes.py > $out/sor_sizes.txt 2>> $out/bench_other.err
 python3 bench.py --cook > $out/cook_256.json 2>> $out/bench_other.err
 python3 bench.py --cook --config 128 > $out/cook_128.json 2>> $out/bench_other.err
 cd /tmp && export TMPDIR=/tmp

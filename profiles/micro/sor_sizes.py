@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from hnanosolver_amd import api, device as D, fields
 
-for R in (64, 96, 128, 160, 192, 224, 256, 288, 320, 384, 448, 512):
+for R in (64, 128, 192, 256, 288, 320, 384, 512):
     origins = fields.dense_leaves(R)
     grid = api.create_grid_from_leaves(origins, 1.0 / R)
     N = len(origins) * 512
