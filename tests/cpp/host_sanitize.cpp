@@ -87,6 +87,27 @@ int main() {
 	hns_grid_destroy(g);
 	REQUIRE(hns_grid_create(coords.data(), 700, 1.0f, HNS_GRID_HOST_ONLY, &err) == nullptr && err == HNS_ERR_TOPOLOGY);
 	REQUIRE(hns_grid_create(nullptr, 512, 1.0f, HNS_GRID_HOST_ONLY, &err) == nullptr && err == HNS_ERR_INVALID_ARGUMENT);
+	// the OpenVDB-free leaf I/O (hns_leafio.cpp): int32-edge origins, exact-capacity outputs, masks, fills
+	{
+		const std::vector<int32_t> lo = {2147483640, 0, 0, -2147483648, -8, 8, 0, 0, 0};
+		std::vector<unsigned char> masks(3 * 64, 0);
+		masks[0] = 1, masks[64 + 63] = 0x80, masks[128 + 9] = 0x10;
+		uint64_t n_out = 0;
+		REQUIRE(hns_dilate_leaves(lo.data(), 3, masks.data(), 9, nullptr, 0, &n_out) == HNS_OK && n_out > 3);
+		std::vector<int32_t> dil(3 * n_out);
+		REQUIRE(hns_dilate_leaves(lo.data(), 3, masks.data(), 9, dil.data(), n_out, &n_out) == HNS_OK);
+		REQUIRE(hns_dilate_leaves(lo.data(), 3, masks.data(), 9, dil.data(), n_out - 1, &n_out) == HNS_ERR_INVALID_ARGUMENT);
+		uint64_t n_uni = 0;
+		REQUIRE(hns_union_leaves(dil.data(), n_out, lo.data(), 3, nullptr, 0, &n_uni) == HNS_OK && n_uni == n_out);
+		std::vector<float> src(2 * 512 * 3, 2.5f), flat(n_out * 512 * 3);
+		REQUIRE(hns_gather_leaves(dil.data(), n_out, lo.data(), 2, src.data(), 3, HNS_FILL_SDF, flat.data()) == HNS_OK);
+		std::vector<std::vector<float>> leaves(n_out, std::vector<float>(512 * 3));
+		std::vector<float*> ptrs;
+		for (auto& v : leaves) ptrs.push_back(v.data());
+		REQUIRE(hns_scatter_leaves(flat.data(), n_out, 3, ptrs.data()) == HNS_OK);
+		const int32_t bad[3] = {4, 0, 0};
+		REQUIRE(hns_dilate_leaves(bad, 1, nullptr, 1, nullptr, 0, &n_out) == HNS_ERR_TOPOLOGY);
+	}
 	std::puts("host_sanitize OK");
 	return 0;
 }

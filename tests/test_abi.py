@@ -224,7 +224,7 @@ def test_header_is_plain_c99_and_links_from_c(tmp_path):
 
 
 def test_host_code_under_address_and_ub_sanitizers(tmp_path):
-    """hns_topology.cpp + hns_nanovdb.cpp (all of libhns that runs on the host without a device) compiled with
+    """hns_topology.cpp + hns_nanovdb.cpp + hns_leafio.cpp (all of libhns that runs on the host without a device) compiled with
     -fsanitize=address,undefined and driven through int32-edge origins, threaded validation, malformed inputs and
     exact-size export buffers (tests/cpp/host_sanitize.cpp). GPU sanitizers are not available on the target pool."""
     rocm_inc = "/opt/rocm/include"
@@ -234,7 +234,7 @@ def test_host_code_under_address_and_ub_sanitizers(tmp_path):
     csrc = os.path.join(ROOT, "hnanosolver_amd", "csrc")
     cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
            "-D__HIP_PLATFORM_AMD__", "-I" + rocm_inc, "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
-           os.path.join(ROOT, "tests", "cpp", "host_sanitize.cpp"), os.path.join(csrc, "hns_topology.cpp"), os.path.join(csrc, "hns_nanovdb.cpp"),
+           os.path.join(ROOT, "tests", "cpp", "host_sanitize.cpp"), os.path.join(csrc, "hns_topology.cpp"), os.path.join(csrc, "hns_nanovdb.cpp"), os.path.join(csrc, "hns_leafio.cpp"),
            "-pthread", "-o", exe]
     b = subprocess.run(cmd, capture_output=True, text=True)
     assert b.returncode == 0, b.stderr[-3000:]
