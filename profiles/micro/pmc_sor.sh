@@ -11,4 +11,4 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
 	rocprofv3 --pmc $grp --output-format csv -d $d -- python3 $root/profiles/micro/sor_one.py $cfg > $d.log 2>&1
 	dirs="$dirs $d"
 done
-python3 $root/profiles/summarize_pmc.py $out/pmc.json $dirs | grep -A14 "k_rbgs_pair<false>"
+python3 $root/profiles/summarize_pmc.py $out/pmc.json $dirs | grep -A14 "k_rbgs_pair<false>\|k_rbgs_tile<false>"
