@@ -17,7 +17,8 @@ interior kernels (csrc/hns_dist.hip; hnanosolver_amd/dist.py is the host mirror)
 Rank 0 prints ONE JSON line. `roofline`: dominant kernel k_rbgs_pair, algorithmic 12 B/voxel per launch (read p, read
 div, write p once each), launch time from hipEvents recorded on the launch stream around the pressure loop of every
 timed step. `roofline.kernels` carries the same figures for all five kernels of the substep (each bracketed by hipEvents
-on the launch stream) and `roofline.substep` the whole substep against 688 B/voxel. `traffic` is NOT measured by this
+on the launch stream, in a short pass of its own after the timed region) and `roofline.substep` the whole substep
+against 688 B/voxel. `traffic` is NOT measured by this
 run (bench.py cannot run rocprofv3 on itself): it is the PMC-derived HBM bytes per launch from the builder's committed
 rocprofv3 profile of this same command (profiles/pmc_latest.json), reported only while that profile was taken from the
 kernel source this library was built from, and labelled with `traffic_source`. `cpu_baseline`: the oracle (C restatement
@@ -196,6 +197,13 @@ def main():
             return sim.pressure_time()
 
         def stage_times():
+            # per-kernel figures from a pass of its own, after the timed region: six more events per substep on the launch
+            # stream would cost the timed loop ~1 % at 256^3 (and 10 % at 64^3)
+            n = min(args.steps, 10)
+            sim.stage_timing(n)
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
             return sim.stage_times()
     else:
         from hnanosolver_amd import dist as HD

@@ -94,6 +94,7 @@ SIGNATURES = {
     "hns_sim_pressure_solve": (_i, [_vp, _i, _f, _vp]),
     "hns_sim_timing": (_i, [_vp, _i]),
     "hns_sim_pressure_time": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_longlong)]),
+    "hns_sim_stage_timing": (_i, [_vp, _i]),
     "hns_sim_stage_times": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_longlong)]),
     "hns_sim_velocity_ptr": (_vp, [_vp]),
     "hns_sim_field_ptr": (_vp, [_vp, C.c_char_p]),

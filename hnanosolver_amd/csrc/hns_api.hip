@@ -74,7 +74,8 @@ struct hns_sim {
 	std::vector<hipEvent_t> ev;  // start/stop pairs
 	size_t ev_used = 0;
 	long long timed_launches = 0;
-	std::vector<hipEvent_t> sev;  // stage boundaries of hns_sim_core_substep while timing is on: six per substep
+	bool stage_timing = false;    // hns_sim_stage_timing: also bracket the five stages of hns_sim_core_substep
+	std::vector<hipEvent_t> sev;  // stage boundaries: six per substep
 	size_t sev_used = 0;
 	hipStream_t xfer = nullptr;  // transfer stream + hand-off events of the pipelined operator path (compute_sim_pipelined)
 	hipEvent_t xev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -390,19 +391,27 @@ extern "C" int hns_sim_timing(hns_sim* s, int max_solves) {
 		HNS_HIP(hipEventCreate(&e));
 		s->ev.push_back(e);
 	}
-	while (s->sev.size() < (size_t)max_solves * 6) {
-		hipEvent_t e;
-		HNS_HIP(hipEventCreate(&e));
-		s->sev.push_back(e);
-	}
 	s->timing = max_solves > 0;
 	s->ev_used = 0;
-	s->sev_used = 0;
 	s->timed_launches = 0;
 	return HNS_OK;
 }
 
-// Per-stage device time of the core substeps run since hns_sim_timing(): ms5 = {advect_vector, divergence, pressure loop,
+// Bracket the five stages of the next max_substeps hns_sim_core_substep calls (six events per substep: a few microseconds
+// each on the launch stream, which is why this is a switch of its own and not part of hns_sim_timing).
+extern "C" int hns_sim_stage_timing(hns_sim* s, int max_substeps) {
+	if (!s || max_substeps < 0) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_sim_stage_timing: bad arguments");
+	while (s->sev.size() < (size_t)max_substeps * 6) {
+		hipEvent_t e;
+		HNS_HIP(hipEventCreate(&e));
+		s->sev.push_back(e);
+	}
+	s->stage_timing = max_substeps > 0;
+	s->sev_used = 0;
+	return HNS_OK;
+}
+
+// Per-stage device time of the core substeps run since hns_sim_stage_timing(): ms5 = {advect_vector, divergence, pressure loop,
 // gradient subtraction, advect_scalars}, summed over `*substeps` substeps; events sit on the launch stream.
 extern "C" int hns_sim_stage_times(hns_sim* s, float* ms5, long long* substeps) {
 	if (!s || !ms5 || !substeps) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_sim_stage_times: null argument");
@@ -554,7 +563,7 @@ extern "C" int hns_sim_core_substep(hns_sim* s, int iterations, float dt, float 
 	if (s->n == 0) return HNS_OK;
 	const float inv_dx = 1.0f / voxel_size;
 	hns_grid* g = s->grid;
-	const bool staged = s->timing && s->sev_used + 6 <= s->sev.size();
+	const bool staged = s->stage_timing && s->sev_used + 6 <= s->sev.size();
 	hipEvent_t* se = staged ? &s->sev[s->sev_used] : nullptr;
 	if (staged) HNS_HIP(hipEventRecord(se[0], (hipStream_t)stream));
 	HNS_TRY(hns_dev_advect_vector(g, s->vel, s->adv, nullptr, 0, dt, inv_dx, stream));

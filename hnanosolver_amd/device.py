@@ -167,6 +167,9 @@ class Sim:
         _raise(lib.hns_sim_pressure_time(self._ptr, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
+    def stage_timing(self, max_substeps: int) -> None:
+        _raise(lib.hns_sim_stage_timing(self._ptr, max_substeps))
+
     def stage_times(self):
         """({stage: total ms} over the core substeps timed since timing(), number of substeps)"""
         ms, n = (C.c_float * 5)(), C.c_longlong(0)

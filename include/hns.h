@@ -209,8 +209,10 @@ int hns_sim_pressure_solve(hns_sim*, int iterations, float voxel_size, void* str
  * number of fused-iteration launches they contained. hns_sim_timing(sim, 0) switches it off. */
 int hns_sim_timing(hns_sim*, int max_solves);
 int hns_sim_pressure_time(hns_sim*, float* total_ms, long long* launches);
-/* The same switch also brackets the five stages of every hns_sim_core_substep: ms5 receives the summed milliseconds of
- * {advect_vector, divergence, pressure loop, gradient subtraction, advect_scalars} over *substeps substeps. */
+/* hns_sim_stage_timing(sim, n) brackets the five stages of the next n hns_sim_core_substep calls (six events per substep;
+ * a switch of its own because the events cost microseconds each on the launch stream); hns_sim_stage_times: ms5 receives the
+ * summed milliseconds of {advect_vector, divergence, pressure loop, gradient subtraction, advect_scalars} over *substeps. */
+int hns_sim_stage_timing(hns_sim*, int max_substeps);
 int hns_sim_stage_times(hns_sim*, float* ms5, long long* substeps);
 /* Raw device pointers of the sim's buffers (Vec3f AoS velocity, float fields, divergence, pressure). */
 float* hns_sim_velocity_ptr(hns_sim*);
