@@ -136,6 +136,39 @@ __global__ __launch_bounds__(64) void k_halo_copy(float* __restrict__ field, con
 	}
 }
 
+// The same for ALL peers of a rank in one launch (a rank of a 3-d decomposition talks to several: 7 in the 8-range plume):
+// entry i carries its peer, whose message base and region size come by value.
+constexpr int kMaxBatchPeers = 16;
+struct PeerMsgs {
+	float* base[kMaxBatchPeers];
+	int voxels[kMaxBatchPeers];
+};
+
+template <int NCOMP, bool PACK>
+__global__ __launch_bounds__(64) void k_halo_copy_all(float* __restrict__ field, const int* __restrict__ leaf, const unsigned char* __restrict__ mask,
+                                                      const int* __restrict__ off, const int* __restrict__ peer, const PeerMsgs msgs, const int comps_before) {
+	const int i = blockIdx.x, l = threadIdx.x;
+	const unsigned m = mask[(size_t)i * 64 + l];
+	const int p = peer[i];
+	const int base = off[i] + wave_exclusive_scan(__popc(m));
+	float* f = field + ((size_t)leaf[i] * 512 + l * 8) * NCOMP;
+	float* q = msgs.base[p] + (size_t)comps_before * (size_t)msgs.voxels[p] + (size_t)base * NCOMP;
+	int c = 0;
+#pragma unroll
+	for (int z = 0; z < 8; ++z) {
+		if (m >> z & 1) {
+#pragma unroll
+			for (int k = 0; k < NCOMP; ++k) {
+				if (PACK)
+					q[c * NCOMP + k] = f[z * NCOMP + k];
+				else
+					f[z * NCOMP + k] = q[c * NCOMP + k];
+			}
+			++c;
+		}
+	}
+}
+
 }  // namespace hns
 
 using namespace hns;
@@ -222,6 +255,14 @@ struct hns_dist {
 	float *u = nullptr, *adv = nullptr, *div = nullptr, *p_a = nullptr, *p_b = nullptr, *p_result = nullptr, *stage = nullptr;
 	std::vector<float*> phi, phi_next;
 	void* tables = nullptr;  // region tables of every peer (one allocation)
+	// the same regions, all peers concatenated (one pack / unpack launch per field when a rank has several peers)
+	struct AllPeers {
+		int n = 0;
+		int* d_leaf = nullptr;
+		unsigned char* d_mask = nullptr;
+		int* d_off = nullptr;
+		int* d_peer = nullptr;
+	} all_send[4], all_recv[4];
 	int* d_perm = nullptr;
 	// streams and events
 	hipStream_t cs = nullptr;
@@ -458,6 +499,14 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 			}
 			bytes += 2 * pad256(sizeof(float) * p.sbuf_floats) + 2 * pad256(sizeof(float) * p.rbuf_floats);
 		}
+		const bool batch = d->peers.size() > 1 && d->peers.size() <= (size_t)kMaxBatchPeers;
+		if (batch)
+			for (int t = 0; t < X_COUNT; ++t)
+				for (int dir = 0; dir < 2; ++dir) {
+					size_t n = 0;
+					for (Peer& p : d->peers) n += (dir ? p.recv[t] : p.send[t]).leaf.size();
+					bytes += 3 * pad256(sizeof(int) * n) + pad256(64 * n);
+				}
 		if (hipMalloc(&d->tables, bytes) != hipSuccess) return bail(fail(HNS_ERR_HIP, "hns_dist_create: allocating the halo tables failed"));
 		char* q = (char*)d->tables;
 		auto put = [&](const void* src, size_t n) -> void* {
@@ -480,6 +529,25 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 				p.rbuf[i] = (float*)q, q += pad256(sizeof(float) * p.rbuf_floats);
 			}
 		}
+		if (batch)
+			for (int t = 0; t < X_COUNT; ++t)
+				for (int dir = 0; dir < 2; ++dir) {
+					std::vector<int> leaf, off, peer;
+					std::vector<unsigned char> mask;
+					for (size_t pi = 0; pi < d->peers.size(); ++pi) {
+						const Region& r = dir ? d->peers[pi].recv[t] : d->peers[pi].send[t];
+						leaf.insert(leaf.end(), r.leaf.begin(), r.leaf.end());
+						off.insert(off.end(), r.off.begin(), r.off.end());
+						mask.insert(mask.end(), r.mask.begin(), r.mask.end());
+						peer.insert(peer.end(), r.leaf.size(), (int)pi);
+					}
+					hns_dist::AllPeers& a = dir ? d->all_recv[t] : d->all_send[t];
+					a.n = (int)leaf.size();
+					a.d_leaf = (int*)put(leaf.data(), sizeof(int) * leaf.size());
+					a.d_mask = (unsigned char*)put(mask.data(), mask.size());
+					a.d_off = (int*)put(off.data(), sizeof(int) * off.size());
+					a.d_peer = (int*)put(peer.data(), sizeof(int) * peer.size());
+				}
 		if (rc != HNS_OK) return bail(rc);
 	}
 	for (int i = 0; i < 2; ++i)
@@ -665,6 +733,45 @@ int halo_copy(bool pack, float* field, int ncomp, const Region& r, float* msg, h
 	return launch_status("hns_dist: halo pack/unpack");
 }
 
+// every field of exchange `x`, all peers: one launch per field where the combined tables exist, per peer otherwise
+int halo_copy_exchange(hns_dist* d, bool pack, const Pending& x, hipStream_t st) {
+	const hns_dist::AllPeers& a = pack ? d->all_send[x.type] : d->all_recv[x.type];
+	if (a.d_leaf) {
+		if (a.n == 0) return HNS_OK;
+		PeerMsgs msgs;
+		for (size_t pi = 0; pi < d->peers.size(); ++pi) {
+			msgs.base[pi] = pack ? d->peers[pi].sbuf[x.parity] : d->peers[pi].rbuf[x.parity];
+			msgs.voxels[pi] = (pack ? d->peers[pi].send[x.type] : d->peers[pi].recv[x.type]).voxels;
+		}
+		int before = 0;
+		const dim3 grid((unsigned)a.n), block(64);
+		for (auto& f : x.fields) {
+			if (f.second == 3) {
+				if (pack)
+					hipLaunchKernelGGL((k_halo_copy_all<3, true>), grid, block, 0, st, f.first, a.d_leaf, a.d_mask, a.d_off, a.d_peer, msgs, before);
+				else
+					hipLaunchKernelGGL((k_halo_copy_all<3, false>), grid, block, 0, st, f.first, a.d_leaf, a.d_mask, a.d_off, a.d_peer, msgs, before);
+			} else {
+				if (pack)
+					hipLaunchKernelGGL((k_halo_copy_all<1, true>), grid, block, 0, st, f.first, a.d_leaf, a.d_mask, a.d_off, a.d_peer, msgs, before);
+				else
+					hipLaunchKernelGGL((k_halo_copy_all<1, false>), grid, block, 0, st, f.first, a.d_leaf, a.d_mask, a.d_off, a.d_peer, msgs, before);
+			}
+			before += f.second;
+		}
+		return launch_status("hns_dist: halo pack/unpack");
+	}
+	for (Peer& p : d->peers) {
+		float* msg = pack ? p.sbuf[x.parity] : p.rbuf[x.parity];
+		const Region& r = pack ? p.send[x.type] : p.recv[x.type];
+		for (auto& f : x.fields) {
+			HNS_TRY(halo_copy(pack, f.first, f.second, r, msg, st));
+			msg += (size_t)f.second * (size_t)r.voxels;
+		}
+	}
+	return HNS_OK;
+}
+
 size_t message_floats(const Pending& x, const Region& r) {
 	size_t c = 0;
 	for (auto& f : x.fields) c += (size_t)f.second;
@@ -673,13 +780,7 @@ size_t message_floats(const Pending& x, const Region& r) {
 
 // received regions -> ghost voxels, on the communication stream; ev_done marks the end of the exchange
 int unpack(hns_dist* d, Pending& x) {
-	for (Peer& p : d->peers) {
-		float* msg = p.rbuf[x.parity];
-		for (auto& f : x.fields) {
-			HNS_TRY(halo_copy(false, f.first, f.second, p.recv[x.type], msg, x.stream));
-			msg += (size_t)f.second * (size_t)p.recv[x.type].voxels;
-		}
-	}
+	HNS_TRY(halo_copy_exchange(d, false, x, x.stream));
 	if (!d->single_stream) HNS_HIP(hipEventRecord(d->ev_done[x.parity], x.stream));
 	return HNS_OK;
 }
@@ -706,12 +807,8 @@ int post(hns_dist* d, int type, std::vector<std::pair<float*, int>> fields, hipS
 		HNS_HIP(hipStreamWaitEvent(cs, d->ev_ready, 0));
 	}
 	HNS_TRY(boundary(cs));
+	HNS_TRY(halo_copy_exchange(d, true, x, cs));
 	for (Peer& p : d->peers) {
-		float* msg = p.sbuf[x.parity];
-		for (auto& f : x.fields) {
-			HNS_TRY(halo_copy(true, f.first, f.second, p.send[type], msg, cs));
-			msg += (size_t)f.second * (size_t)p.send[type].voxels;
-		}
 		const size_t fl = message_floats(x, p.send[type]);
 		if (fl) d->bytes_sent[type] += sizeof(float) * fl, ++d->messages_sent;
 	}
