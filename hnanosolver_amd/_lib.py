@@ -119,6 +119,7 @@ SIGNATURES = {
     "hns_dist_connect_rccl": (_i, [_vp, _vp]),
     "hns_dist_connect_local": (_i, [C.POINTER(C.c_void_p), _i]),
     "hns_dist_connect_loopback": (_i, [_vp]),
+    "hns_dist_connect_loopback_rccl": (_i, [_vp]),
     "hns_dist_owned_leaves": (_u64, [_vp]),
     "hns_dist_first_owned_leaf": (_u64, [_vp]),
     "hns_dist_info": (_i, [_vp, C.POINTER(hns_dist_stats)]),

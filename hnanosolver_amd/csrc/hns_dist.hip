@@ -217,6 +217,7 @@ struct Region {  // the voxels of some local leaves that travel in one exchange 
 	std::vector<int> off;             // voxel offset of each listed leaf in the message
 	int voxels = 0;
 	bool whole = false;  // every listed leaf travels whole: plain 16-byte copies instead of the masked kernel
+	int direct = -1;     // whole AND the listed leaves are consecutive local leaves starting here: the message IS that slice of the field
 	int* d_leaf = nullptr;
 	unsigned char* d_mask = nullptr;
 	int* d_off = nullptr;
@@ -339,13 +340,15 @@ int build_plan(hns_dist* d, const int32_t* origins, int64_t n, int world, int ra
 			is_boundary[(size_t)(l - o0)] = 1;
 		}
 	}
-	if (world > 1 && n > 0) {  // the mirror of global element 0 (voxel 0 of global leaf 0), advection inputs only
+	// the mirror of global element 0 (voxel 0 of global leaf 0), advection inputs only; the whole leaf travels (8 KB per
+	// exchange) so that the region stays one of whole leaves, which can be sent without packing
+	if (world > 1 && n > 0) {
 		if (owner0 == rank) {
 			for (int q = 0; q < world; ++q)
-				if (q != rank) entry(send_of[(size_t)q], send_keys[(size_t)q], 0).m[X_ADV].row[0] |= 1;
+				if (q != rank) entry(send_of[(size_t)q], send_keys[(size_t)q], 0).m[X_ADV].fill();
 			is_boundary[0] = 1;
 		} else {
-			entry(recv_of[(size_t)owner0], recv_keys[(size_t)owner0], 0).m[X_ADV].row[0] |= 1;
+			entry(recv_of[(size_t)owner0], recv_keys[(size_t)owner0], 0).m[X_ADV].fill();
 		}
 	}
 
@@ -393,7 +396,12 @@ int build_plan(hns_dist* d, const int32_t* origins, int64_t n, int world, int ra
 			}
 		}
 		for (int t = 0; t < X_COUNT; ++t)
-			for (Region* r : {&p.send[t], &p.recv[t]}) r->whole = r->voxels == 512 * (int)r->leaf.size();
+			for (Region* r : {&p.send[t], &p.recv[t]}) {
+				r->whole = r->voxels == 512 * (int)r->leaf.size();
+				bool run = r->whole && !r->leaf.empty();
+				for (size_t i = 1; run && i < r->leaf.size(); ++i) run = r->leaf[i] == r->leaf[0] + (int)i;
+				r->direct = run ? r->leaf[0] : -1;
+			}
 		d->peers.push_back(std::move(p));
 	}
 	d->nG = (int)d->local_global.size() - n_owned;
@@ -504,7 +512,7 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 			for (int t = 0; t < X_COUNT; ++t)
 				for (int dir = 0; dir < 2; ++dir) {
 					size_t n = 0;
-					for (Peer& p : d->peers) n += (dir ? p.recv[t] : p.send[t]).leaf.size();
+					for (Peer& p : d->peers) n += (dir ? p.recv[t] : p.send[t]).leaf.size();  // (direct regions are left out below)
 					bytes += 3 * pad256(sizeof(int) * n) + pad256(64 * n);
 				}
 		if (hipMalloc(&d->tables, bytes) != hipSuccess) return bail(fail(HNS_ERR_HIP, "hns_dist_create: allocating the halo tables failed"));
@@ -536,6 +544,7 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 					std::vector<unsigned char> mask;
 					for (size_t pi = 0; pi < d->peers.size(); ++pi) {
 						const Region& r = dir ? d->peers[pi].recv[t] : d->peers[pi].send[t];
+						if (r.direct >= 0) continue;  // travels straight out of / into the field
 						leaf.insert(leaf.end(), r.leaf.begin(), r.leaf.end());
 						off.insert(off.end(), r.off.begin(), r.off.end());
 						mask.insert(mask.end(), r.mask.begin(), r.mask.end());
@@ -598,6 +607,21 @@ int hns_dist_connect_loopback(hns_dist* d) {
 	if (!d || !d->gA) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_loopback: bad handle");
 	if (d->comm || !d->local_ranks.empty()) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_loopback: already connected");
 	HNS_TRY(ensure_comm_stream(d));
+	d->loopback = true;
+	return HNS_OK;
+}
+
+// The same, but every message really goes through RCCL: a one-rank communicator, ncclSend / ncclRecv to itself in the groups
+// the multi-rank path issues (same entry points, argument order, per-field segments, streams). What a single-GPU box can
+// verify of the RCCL path: it must leave exactly what the copy-based loopback leaves.
+int hns_dist_connect_loopback_rccl(hns_dist* d) {
+	if (!d || !d->gA) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_loopback_rccl: bad handle");
+	if (d->comm || d->loopback || !d->local_ranks.empty()) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_loopback_rccl: already connected");
+	HNS_TRY(need_rccl("hns_dist_connect_loopback_rccl"));
+	HNS_TRY(ensure_comm_stream(d));
+	ncclUniqueId id;
+	HNS_NCCL(rccl().GetUniqueId(&id));
+	HNS_NCCL(rccl().CommInitRank(&d->comm, 1, id, 0));
 	d->loopback = true;
 	return HNS_OK;
 }
@@ -764,12 +788,19 @@ int halo_copy_exchange(hns_dist* d, bool pack, const Pending& x, hipStream_t st)
 	for (Peer& p : d->peers) {
 		float* msg = pack ? p.sbuf[x.parity] : p.rbuf[x.parity];
 		const Region& r = pack ? p.send[x.type] : p.recv[x.type];
+		if (r.direct >= 0) continue;
 		for (auto& f : x.fields) {
 			HNS_TRY(halo_copy(pack, f.first, f.second, r, msg, st));
 			msg += (size_t)f.second * (size_t)r.voxels;
 		}
 	}
 	return HNS_OK;
+}
+
+// where field `f` (ncomp components, `before` components of earlier fields ahead of it) of a message lives: in the field itself
+// when the region is a run of whole consecutive leaves, in the message buffer otherwise
+float* segment(const Region& r, float* field, int ncomp, float* buf, int before) {
+	return r.direct >= 0 ? field + (size_t)r.direct * 512 * (size_t)ncomp : buf + (size_t)before * (size_t)r.voxels;
 }
 
 size_t message_floats(const Pending& x, const Region& r) {
@@ -816,16 +847,30 @@ int post(hns_dist* d, int type, std::vector<std::pair<float*, int>> fields, hipS
 	if (d->comm) {
 		HNS_NCCL(rccl().GroupStart());
 		for (Peer& p : d->peers) {
-			const size_t ns = message_floats(x, p.send[type]), nr = message_floats(x, p.recv[type]);
-			if (ns) HNS_NCCL(rccl().Send(p.sbuf[x.parity], ns, ncclFloat, p.rank, d->comm, cs));
-			if (nr) HNS_NCCL(rccl().Recv(p.rbuf[x.parity], nr, ncclFloat, p.rank, d->comm, cs));
+			const Region &rs = p.send[type], &rr = p.recv[type];
+			// (loopback over RCCL: the peer is this rank, the answer to a message is the message, cut to the smaller region)
+			const int to = d->loopback ? 0 : p.rank;
+			const size_t vs = d->loopback ? (size_t)std::min(rs.voxels, rr.voxels) : (size_t)rs.voxels, vr = d->loopback ? vs : (size_t)rr.voxels;
+			int before = 0;
+			for (auto& f : x.fields) {  // one send and one receive per field: either end may use the field itself or its buffer
+				if (vs) HNS_NCCL(rccl().Send(segment(rs, f.first, f.second, p.sbuf[x.parity], before), vs * f.second, ncclFloat, to, d->comm, cs));
+				if (vr) HNS_NCCL(rccl().Recv(segment(rr, f.first, f.second, p.rbuf[x.parity], before), vr * f.second, ncclFloat, to, d->comm, cs));
+				before += f.second;
+			}
 		}
 		HNS_NCCL(rccl().GroupEnd());
 	} else if (d->loopback) {  // same streams, events and copy sizes as a real exchange, but the payload is this rank's own
 		if (const int us = options().dist_wire_us.load()) hipLaunchKernelGGL(k_wire_delay, dim3(1), dim3(1), 0, cs, (long long)us * 100);
 		for (Peer& p : d->peers) {
-			const size_t nr = std::min(message_floats(x, p.recv[type]), message_floats(x, p.send[type]));
-			if (nr) HNS_HIP(hipMemcpyAsync(p.rbuf[x.parity], p.sbuf[x.parity], sizeof(float) * nr, hipMemcpyDeviceToDevice, cs));
+			const Region &rs = p.send[type], &rr = p.recv[type];
+			int before = 0;
+			for (auto& f : x.fields) {
+				const size_t nr = (size_t)std::min(rs.voxels, rr.voxels) * (size_t)f.second;
+				if (nr)
+					HNS_HIP(hipMemcpyAsync(segment(rr, f.first, f.second, p.rbuf[x.parity], before), segment(rs, f.first, f.second, p.sbuf[x.parity], before), sizeof(float) * nr,
+					                       hipMemcpyDeviceToDevice, cs));
+				before += f.second;
+			}
 		}
 	} else {
 		if (!d->single_stream) HNS_HIP(hipEventRecord(d->ev_post[x.parity], cs));  // packed: the peers may pull
@@ -849,8 +894,17 @@ int complete(hns_dist* d, hipStream_t st) {
 			const size_t nr = message_floats(x, p.recv[x.type]);
 			if (!nr) continue;
 			if (!back || message_floats(x, back->send[x.type]) != nr) return fail(HNS_ERR_RUNTIME, "hns_dist: send/receive plans of two ranks disagree");
+			const Pending& y = q->pending;  // the peer's record of the same exchange (its fields are ITS device arrays)
+			if (y.type != x.type || y.parity != x.parity || y.fields.size() != x.fields.size()) return fail(HNS_ERR_RUNTIME, "hns_dist: locally connected ranks are out of step");
 			if (!d->single_stream) HNS_HIP(hipStreamWaitEvent(x.stream, q->ev_post[x.parity], 0));
-			HNS_HIP(hipMemcpyAsync(p.rbuf[x.parity], back->sbuf[x.parity], sizeof(float) * nr, hipMemcpyDeviceToDevice, x.stream));
+			int before = 0;
+			for (size_t fi = 0; fi < x.fields.size(); ++fi) {
+				const int nc = x.fields[fi].second;
+				HNS_HIP(hipMemcpyAsync(segment(p.recv[x.type], x.fields[fi].first, nc, p.rbuf[x.parity], before),
+				                       segment(back->send[x.type], y.fields[fi].first, nc, back->sbuf[x.parity], before), sizeof(float) * (size_t)p.recv[x.type].voxels * nc,
+				                       hipMemcpyDeviceToDevice, x.stream));
+				before += nc;
+			}
 		}
 		HNS_TRY(unpack(d, x));
 	}
@@ -988,8 +1042,13 @@ int hns_dist_local_core_substep(hns_dist* const* ranks, int world, int iteration
 		ranks[r]->messages_sent = ranks[r]->exchanges = 0;
 		steps.push_back(Step{ranks[r], iterations, dt, (hipStream_t)stream});
 	}
-	for (int ph = 0, n = steps[0].n_phases(); ph < n; ++ph)
+	// a message may be the sender's field itself (whole-leaf regions are not packed): every rank takes delivery of the previous
+	// phase's exchange before any rank's next kernel overwrites what was sent
+	for (int ph = 0, n = steps[0].n_phases(); ph < n; ++ph) {
+		if (ph > 0)
+			for (Step& s : steps) HNS_TRY(complete(s.d, s.st));
 		for (Step& s : steps) HNS_TRY(s.run(ph));
+	}
 	return HNS_OK;
 }
 

@@ -124,9 +124,10 @@ class DistRank:
         arr = (C.c_void_p * len(ranks))(*[r._ptr for r in ranks])
         _raise(lib.hns_dist_connect_local(arr, len(ranks)))
 
-    def connect_loopback(self) -> None:
-        """TIMING ONLY: this rank alone, messages answered with its own payload (hns_dist_connect_loopback)."""
-        _raise(lib.hns_dist_connect_loopback(self._ptr))
+    def connect_loopback(self, rccl: bool = False) -> None:
+        """TIMING ONLY: this rank alone, messages answered with its own payload (hns_dist_connect_loopback); rccl=True carries
+        them through a one-rank RCCL communicator (hns_dist_connect_loopback_rccl)."""
+        _raise((lib.hns_dist_connect_loopback_rccl if rccl else lib.hns_dist_connect_loopback)(self._ptr))
 
     # ---- data ----
     def upload(self, vel: np.ndarray, scalars: Sequence[np.ndarray], stream: int = 0) -> None:

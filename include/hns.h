@@ -275,7 +275,7 @@ typedef struct hns_dist hns_dist;
 typedef struct {
 	int world, rank, peers, sweeps_per_exchange;
 	uint64_t boundary_leaves, interior_leaves, ghost_leaves; /* local leaf order: [boundary | interior | ghosts] */
-	/* per halo region type {advection inputs (whole leaves + the element-0 mirror), L1 reach 1, div (2k-1), p (2k)}: */
+	/* per halo region type {advection inputs (whole leaves, global leaf 0 = the element-0 mirror among them), L1 reach 1, div (2k-1), p (2k)}: */
 	uint64_t region_voxels_sent[4]; /* voxels this rank sends per exchange of that type (a property of the plan)   */
 	uint64_t bytes_sent[4];         /* payload bytes this rank sent during the last substep                          */
 	uint64_t messages_sent, exchanges; /* point-to-point messages / exchange rounds of the last substep              */
@@ -298,6 +298,9 @@ int hns_dist_connect_local(hns_dist* const* ranks, int world);
 /* Transport, loopback (TIMING ONLY, results are meaningless): this rank alone, every message answered with the rank's own
  * payload of the same size. Measures what one rank costs next to the single-GPU substep before any wire time. */
 int hns_dist_connect_loopback(hns_dist*);
+/* The same with every message carried by RCCL (a one-rank communicator, sends and receives to itself in the groups the
+ * multi-rank path issues): what a single-GPU box can check of the RCCL path. Leaves what the copy-based loopback leaves. */
+int hns_dist_connect_loopback_rccl(hns_dist*);
 uint64_t hns_dist_owned_leaves(const hns_dist*);
 uint64_t hns_dist_first_owned_leaf(const hns_dist*); /* global id of the first owned leaf; owned leaves are contiguous */
 int hns_dist_info(const hns_dist*, hns_dist_stats* out);

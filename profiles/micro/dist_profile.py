@@ -24,7 +24,7 @@ if mode == "single":
     step = lambda: sim.core_substep(iters, dt, vs, st)
 else:
     d = HD.DistRank(HD.slab_domain(origins, R, 2), 2, 0, vs, n_scalars=1, sweeps_per_exchange=k)
-    d.connect_loopback()
+    d.connect_loopback(rccl=len(sys.argv) > 4 and sys.argv[4] == "rccl")
     d.upload(f["vel"], [f["density"]])
     step = lambda: d.core_substep(iters, dt, st)
 for _ in range(3):
@@ -34,4 +34,4 @@ t0 = time.perf_counter()
 for _ in range(n):
     step()
 torch.cuda.synchronize()
-print(mode, "k", k, "wire_us", H.get_option("dist_wire_us"), "ms per substep", round(1e3 * (time.perf_counter() - t0) / n, 3))
+print(mode, "rccl" if len(sys.argv) > 4 else "", "k", k, "wire_us", H.get_option("dist_wire_us"), "ms per substep", round(1e3 * (time.perf_counter() - t0) / n, 3))

@@ -154,6 +154,42 @@ def test_loopback_transport_two_stream_structure_terminates_and_repeats():
     assert np.array_equal(outs[0]["vel"], outs[1]["vel"]) and np.array_equal(outs[0]["scalars"][0], outs[1]["scalars"][0])
 
 
+def _loopback_run(origins, R, world, rank, k, rccl, substeps=2, iters=9):
+    import torch
+
+    b = HD.partition_bounds(len(origins), world)
+    f = fields.synthetic_fields(origins[b[rank]:b[rank + 1]], R)
+    d = HD.DistRank(origins, world, rank, 1.0 / R, n_scalars=1, sweeps_per_exchange=k)
+    d.connect_loopback(rccl=rccl)
+    d.upload(f["vel"], [f["density"]])
+    stream = int(torch.cuda.current_stream().cuda_stream)
+    for _s in range(substeps):
+        d.core_substep(iters, 1.0 / 24.0, stream)
+    d.synchronize(stream)
+    got = d.download(pressure=True)
+    info = d.info()
+    d.close()
+    return got, info
+
+
+@pytest.mark.parametrize("case", ["dense_k4", "dense_k2", "plume_4ranks"])
+def test_rccl_carries_the_loopback_messages_exactly(case):
+    """What one GPU can verify of the RCCL transport: the same groups of ncclSend / ncclRecv the multi-rank path issues (one
+    per field and peer, out of the field itself for unpacked whole-leaf regions, out of the message buffers otherwise), on
+    the communication stream, through a one-rank communicator to itself -- must leave bit for bit what the copy-based
+    loopback leaves (both answer every message with the rank's own payload)."""
+    if case == "plume_4ranks":
+        origins, R, world, rank, k = fields.plume_leaves(12, 1.8, 0.28), 96, 4, 1, 3
+    else:
+        origins, R, world, rank, k = fields.dense_leaves(64), 64, 2, 0, 4 if case == "dense_k4" else 2
+    want, wi = _loopback_run(origins, R, world, rank, k, rccl=False)
+    got, gi = _loopback_run(origins, R, world, rank, k, rccl=True)
+    assert wi == gi and gi["messages_sent"] > 0
+    for key in ("vel", "pressure"):
+        assert np.array_equal(got[key], want[key]), key
+    assert np.array_equal(got["scalars"][0], want["scalars"][0])
+
+
 def test_unconnected_ranks_refuse_to_step():
     import hnanosolver_amd as H
 
