@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--partition", action="store_true", help="N > 1: split ONE --config domain across the ranks (strong scaling) instead of one slab per rank")
     ap.add_argument("--sweeps-per-exchange", type=int, default=0, help="N > 1: fused SOR sweeps between two halo refreshes of p (1..4, 0 = library default)")
+    ap.add_argument("--transport", choices=["rccl", "ipc"], default="rccl",
+                    help="N > 1 halo transport: RCCL send/recv groups (default) or one-sided puts into hipIpc-mapped peer memory")
+    ap.add_argument("--share-one-gpu", action="store_true",
+                    help="builder's check on a 1-GPU box: all N ranks on cuda:0, host rendezvous over gloo, --transport ipc (RCCL refuses two ranks on one device)")
     ap.add_argument("--cook", action="store_true", help="time the cook-equivalent hns_compute_sim call (upload + grid build + substep + download) instead")
     return ap.parse_args()
 
@@ -166,10 +170,15 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE is {world}: launch N>1 with torch.distributed.run --nproc-per-node N")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    if args.share_one_gpu:
+        local_rank, args.transport = 0, "ipc"
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.share_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from hnanosolver_amd import api, device as D, fields
 
@@ -208,7 +217,8 @@ def main():
     else:
         from hnanosolver_amd import dist as HD
 
-        runner = HD.SlabBench(origins, R, rank, world, args.iterations, dt, partition=args.partition, sweeps_per_exchange=args.sweeps_per_exchange)
+        runner = HD.SlabBench(origins, R, rank, world, args.iterations, dt, partition=args.partition, sweeps_per_exchange=args.sweeps_per_exchange,
+                              transport=args.transport)
         n_vox_rank = runner.n_owned * 512
         step, pressure_time, stage_times = runner.step, runner.pressure_time, None
 
@@ -231,7 +241,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -284,8 +294,10 @@ def main():
                 "algorithmic_bytes_per_voxel_substep": BYTES_PER_VOXEL_SUBSTEP - 600 + 12 * args.iterations,
                 "halo": None if world == 1 else {k: runner.info()[k] for k in ("boundary_leaves", "interior_leaves", "ghost_leaves", "peers", "sweeps_per_exchange",
                                                                                 "bytes_sent", "messages_sent", "exchanges")},
-                "parallelism": "single GPU" if world == 1 else (f"one domain in {world} contiguous leaf ranges, RCCL halo exchange" if args.partition
-                                                                else f"x-slab leaf partition over {world} GPUs, RCCL halo exchange"),
+                "parallelism": "single GPU" if world == 1 else (
+                    (f"one domain in {world} contiguous leaf ranges" if args.partition else f"x-slab leaf partition over {world} ranks")
+                    + (", RCCL halo exchange" if args.transport == "rccl" else ", one-sided halo puts into mapped peer memory")
+                    + (" -- ALL RANKS SHARE ONE GPU (builder's check, not a scaling figure)" if args.share_one_gpu else "")),
             },
             "roofline": {
                 "kernel": "k_rbgs_pair (one launch = one full red+black SOR iteration over all leaves)" if world == 1 else

@@ -39,6 +39,7 @@ class hns_dist_stats(C.Structure):
                 ("region_voxels_sent", C.c_uint64 * 4), ("bytes_sent", C.c_uint64 * 4), ("messages_sent", C.c_uint64), ("exchanges", C.c_uint64)]
 
 
+HNS_DIST_IPC_BLOB_BYTES = 2048
 HNS_DIST_PLAN_ONLY = 1
 
 
@@ -120,6 +121,8 @@ SIGNATURES = {
     "hns_dist_connect_local": (_i, [C.POINTER(C.c_void_p), _i]),
     "hns_dist_connect_loopback": (_i, [_vp]),
     "hns_dist_connect_loopback_rccl": (_i, [_vp]),
+    "hns_dist_ipc_export": (_i, [_vp, _vp]),
+    "hns_dist_connect_ipc": (_i, [_vp, _vp]),
     "hns_dist_owned_leaves": (_u64, [_vp]),
     "hns_dist_first_owned_leaf": (_u64, [_vp]),
     "hns_dist_info": (_i, [_vp, C.POINTER(hns_dist_stats)]),

@@ -19,10 +19,16 @@
 //                      the decomposition lives in this process on one device and a message is a device copy out of the
 //                      peer's send buffer -- the same plan, kernels, streams and events without a wire; used by the tests
 //                      (8 emulated ranks on one GPU) and to measure the per-rank overhead before any wire time.
+//                      "ipc": one process per GPU like RCCL, but one-sided: field memory, message buffers and a page of
+//                      flags of every rank are mapped into its peers (hipIpc*), a rank PUTS its messages straight into
+//                      the peer's receive buffer or ghost voxels with a copy kernel and the two sides meet through
+//                      sequence-numbered flags (ready-to-receive / landed) polled by tiny kernels: no RCCL launch, no
+//                      rendezvous kernel; verified between processes sharing one GPU.
 //
 // Owned results are bit-identical to the single-domain run: every exchange sits where the single-GPU code has a kernel
 // boundary that a stencil crosses, and a ghost voxel is never read beyond the depth its last refresh made valid.
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library itself is opened on first use (see Rccl below)
 
 #include <algorithm>
@@ -169,6 +175,85 @@ __global__ __launch_bounds__(64) void k_halo_copy_all(float* __restrict__ field,
 	}
 }
 
+// ---- one-sided transport (hipIpc-mapped peers): sequence-numbered flags, bounded waits ----
+constexpr int kIpcMaxSegs = 32, kIpcMaxPeers = 16, kIpcFlagSlots = 512;  // flags page: ready[rank] at [rank], landed[rank] at [512 + rank]
+constexpr long long kIpcWaitTicks = 2000000000LL;                      // 20 s of the 100 MHz wall clock, then give up (status word, no hang)
+
+__device__ __forceinline__ uint32_t flag_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void flag_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// sequence numbers wrap: "reached" = not behind
+__device__ bool flag_wait(const uint32_t* flag, uint32_t seq, volatile int* status) {
+	if ((int32_t)(flag_load(flag) - seq) >= 0) return true;
+	const long long t0 = wall_clock64();
+	for (unsigned spins = 1;; ++spins) {
+		if ((int32_t)(flag_load(flag) - seq) >= 0) return true;
+		__builtin_amdgcn_s_sleep(2);
+		if ((spins & 1023u) == 0 && (*status != 0 || wall_clock64() - t0 > kIpcWaitTicks)) {  // a peer gave up or is gone: so do we
+			*status = 1;
+			return false;
+		}
+	}
+}
+
+struct IpcPeers {
+	int n;
+	uint32_t* theirs_ready[kIpcMaxPeers];   // the peer's flag "rank <me> is ready to receive"   (in the PEER's memory)
+	uint32_t* theirs_landed[kIpcMaxPeers];  // the peer's flag "what rank <me> sent has landed"   (in the PEER's memory)
+	int rank[kIpcMaxPeers];
+};
+
+// "my receive side of exchange `seq` may be written": told to every peer; then wait for the same from every peer. One wave
+// does all the waiting of a rank: waiting inside the copy kernel's workgroups filled the device with spinning waves (four
+// processes of a 66k-leaf plume on one GPU: nothing else could be scheduled, every bounded wait ran out).
+__global__ void k_ipc_ready(const IpcPeers peers, const uint32_t* __restrict__ my_flags, const uint32_t seq, int* status) {
+	if ((int)threadIdx.x < peers.n) {
+		flag_store(peers.theirs_ready[threadIdx.x], seq);
+		flag_wait(my_flags + peers.rank[threadIdx.x], seq, status);
+	}
+}
+
+struct IpcSegs {
+	int n;
+	float* dst[kIpcMaxSegs];  // in the peer's memory
+	const float* src[kIpcMaxSegs];
+	unsigned floats[kIpcMaxSegs];
+	unsigned wg0[kIpcMaxSegs + 1];  // first workgroup of every segment
+};
+
+// Copies the segments into the peers' memory, 4,096 floats per workgroup (the receivers are ready: k_ipc_ready ran).
+__global__ __launch_bounds__(256) void k_ipc_put(const IpcSegs segs) {
+	int s = 0;
+	while (s + 1 < segs.n && blockIdx.x >= segs.wg0[s + 1]) ++s;
+	const size_t first = (size_t)(blockIdx.x - segs.wg0[s]) * 4096u;
+	const unsigned n = segs.floats[s];
+	const float* __restrict__ src = segs.src[s];
+	float* __restrict__ dst = segs.dst[s];
+	if ((((uintptr_t)src | (uintptr_t)dst) & 15u) == 0 && (n & 3u) == 0) {
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const size_t i = first + ((size_t)j * 256u + threadIdx.x) * 4u;
+			if (i < n) *(float4*)(dst + i) = *(const float4*)(src + i);
+		}
+	} else {
+#pragma unroll 4
+		for (int j = 0; j < 16; ++j) {
+			const size_t i = first + (size_t)j * 256u + threadIdx.x;
+			if (i < n) dst[i] = src[i];
+		}
+	}
+	__threadfence_system();
+}
+
+// after the puts (kernel boundary + fence): tell every peer its message has landed, then wait for theirs
+__global__ void k_ipc_landed(const IpcPeers peers, const uint32_t* __restrict__ my_flags, const uint32_t seq, int* status) {
+	__threadfence_system();
+	if ((int)threadIdx.x < peers.n) {
+		flag_store(peers.theirs_landed[threadIdx.x], seq);
+		flag_wait(my_flags + kIpcFlagSlots + peers.rank[threadIdx.x], seq, status);
+	}
+}
+
 }  // namespace hns
 
 using namespace hns;
@@ -278,6 +363,20 @@ struct hns_dist {
 	std::vector<hns_dist*> local_ranks;  // "local" transport: every rank of the decomposition, in this process
 	bool single_stream = false;          // local transport: no communication stream, everything in host order on the caller's stream
 	bool loopback = false;               // timing-only transport: every message is answered out of this rank's own send buffer
+	// "ipc" transport: what every peer mapped of its memory into this process, and this rank's own flags
+	struct IpcPeer {
+		char *arena = nullptr, *tables = nullptr;  // the peer's field memory and its table / message-buffer allocation, mapped here
+		uint32_t* flags = nullptr;
+		void* opened[3] = {nullptr, nullptr, nullptr};
+		uint64_t unit_bytes = 0, rbuf_off[2] = {0, 0};
+		int recv_direct[4] = {-1, -1, -1, -1}, recv_voxels[4] = {0, 0, 0, 0};
+	};
+	std::vector<IpcPeer> ipc_peers;  // parallel to `peers`
+	uint32_t* ipc_flags = nullptr;   // fine-grained device memory, written by the peers
+	int* ipc_status = nullptr;       // host-mapped: non-zero once a wait on a peer ran out
+	uint32_t ipc_seq = 0;
+	bool ipc = false;
+	size_t unit_bytes = 0;  // bytes per scalar field over the local leaves (fields sit at multiples of it in the arena)
 	// statistics of the last substep
 	uint64_t bytes_sent[X_COUNT] = {0, 0, 0, 0}, messages_sent = 0, exchanges = 0;
 	// hipEvent bracketing of the pressure loop (communication included)
@@ -422,6 +521,11 @@ void hns_dist_destroy(hns_dist* d) {
 	if (!d) return;
 	if (d->cs) (void)hipStreamSynchronize(d->cs);
 	if (d->comm) (void)rccl().CommDestroy(d->comm);
+	for (hns_dist::IpcPeer& q : d->ipc_peers)
+		for (void* o : q.opened)
+			if (o) (void)hipIpcCloseMemHandle(o);
+	if (d->ipc_flags) (void)hipFree(d->ipc_flags);
+	if (d->ipc_status) (void)hipHostFree(d->ipc_status);
 	for (hipEvent_t e : d->tev) (void)hipEventDestroy(e);
 	if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
 	for (int i = 0; i < 2; ++i) {
@@ -479,6 +583,7 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 	// device state: u, adv (Vec3f) | div, p_a, p_b | phi, phi_next per scalar | upload/download staging (Vec3f over the owned leaves)
 	{
 		const size_t unit = pad256(sizeof(float) * 512 * (size_t)std::max(n_local, 1));
+		d->unit_bytes = unit;
 		const size_t units = 3 + 3 + 3 + 2 * (size_t)n_scalars + 3;
 		if ((rc = hns_arena_get(unit * units, d->device, &d->arena, &d->arena_bytes)) != HNS_OK) return bail(rc);
 		if (hipMemset(d->arena, 0, unit * units) != hipSuccess) return bail(fail(HNS_ERR_HIP, "hns_dist_create: clearing the field memory failed"));
@@ -623,6 +728,87 @@ int hns_dist_connect_loopback_rccl(hns_dist* d) {
 	HNS_NCCL(rccl().GetUniqueId(&id));
 	HNS_NCCL(rccl().CommInitRank(&d->comm, 1, id, 0));
 	d->loopback = true;
+	return HNS_OK;
+}
+
+// ---- "ipc" transport: one process per GPU, peers' memory mapped with hipIpc*, one-sided puts and flags ----
+namespace {
+struct IpcBlob {  // what a rank tells the others (hns_dist_ipc_export): plain data, HNS_DIST_IPC_BLOB_BYTES on the wire
+	uint32_t magic, world, rank, n_peers;
+	uint64_t unit_bytes, pid;
+	hipIpcMemHandle_t arena, tables, flags;
+	struct PeerInfo {
+		int32_t rank;
+		int32_t recv_direct[4], recv_voxels[4];
+		uint64_t rbuf_off[2];
+	} peer[kIpcMaxPeers];
+};
+static_assert(sizeof(IpcBlob) <= HNS_DIST_IPC_BLOB_BYTES, "HNS_DIST_IPC_BLOB_BYTES is too small");
+constexpr uint32_t kIpcMagic = 0x48495043u;
+}  // namespace
+
+int hns_dist_ipc_export(hns_dist* d, void* out_blob) {
+	if (!d || !out_blob) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_ipc_export: null argument");
+	if (!d->gA) return fail(HNS_ERR_NO_DEVICE, "hns_dist_ipc_export: plan-only handle");
+	if (d->peers.size() > (size_t)kIpcMaxPeers || d->world > kIpcFlagSlots) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_ipc_export: more than 16 peers or 512 ranks");
+	if (!d->ipc_flags) {
+		// fine-grained: written by kernels of other processes / devices while kernels here poll it
+		if (hipExtMallocWithFlags((void**)&d->ipc_flags, sizeof(uint32_t) * 2 * kIpcFlagSlots, hipDeviceMallocFinegrained) != hipSuccess) {
+			(void)hipGetLastError();
+			return fail(HNS_ERR_HIP, "hns_dist_ipc_export: allocating the flag page failed");
+		}
+		HNS_HIP(hipMemset(d->ipc_flags, 0, sizeof(uint32_t) * 2 * kIpcFlagSlots));
+		HNS_HIP(hipHostMalloc((void**)&d->ipc_status, 64, hipHostMallocMapped));
+		*d->ipc_status = 0;
+		HNS_HIP(hipDeviceSynchronize());
+	}
+	IpcBlob b;
+	memset(&b, 0, sizeof(b));
+	b.magic = kIpcMagic, b.world = (uint32_t)d->world, b.rank = (uint32_t)d->rank, b.n_peers = (uint32_t)d->peers.size();
+	b.unit_bytes = d->unit_bytes, b.pid = (uint64_t)getpid();
+	HNS_HIP(hipIpcGetMemHandle(&b.arena, d->arena));
+	HNS_HIP(hipIpcGetMemHandle(&b.tables, d->tables));
+	HNS_HIP(hipIpcGetMemHandle(&b.flags, d->ipc_flags));
+	for (size_t i = 0; i < d->peers.size(); ++i) {
+		const Peer& p = d->peers[i];
+		b.peer[i].rank = p.rank;
+		for (int t = 0; t < X_COUNT; ++t) b.peer[i].recv_direct[t] = p.recv[t].direct, b.peer[i].recv_voxels[t] = p.recv[t].voxels;
+		for (int k = 0; k < 2; ++k) b.peer[i].rbuf_off[k] = (uint64_t)((char*)p.rbuf[k] - (char*)d->tables);
+	}
+	memset(out_blob, 0, HNS_DIST_IPC_BLOB_BYTES);
+	memcpy(out_blob, &b, sizeof(b));
+	return HNS_OK;
+}
+
+// Collective in effect: every rank exports, the blobs travel by any host means (DistRank.connect_ipc gathers them over
+// torch.distributed), every rank connects with all `world` blobs in rank order. Ranks must be separate processes.
+int hns_dist_connect_ipc(hns_dist* d, const void* blobs) {
+	if (!d || !blobs) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_ipc: null argument");
+	if (!d->gA || !d->ipc_flags) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_ipc: call hns_dist_ipc_export first");
+	if (d->comm || d->loopback || d->ipc || !d->local_ranks.empty()) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_ipc: already connected");
+	HNS_TRY(ensure_comm_stream(d));
+	d->ipc_peers.assign(d->peers.size(), hns_dist::IpcPeer());
+	for (size_t i = 0; i < d->peers.size(); ++i) {
+		IpcBlob b;
+		memcpy(&b, (const char*)blobs + (size_t)d->peers[i].rank * HNS_DIST_IPC_BLOB_BYTES, sizeof(b));
+		if (b.magic != kIpcMagic || (int)b.world != d->world || (int)b.rank != d->peers[i].rank) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_ipc: blob of the wrong rank or world");
+		if (b.pid == (uint64_t)getpid()) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_ipc: ranks must be separate processes (use hns_dist_connect_local inside one)");
+		const IpcBlob::PeerInfo* me = nullptr;
+		for (uint32_t k = 0; k < b.n_peers && k < (uint32_t)kIpcMaxPeers; ++k)
+			if (b.peer[k].rank == d->rank) me = &b.peer[k];
+		if (!me) return fail(HNS_ERR_RUNTIME, "hns_dist_connect_ipc: a peer does not list this rank (plans disagree)");
+		hns_dist::IpcPeer& q = d->ipc_peers[i];
+		for (int t = 0; t < X_COUNT; ++t) {
+			if (me->recv_voxels[t] != d->peers[i].send[t].voxels) return fail(HNS_ERR_RUNTIME, "hns_dist_connect_ipc: send/receive plans of two ranks disagree");
+			q.recv_direct[t] = me->recv_direct[t], q.recv_voxels[t] = me->recv_voxels[t];
+		}
+		q.unit_bytes = b.unit_bytes, q.rbuf_off[0] = me->rbuf_off[0], q.rbuf_off[1] = me->rbuf_off[1];
+		HNS_HIP(hipIpcOpenMemHandle(&q.opened[0], b.arena, hipIpcMemLazyEnablePeerAccess));
+		HNS_HIP(hipIpcOpenMemHandle(&q.opened[1], b.tables, hipIpcMemLazyEnablePeerAccess));
+		HNS_HIP(hipIpcOpenMemHandle(&q.opened[2], b.flags, hipIpcMemLazyEnablePeerAccess));
+		q.arena = (char*)q.opened[0], q.tables = (char*)q.opened[1], q.flags = (uint32_t*)q.opened[2];
+	}
+	d->ipc = true;
 	return HNS_OK;
 }
 
@@ -826,8 +1012,8 @@ template <class BoundaryFn>
 int post(hns_dist* d, int type, std::vector<std::pair<float*, int>> fields, hipStream_t st, BoundaryFn boundary) {
 	if (d->pending.active) return fail(HNS_ERR_RUNTIME, "hns_dist: an exchange is already in flight");
 	if (d->world == 1) return boundary(st);  // nobody to talk to: the boundary range is empty, keep everything on one stream
-	if (!d->comm && !d->loopback && d->local_ranks.empty())
-		return fail(HNS_ERR_RUNTIME, "hns_dist: not connected (call hns_dist_connect_rccl or hns_dist_connect_local first)");
+	if (!d->comm && !d->loopback && !d->ipc && d->local_ranks.empty())
+		return fail(HNS_ERR_RUNTIME, "hns_dist: not connected (call hns_dist_connect_rccl, hns_dist_connect_ipc or hns_dist_connect_local first)");
 	Pending& x = d->pending;
 	x.active = true, x.type = type, x.parity = d->parity, x.fields = std::move(fields);
 	d->parity ^= 1;
@@ -844,7 +1030,46 @@ int post(hns_dist* d, int type, std::vector<std::pair<float*, int>> fields, hipS
 		if (fl) d->bytes_sent[type] += sizeof(float) * fl, ++d->messages_sent;
 	}
 	++d->exchanges;
-	if (d->comm) {
+	if (d->ipc) {
+		const uint32_t seq = ++d->ipc_seq;
+		IpcPeers ip;
+		ip.n = (int)d->peers.size();
+		for (int i = 0; i < ip.n; ++i) {
+			ip.theirs_ready[i] = d->ipc_peers[(size_t)i].flags + d->rank;
+			ip.theirs_landed[i] = d->ipc_peers[(size_t)i].flags + kIpcFlagSlots + d->rank;
+			ip.rank[i] = d->peers[(size_t)i].rank;
+		}
+		hipLaunchKernelGGL(k_ipc_ready, dim3(1), dim3(64), 0, cs, ip, (const uint32_t*)d->ipc_flags, seq, d->ipc_status);
+		IpcSegs sg;
+		sg.n = 0, sg.wg0[0] = 0;
+		auto flush = [&]() {
+			if (sg.n) hipLaunchKernelGGL(k_ipc_put, dim3(sg.wg0[sg.n]), dim3(256), 0, cs, sg);
+			sg.n = 0;
+		};
+		for (size_t i = 0; i < d->peers.size(); ++i) {
+			Peer& p = d->peers[i];
+			const hns_dist::IpcPeer& q = d->ipc_peers[i];
+			const Region& rs = p.send[type];
+			int before = 0;
+			for (auto& f : x.fields) {
+				const size_t fl = (size_t)rs.voxels * (size_t)f.second;
+				if (fl) {
+					if (sg.n == kIpcMaxSegs) flush();
+					// the same field in the peer's memory: fields sit at the same multiples of the (peer's) unit
+					const size_t unit_index = (size_t)((char*)f.first - (char*)d->arena) / d->unit_bytes;
+					char* dst = q.recv_direct[type] >= 0 ? q.arena + unit_index * q.unit_bytes + sizeof(float) * 512 * (size_t)q.recv_direct[type] * (size_t)f.second
+					                                     : q.tables + q.rbuf_off[x.parity] + sizeof(float) * (size_t)before * (size_t)q.recv_voxels[type];
+					sg.dst[sg.n] = (float*)dst, sg.src[sg.n] = segment(rs, f.first, f.second, p.sbuf[x.parity], before), sg.floats[sg.n] = (unsigned)fl;
+					sg.wg0[sg.n + 1] = sg.wg0[sg.n] + (unsigned)((fl + 4095) / 4096);
+					++sg.n;
+				}
+				before += f.second;
+			}
+		}
+		flush();
+		hipLaunchKernelGGL(k_ipc_landed, dim3(1), dim3(64), 0, cs, ip, (const uint32_t*)d->ipc_flags, seq, d->ipc_status);
+		HNS_TRY(launch_status("hns_dist: one-sided exchange"));
+	} else if (d->comm) {
 		HNS_NCCL(rccl().GroupStart());
 		for (Peer& p : d->peers) {
 			const Region &rs = p.send[type], &rr = p.recv[type];
@@ -883,7 +1108,7 @@ int post(hns_dist* d, int type, std::vector<std::pair<float*, int>> fields, hipS
 int complete(hns_dist* d, hipStream_t st) {
 	Pending& x = d->pending;
 	if (!x.active) return HNS_OK;
-	if (!d->comm && !d->loopback) {  // local transport: pull every peer's message out of its send buffer, once the peer has packed it
+	if (!d->comm && !d->loopback && !d->ipc) {  // local transport: pull every peer's message out of its send buffer, once the peer has packed it
 		for (Peer& p : d->peers) {
 			// the peer packed this message into its buffer of the same parity when it posted the same exchange; it may already
 			// have posted the NEXT one (other parity) -- never the one after, which its own complete() of this one precedes
@@ -1024,6 +1249,7 @@ int hns_dist_core_substep(hns_dist* d, int iterations, float dt, void* stream) {
 	HNS_TRY(check_step(d, iterations, dt));
 	if (!d->gA) return fail(HNS_ERR_NO_DEVICE, "hns_dist_core_substep: plan-only handle (there is no CPU fallback)");
 	if (!d->local_ranks.empty() && d->world > 1) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_core_substep: locally connected ranks step together (hns_dist_local_core_substep)");
+	if (d->ipc_status && *(volatile int*)d->ipc_status) return fail(HNS_ERR_RUNTIME, "hns_dist: a peer did not answer within 20 s (one-sided transport); results are invalid");
 	memset(d->bytes_sent, 0, sizeof(d->bytes_sent));
 	d->messages_sent = d->exchanges = 0;
 	Step s{d, iterations, dt, (hipStream_t)stream};
@@ -1083,6 +1309,7 @@ int hns_dist_synchronize(hns_dist* d, void* stream) {
 	if (!d) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_synchronize: null handle");
 	HNS_HIP(hipStreamSynchronize((hipStream_t)stream));
 	if (d->cs) HNS_HIP(hipStreamSynchronize(d->cs));
+	if (d->ipc_status && *(volatile int*)d->ipc_status) return fail(HNS_ERR_RUNTIME, "hns_dist: a peer did not answer within 20 s (one-sided transport); results are invalid");
 	return HNS_OK;
 }
 

@@ -119,6 +119,22 @@ class DistRank:
         raw = bytes(t.cpu().tolist())
         _raise(lib.hns_dist_connect_rccl(self._ptr, C.create_string_buffer(raw, 128)))
 
+    def connect_ipc(self, group=None) -> None:
+        """Collective over torch.distributed (any backend): every rank exports the handles of its field memory, message
+        buffers and flag page, all ranks gather them and map their peers' (hns_dist_connect_ipc). One process per rank."""
+        import torch
+        import torch.distributed as dist
+
+        n = _lib.HNS_DIST_IPC_BLOB_BYTES
+        mine = (C.c_ubyte * n)()
+        _raise(lib.hns_dist_ipc_export(self._ptr, mine))
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.frombuffer(bytearray(bytes(mine)), dtype=torch.uint8).to(dev)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=group)
+        blobs = b"".join(bytes(o.cpu().numpy().tobytes()) for o in out)
+        _raise(lib.hns_dist_connect_ipc(self._ptr, C.create_string_buffer(blobs, n * self.world)))
+
     @staticmethod
     def connect_local(ranks: Sequence["DistRank"]) -> None:
         arr = (C.c_void_p * len(ranks))(*[r._ptr for r in ranks])
@@ -200,7 +216,7 @@ class SlabBench:
     ONE domain (e.g. BASELINE.json configs[4], the 1024^3-extent plume) split into `world` contiguous leaf ranges."""
 
     def __init__(self, slab_origins: np.ndarray, R: int, rank: int, world: int, iterations: int, dt: float, partition: bool = False,
-                 sweeps_per_exchange: int = 0, connect: bool = True):
+                 sweeps_per_exchange: int = 0, connect: bool = True, transport: str = "rccl"):
         import torch
 
         from . import fields
@@ -211,7 +227,7 @@ class SlabBench:
         self.iterations, self.dt, self.vs = iterations, dt, 1.0 / R  # same voxel size (and omega) as the single-GPU workload
         self.rank_obj = DistRank(glob, world, rank, self.vs, n_scalars=1, sweeps_per_exchange=sweeps_per_exchange)
         if world > 1 and connect:
-            self.rank_obj.connect_rccl()
+            self.rank_obj.connect_ipc() if transport == "ipc" else self.rank_obj.connect_rccl()
         d = self.rank_obj
         own = glob[d.first_owned:d.first_owned + d.n_owned].copy()
         if not partition:

@@ -292,6 +292,14 @@ void hns_dist_destroy(hns_dist*);
  * by any means (torch.distributed broadcast, MPI, a file); every rank then calls hns_dist_connect_rccl (collective). */
 int hns_dist_unique_id(void* out128);
 int hns_dist_connect_rccl(hns_dist*, const void* unique_id128);
+/* Transport, one-sided over mapped peer memory (one process per GPU, xGMI peer access; also between processes sharing one
+ * GPU): every rank calls hns_dist_ipc_export, the HNS_DIST_IPC_BLOB_BYTES-byte blobs travel by any host means, every rank
+ * calls hns_dist_connect_ipc with all `world` blobs in rank order. A rank then PUTS its messages into the peer's receive
+ * buffer / ghost voxels with a copy kernel; the two sides meet through sequence-numbered flags in device memory (bounded
+ * waits: a peer that does not answer within 20 s makes the next call fail instead of hanging the device). */
+#define HNS_DIST_IPC_BLOB_BYTES 2048
+int hns_dist_ipc_export(hns_dist*, void* out_blob);
+int hns_dist_connect_ipc(hns_dist*, const void* blobs_of_all_ranks);
 /* Transport, local: all `world` ranks live in this process on ONE device; a message is a device copy out of the peer's
  * send buffer. Same plan, kernels, streams and events as the RCCL path (tests; per-rank overhead without a wire). */
 int hns_dist_connect_local(hns_dist* const* ranks, int world);

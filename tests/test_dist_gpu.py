@@ -190,6 +190,54 @@ def test_rccl_carries_the_loopback_messages_exactly(case):
     assert np.array_equal(got["scalars"][0], want["scalars"][0])
 
 
+def _run_processes(world, case, k, iters, substeps, tmp_path, timeout=420):
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_process_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), case, str(k), str(iters), str(substeps), str(tmp_path)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout)[0])
+    finally:
+        for p in procs:  # exactly the processes started here
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:] if r < len(outs) else ''}"
+    return [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+
+
+@pytest.mark.parametrize("case,world,k,iters", [("dense32", 2, 4, 7), ("plume", 3, 2, 7), ("plume12", 4, 3, 9), ("dense64", 2, 0, 50)])
+def test_one_process_per_rank_over_mapped_peer_memory(case, world, k, iters, tmp_path):
+    """The multi-process path for real: `world` PROCESSES (here sharing the one GPU), each a rank with its own streams, the
+    halos put into the peer's memory through hipIpc mappings and the ranks meeting through device-side flags while their
+    kernels run concurrently (hns_dist_connect_ipc). Owned results equal the single-grid run bit for bit. (At most 4 processes:
+    with 8 sharing one GPU a rank's waiting wave can keep the device from ever scheduling the process it waits for, and the
+    20 s bounded wait ran out in about half of the runs -- reported as an error, not a hang; with one process per GPU a
+    waiting wave shares the device with nobody it waits for.)"""
+    from dist_process_worker import case_leaves
+
+    origins, R = case_leaves(case)
+    names, substeps = ["density", "temperature"], 2
+    _, want = single_grid(origins, R, names, iters, substeps)
+    got = _run_processes(world, case, k, iters, substeps, tmp_path)
+    b = HD.partition_bounds(len(origins), world)
+    for r, g in enumerate(got):
+        sl = slice(b[r] * 512, b[r + 1] * 512)
+        assert np.array_equal(g["vel"], want["vel"][sl]), f"rank {r} velocity"
+        for n in names:
+            assert np.array_equal(g[n], want[n][sl]), f"rank {r} {n}"
+        assert int(g["messages"]) > 0
+
+
 def test_unconnected_ranks_refuse_to_step():
     import hnanosolver_amd as H
 
