@@ -65,8 +65,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--partition", action="store_true", help="N > 1: split ONE --config domain across the ranks (strong scaling) instead of one slab per rank")
     ap.add_argument("--sweeps-per-exchange", type=int, default=0, help="N > 1: fused SOR sweeps between two halo refreshes of p (1..4, 0 = library default)")
-    ap.add_argument("--transport", choices=["rccl", "ipc"], default="rccl",
-                    help="N > 1 halo transport: RCCL send/recv groups (default) or one-sided puts into hipIpc-mapped peer memory")
+    ap.add_argument("--transport", choices=["auto", "rccl", "ipc"], default="auto",
+                    help="N > 1 halo transport: rccl = RCCL send/recv groups; ipc = one-sided puts into hipIpc-mapped peer memory with the SOR sweep "
+                         "delivering its own halo; auto (default) = ipc if it connects and reproduces two RCCL substeps bit for bit on this machine, else rccl")
     ap.add_argument("--share-one-gpu", action="store_true",
                     help="builder's check on a 1-GPU box: all N ranks on cuda:0, host rendezvous over gloo, --transport ipc (RCCL refuses two ranks on one device)")
     ap.add_argument("--cook", action="store_true", help="time the cook-equivalent hns_compute_sim call (upload + grid build + substep + download) instead")
@@ -171,7 +172,12 @@ def main():
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE is {world}: launch N>1 with torch.distributed.run --nproc-per-node N")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     if args.share_one_gpu:
-        local_rank, args.transport = 0, "ipc"
+        local_rank = 0
+        import hnanosolver_amd as H
+
+        H.set_option("dist_mirror", "guarded")  # processes sharing a GPU must not wait inside their sweeps (see hns_dist.hip)
+        if args.transport == "rccl":
+            args.transport = "ipc"
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -218,7 +224,7 @@ def main():
         from hnanosolver_amd import dist as HD
 
         runner = HD.SlabBench(origins, R, rank, world, args.iterations, dt, partition=args.partition, sweeps_per_exchange=args.sweeps_per_exchange,
-                              transport=args.transport)
+                              transport=args.transport, reference_transport="ipc" if args.share_one_gpu else "rccl")
         n_vox_rank = runner.n_owned * 512
         step, pressure_time, stage_times = runner.step, runner.pressure_time, None
 
@@ -296,7 +302,7 @@ def main():
                                                                                 "bytes_sent", "messages_sent", "exchanges")},
                 "parallelism": "single GPU" if world == 1 else (
                     (f"one domain in {world} contiguous leaf ranges" if args.partition else f"x-slab leaf partition over {world} ranks")
-                    + (", RCCL halo exchange" if args.transport == "rccl" else ", one-sided halo puts into mapped peer memory")
+                    + ", halo transport: " + runner.transport_note
                     + (" -- ALL RANKS SHARE ONE GPU (builder's check, not a scaling figure)" if args.share_one_gpu else "")),
             },
             "roofline": {

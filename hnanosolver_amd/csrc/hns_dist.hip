@@ -38,6 +38,7 @@
 #include <utility>
 
 #include "hns_device.hpp"
+#include "hns_flags.hpp"
 
 #define HNS_TRY(call)                    \
 	do {                                 \
@@ -175,26 +176,8 @@ __global__ __launch_bounds__(64) void k_halo_copy_all(float* __restrict__ field,
 	}
 }
 
-// ---- one-sided transport (hipIpc-mapped peers): sequence-numbered flags, bounded waits ----
-constexpr int kIpcMaxSegs = 32, kIpcMaxPeers = 16, kIpcFlagSlots = 512;  // flags page: ready[rank] at [rank], landed[rank] at [512 + rank]
-constexpr long long kIpcWaitTicks = 2000000000LL;                      // 20 s of the 100 MHz wall clock, then give up (status word, no hang)
-
-__device__ __forceinline__ uint32_t flag_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void flag_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-
-// sequence numbers wrap: "reached" = not behind
-__device__ bool flag_wait(const uint32_t* flag, uint32_t seq, volatile int* status) {
-	if ((int32_t)(flag_load(flag) - seq) >= 0) return true;
-	const long long t0 = wall_clock64();
-	for (unsigned spins = 1;; ++spins) {
-		if ((int32_t)(flag_load(flag) - seq) >= 0) return true;
-		__builtin_amdgcn_s_sleep(2);
-		if ((spins & 1023u) == 0 && (*status != 0 || wall_clock64() - t0 > kIpcWaitTicks)) {  // a peer gave up or is gone: so do we
-			*status = 1;
-			return false;
-		}
-	}
-}
+// ---- one-sided transport (hipIpc-mapped peers): sequence-numbered flags (hns_flags.hpp), bounded waits ----
+constexpr int kIpcMaxSegs = 32, kIpcMaxPeers = kMirrorMaxPeers;
 
 struct IpcPeers {
 	int n;
@@ -250,8 +233,17 @@ __global__ void k_ipc_landed(const IpcPeers peers, const uint32_t* __restrict__ 
 	__threadfence_system();
 	if ((int)threadIdx.x < peers.n) {
 		flag_store(peers.theirs_landed[threadIdx.x], seq);
-		flag_wait(my_flags + kIpcFlagSlots + peers.rank[threadIdx.x], seq, status);
+		flag_wait(my_flags + kFlagLanded + peers.rank[threadIdx.x], seq, status);
 	}
+}
+
+// mirror pressure loop: a rank without boundary waves still tells its peers that its sweep is complete; and, after the last
+// sweep of a solve, a rank waits for its peers' before the gradient kernel reads the ghost voxels they wrote
+__global__ void k_sweep_signal(const RbgsMirror m) {
+	if ((int)threadIdx.x < m.n_peers) flag_store(m.peer_flag[threadIdx.x], m.seq);
+}
+__global__ void k_sweep_wait(const RbgsMirror m) {
+	if ((int)threadIdx.x < m.n_peers) flag_wait(m.my_flags + kFlagSweep + m.peer_rank[threadIdx.x], m.seq, m.status);
 }
 
 }  // namespace hns
@@ -370,6 +362,8 @@ struct hns_dist {
 		void* opened[3] = {nullptr, nullptr, nullptr};
 		uint64_t unit_bytes = 0, rbuf_off[2] = {0, 0};
 		int recv_direct[4] = {-1, -1, -1, -1}, recv_voxels[4] = {0, 0, 0, 0};
+		uint64_t recv_p_leaf_off = 0;
+		uint32_t recv_p_leaves = 0;
 	};
 	std::vector<IpcPeer> ipc_peers;  // parallel to `peers`
 	uint32_t* ipc_flags = nullptr;   // fine-grained device memory, written by the peers
@@ -377,6 +371,13 @@ struct hns_dist {
 	uint32_t ipc_seq = 0;
 	bool ipc = false;
 	size_t unit_bytes = 0;  // bytes per scalar field over the local leaves (fields sit at multiples of it in the arena)
+	// "mirror" pressure loop (sweeps_per_exchange = 1 over the ipc or local transport): the sweep kernel itself writes its
+	// boundary rows into the peers' ghost voxels (hns_pressure.hip: k_rbgs_pair_mirror)
+	bool mirror = false;
+	void* mir_tables = nullptr;
+	RbgsMirror mir;             // everything but the destination arrays and the sweep number
+	float* mir_peer_p[2][kMirrorMaxPeers];  // p_a / p_b of every peer
+	uint32_t sweep_seq = 0;
 	// statistics of the last substep
 	uint64_t bytes_sent[X_COUNT] = {0, 0, 0, 0}, messages_sent = 0, exchanges = 0;
 	// hipEvent bracketing of the pressure loop (communication included)
@@ -511,6 +512,76 @@ size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
 
+// ---- flags and the mirror pressure loop (ipc and local transports) ----
+namespace {
+
+int ensure_flags(hns_dist* d) {
+	if (d->ipc_flags) return HNS_OK;
+	// fine-grained: written by kernels of other processes / devices while kernels here poll it
+	if (hipExtMallocWithFlags((void**)&d->ipc_flags, sizeof(uint32_t) * kFlagWords, hipDeviceMallocFinegrained) != hipSuccess) {
+		(void)hipGetLastError();
+		return fail(HNS_ERR_HIP, "hns_dist: allocating the flag page failed");
+	}
+	HNS_HIP(hipMemset(d->ipc_flags, 0, sizeof(uint32_t) * kFlagWords));
+	HNS_HIP(hipHostMalloc((void**)&d->ipc_status, 64, hipHostMallocMapped));
+	*d->ipc_status = 0;
+	HNS_HIP(hipDeviceSynchronize());
+	return HNS_OK;
+}
+
+// remote_leaf[i][j]: peer i's local index of its ghost copy of the j-th leaf of this rank's send region of type X_P;
+// peer_pa / peer_pb / peer_flags: that peer's p arrays and flag page as addressable from this process
+int setup_mirror(hns_dist* d, const std::vector<std::vector<int>>& remote_leaf, const std::vector<float*>& peer_pa, const std::vector<float*>& peer_pb,
+                 const std::vector<uint32_t*>& peer_flags) {
+	if (d->peers.size() > (size_t)kMirrorMaxPeers || d->world > kFlagSlots) return HNS_OK;  // (stay on the exchanged pressure loop)
+	HNS_TRY(ensure_flags(d));
+	const int nB = d->nB;
+	std::vector<std::vector<std::pair<int2, const unsigned char*>>> per_leaf((size_t)nB);
+	for (size_t i = 0; i < d->peers.size(); ++i) {
+		const Region& r = d->peers[i].send[X_P];
+		if (remote_leaf[i].size() != r.leaf.size()) return fail(HNS_ERR_RUNTIME, "hns_dist: send/receive plans of two ranks disagree");
+		for (size_t j = 0; j < r.leaf.size(); ++j) {
+			if (r.leaf[j] < 0 || r.leaf[j] >= nB) return fail(HNS_ERR_RUNTIME, "hns_dist: a mirrored leaf is not a boundary leaf");
+			per_leaf[(size_t)r.leaf[j]].push_back({int2{(int)i, remote_leaf[i][j]}, r.mask.data() + j * 64});
+		}
+	}
+	std::vector<int> first((size_t)nB + 1, 0);
+	std::vector<int2> entry;
+	std::vector<unsigned char> mask;
+	for (int l = 0; l < nB; ++l) {
+		first[(size_t)l] = (int)entry.size();
+		for (auto& e : per_leaf[(size_t)l]) {
+			entry.push_back(e.first);
+			mask.insert(mask.end(), e.second, e.second + 64);
+		}
+	}
+	first[(size_t)nB] = (int)entry.size();
+	const size_t b0 = pad256(sizeof(int) * first.size()), b1 = pad256(sizeof(int2) * std::max<size_t>(entry.size(), 1)), b2 = pad256(std::max<size_t>(mask.size(), 1));
+	if (hipMalloc(&d->mir_tables, b0 + b1 + b2 + 256) != hipSuccess) return fail(HNS_ERR_HIP, "hns_dist: allocating the mirror tables failed");
+	char* q = (char*)d->mir_tables;
+	HNS_HIP(hipMemcpy(q, first.data(), sizeof(int) * first.size(), hipMemcpyHostToDevice));
+	if (!entry.empty()) HNS_HIP(hipMemcpy(q + b0, entry.data(), sizeof(int2) * entry.size(), hipMemcpyHostToDevice));
+	if (!mask.empty()) HNS_HIP(hipMemcpy(q + b0 + b1, mask.data(), mask.size(), hipMemcpyHostToDevice));
+	RbgsMirror& m = d->mir;
+	memset(&m, 0, sizeof(m));
+	m.n_boundary = nB, m.n_peers = (int)d->peers.size();
+	m.first = (const int*)q, m.entry = (const int2*)(q + b0), m.mask = (const unsigned char*)(q + b0 + b1);
+	m.count = (unsigned*)(q + b0 + b1 + b2);
+	for (size_t i = 0; i < d->peers.size(); ++i) {
+		m.peer_flag[i] = peer_flags[i] + kFlagSweep + d->rank;
+		m.peer_rank[i] = d->peers[i].rank;
+		d->mir_peer_p[0][i] = peer_pa[i], d->mir_peer_p[1][i] = peer_pb[i];
+	}
+	m.my_flags = d->ipc_flags, m.status = d->ipc_status;
+	HNS_TRY(hns_rbgs_count_boundary_records(d->gO, nB, m.count, &m.n_boundary_records, nullptr));
+	d->mirror = true;
+	return HNS_OK;
+}
+
+bool mirror_wanted(const hns_dist* d) { return d->k == 1 && d->world > 1 && options().dist_mirror.load() != 0; }
+
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------------------------
 // create / destroy
 // ---------------------------------------------------------------------------------------------------------------
@@ -524,6 +595,7 @@ void hns_dist_destroy(hns_dist* d) {
 	for (hns_dist::IpcPeer& q : d->ipc_peers)
 		for (void* o : q.opened)
 			if (o) (void)hipIpcCloseMemHandle(o);
+	if (d->mir_tables) (void)hipFree(d->mir_tables);
 	if (d->ipc_flags) (void)hipFree(d->ipc_flags);
 	if (d->ipc_status) (void)hipHostFree(d->ipc_status);
 	for (hipEvent_t e : d->tev) (void)hipEventDestroy(e);
@@ -713,6 +785,20 @@ int hns_dist_connect_loopback(hns_dist* d) {
 	if (d->comm || !d->local_ranks.empty()) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_loopback: already connected");
 	HNS_TRY(ensure_comm_stream(d));
 	d->loopback = true;
+	if (mirror_wanted(d)) {  // the mirroring pressure loop, looped back: boundary rows go into this rank's own ghost leaves, flags to itself
+		HNS_TRY(ensure_flags(d));
+		std::vector<std::vector<int>> remote(d->peers.size());
+		std::vector<float*> pa, pb;
+		std::vector<uint32_t*> fl;
+		for (size_t i = 0; i < d->peers.size(); ++i) {
+			const Peer& p = d->peers[i];
+			for (size_t j = 0; j < p.send[X_P].leaf.size(); ++j)
+				remote[i].push_back(p.recv[X_P].leaf.empty() ? d->nB + d->nI : p.recv[X_P].leaf[j % p.recv[X_P].leaf.size()]);
+			pa.push_back(d->p_a), pb.push_back(d->p_b);
+			fl.push_back(d->ipc_flags + (p.rank - d->rank));  // (so that the flag this rank raises "on the peer" is the one it waits for)
+		}
+		if (d->nG > 0) HNS_TRY(setup_mirror(d, remote, pa, pb, fl));
+	}
 	return HNS_OK;
 }
 
@@ -741,6 +827,8 @@ struct IpcBlob {  // what a rank tells the others (hns_dist_ipc_export): plain d
 		int32_t rank;
 		int32_t recv_direct[4], recv_voxels[4];
 		uint64_t rbuf_off[2];
+		uint64_t recv_p_leaf_off;  // where (in the tables allocation) the local indices of the ghost leaves of region X_P are
+		uint32_t recv_p_leaves, pad;
 	} peer[kIpcMaxPeers];
 };
 static_assert(sizeof(IpcBlob) <= HNS_DIST_IPC_BLOB_BYTES, "HNS_DIST_IPC_BLOB_BYTES is too small");
@@ -750,18 +838,8 @@ constexpr uint32_t kIpcMagic = 0x48495043u;
 int hns_dist_ipc_export(hns_dist* d, void* out_blob) {
 	if (!d || !out_blob) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_ipc_export: null argument");
 	if (!d->gA) return fail(HNS_ERR_NO_DEVICE, "hns_dist_ipc_export: plan-only handle");
-	if (d->peers.size() > (size_t)kIpcMaxPeers || d->world > kIpcFlagSlots) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_ipc_export: more than 16 peers or 512 ranks");
-	if (!d->ipc_flags) {
-		// fine-grained: written by kernels of other processes / devices while kernels here poll it
-		if (hipExtMallocWithFlags((void**)&d->ipc_flags, sizeof(uint32_t) * 2 * kIpcFlagSlots, hipDeviceMallocFinegrained) != hipSuccess) {
-			(void)hipGetLastError();
-			return fail(HNS_ERR_HIP, "hns_dist_ipc_export: allocating the flag page failed");
-		}
-		HNS_HIP(hipMemset(d->ipc_flags, 0, sizeof(uint32_t) * 2 * kIpcFlagSlots));
-		HNS_HIP(hipHostMalloc((void**)&d->ipc_status, 64, hipHostMallocMapped));
-		*d->ipc_status = 0;
-		HNS_HIP(hipDeviceSynchronize());
-	}
+	if (d->peers.size() > (size_t)kIpcMaxPeers || d->world > kFlagSlots) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_ipc_export: more than 16 peers or 512 ranks");
+	HNS_TRY(ensure_flags(d));
 	IpcBlob b;
 	memset(&b, 0, sizeof(b));
 	b.magic = kIpcMagic, b.world = (uint32_t)d->world, b.rank = (uint32_t)d->rank, b.n_peers = (uint32_t)d->peers.size();
@@ -774,6 +852,7 @@ int hns_dist_ipc_export(hns_dist* d, void* out_blob) {
 		b.peer[i].rank = p.rank;
 		for (int t = 0; t < X_COUNT; ++t) b.peer[i].recv_direct[t] = p.recv[t].direct, b.peer[i].recv_voxels[t] = p.recv[t].voxels;
 		for (int k = 0; k < 2; ++k) b.peer[i].rbuf_off[k] = (uint64_t)((char*)p.rbuf[k] - (char*)d->tables);
+		b.peer[i].recv_p_leaf_off = (uint64_t)((char*)p.recv[X_P].d_leaf - (char*)d->tables), b.peer[i].recv_p_leaves = (uint32_t)p.recv[X_P].leaf.size();
 	}
 	memset(out_blob, 0, HNS_DIST_IPC_BLOB_BYTES);
 	memcpy(out_blob, &b, sizeof(b));
@@ -807,8 +886,23 @@ int hns_dist_connect_ipc(hns_dist* d, const void* blobs) {
 		HNS_HIP(hipIpcOpenMemHandle(&q.opened[1], b.tables, hipIpcMemLazyEnablePeerAccess));
 		HNS_HIP(hipIpcOpenMemHandle(&q.opened[2], b.flags, hipIpcMemLazyEnablePeerAccess));
 		q.arena = (char*)q.opened[0], q.tables = (char*)q.opened[1], q.flags = (uint32_t*)q.opened[2];
+		q.recv_p_leaf_off = me->recv_p_leaf_off, q.recv_p_leaves = me->recv_p_leaves;
 	}
 	d->ipc = true;
+	if (mirror_wanted(d)) {
+		std::vector<std::vector<int>> remote(d->peers.size());
+		std::vector<float*> pa, pb;
+		std::vector<uint32_t*> fl;
+		for (size_t i = 0; i < d->peers.size(); ++i) {
+			const hns_dist::IpcPeer& q = d->ipc_peers[i];
+			remote[i].resize(q.recv_p_leaves);
+			if (q.recv_p_leaves) HNS_HIP(hipMemcpy(remote[i].data(), q.tables + q.recv_p_leaf_off, sizeof(int) * q.recv_p_leaves, hipMemcpyDeviceToHost));
+			pa.push_back((float*)(q.arena + (size_t)((char*)d->p_a - (char*)d->arena) / d->unit_bytes * q.unit_bytes));
+			pb.push_back((float*)(q.arena + (size_t)((char*)d->p_b - (char*)d->arena) / d->unit_bytes * q.unit_bytes));
+			fl.push_back(q.flags);
+		}
+		HNS_TRY(setup_mirror(d, remote, pa, pb, fl));
+	}
 	return HNS_OK;
 }
 
@@ -825,6 +919,24 @@ int hns_dist_connect_local(hns_dist* const* ranks, int world) {
 	for (int r = 0; r < world; ++r) {
 		ranks[r]->single_stream = true;
 		ranks[r]->local_ranks.assign(ranks, ranks + world);
+	}
+	bool want = world > 1;
+	for (int r = 0; r < world; ++r) want = want && mirror_wanted(ranks[r]);
+	if (want) {
+		for (int r = 0; r < world; ++r) HNS_TRY(ensure_flags(ranks[r]));
+		for (int r = 0; r < world; ++r) {
+			hns_dist* d = ranks[r];
+			std::vector<std::vector<int>> remote(d->peers.size());
+			std::vector<float*> pa, pb;
+			std::vector<uint32_t*> fl;
+			for (size_t i = 0; i < d->peers.size(); ++i) {
+				hns_dist* q = ranks[d->peers[i].rank];
+				for (const Peer& c : q->peers)
+					if (c.rank == d->rank) remote[i] = c.recv[X_P].leaf;
+				pa.push_back(q->p_a), pb.push_back(q->p_b), fl.push_back(q->ipc_flags);
+			}
+			HNS_TRY(setup_mirror(d, remote, pa, pb, fl));
+		}
 	}
 	return HNS_OK;
 }
@@ -1036,7 +1148,7 @@ int post(hns_dist* d, int type, std::vector<std::pair<float*, int>> fields, hipS
 		ip.n = (int)d->peers.size();
 		for (int i = 0; i < ip.n; ++i) {
 			ip.theirs_ready[i] = d->ipc_peers[(size_t)i].flags + d->rank;
-			ip.theirs_landed[i] = d->ipc_peers[(size_t)i].flags + kIpcFlagSlots + d->rank;
+			ip.theirs_landed[i] = d->ipc_peers[(size_t)i].flags + kFlagLanded + d->rank;
 			ip.rank[i] = d->peers[(size_t)i].rank;
 		}
 		hipLaunchKernelGGL(k_ipc_ready, dim3(1), dim3(64), 0, cs, ip, (const uint32_t*)d->ipc_flags, seq, d->ipc_status);
@@ -1197,6 +1309,33 @@ struct Step {
 				it = 0, src = d->p_a, dst = d->p_b;  // never warm-started (reference HNanoSolver.cu:113): the first sweep reads no p
 				if (d->timing && d->tev_used + 2 <= d->tev.size()) HNS_HIP(hipEventRecord(d->tev[d->tev_used], st));
 			}
+			if (d->mirror) {  // the sweep delivers its boundary rows itself (k_rbgs_pair_mirror): no exchange, no second stream
+				RbgsMirror m = d->mir;
+				const int which = dst == d->p_a ? 0 : 1;
+				for (int i = 0; i < m.n_peers; ++i) m.peer_out[i] = d->mir_peer_p[which][i];
+				m.seq = ++d->sweep_seq;
+				if (options().dist_mirror.load() == 2 && m.n_peers) {
+					// "guarded": ONE wave waits for the peers' previous sweep in front of the launch, so that no boundary wave ever
+					// spins. For ranks that share a GPU (tests, bench.py --share-one-gpu): there the boundary waves of several
+					// processes waiting inside their sweeps can occupy every wave slot of the device, and the process they all
+					// wait for is never scheduled (four 16k-leaf plume ranks: every bounded wait ran out). ~5 us per sweep.
+					RbgsMirror w = m;
+					w.seq = m.seq - 1u;
+					hipLaunchKernelGGL(k_sweep_wait, dim3(1), dim3(64), 0, st, w);
+				}
+				if (m.n_boundary_records) {
+					HNS_TRY(hns_rbgs_mirror_sweep(d->gO, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), it == 0, &m, st));
+				} else {  // (a rank nobody mirrors, e.g. one without leaves)
+					HNS_TRY(sweep(d->gO, it == 0, st));
+					if (m.n_peers) hipLaunchKernelGGL(k_sweep_signal, dim3(1), dim3(64), 0, st, m);
+				}
+				for (Peer& p : d->peers) d->bytes_sent[X_P] += sizeof(float) * (size_t)p.send[X_P].voxels;
+				const bool last_sweep = it + 1 == iterations;
+				std::swap(src, dst);
+				++it;
+				if (last_sweep) d->p_result = src;
+				return launch_status("hns_dist: mirror sweep");
+			}
 			const int n = std::min(d->k, iterations - it);
 			for (int j = 0; j < n - 1; ++j, ++it) {
 				HNS_TRY(sweep(d->gA, it == 0, st));
@@ -1211,6 +1350,15 @@ struct Step {
 			return HNS_OK;
 		}
 		if (ph == 3 + blocks) {
+			if (d->mirror && d->mir.n_peers) {  // the gradient reads what the peers' last sweep wrote into the ghost voxels
+				// (here and not behind the last sweep: locally connected ranks share one stream, and a rank's wait must not sit in
+				// front of the sweeps it waits for)
+				RbgsMirror m = d->mir;
+				m.seq = d->sweep_seq;
+#if !(defined(HNS_MIRROR_EXP) && (HNS_MIRROR_EXP & 4))  // (timing experiment builds without the flags: nothing to wait for)
+				hipLaunchKernelGGL(k_sweep_wait, dim3(1), dim3(64), 0, st, m);
+#endif
+			}
 			if (d->timing && d->tev_used + 2 <= d->tev.size()) {  // the timed region ends when the last refresh of p has landed (complete() above)
 				HNS_HIP(hipEventRecord(d->tev[d->tev_used + 1], st));
 				d->tev_used += 2;

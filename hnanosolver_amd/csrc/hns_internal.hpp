@@ -39,6 +39,7 @@ struct Options {
 	std::atomic<int> cook_cache{1};            // "cook_cache": operator calls keep their device buffers with the grid
 	std::atomic<int> cook_pipeline{1};         // "cook_pipeline": hns_compute_sim overlaps transfers with the substep
 	std::atomic<int> dist_wire_us{0};          // "dist_wire_us": loopback transport only, emulated time on the wire per exchange
+	std::atomic<int> dist_mirror{1};           // "dist_mirror": multi-GPU pressure loop with sweeps_per_exchange = 1 over the ipc / local transport delivers its halo inside the sweep kernel
 	std::atomic<int> sor_block{0};             // "sor_block": 0 = auto, N = leaf pairs per workgroup of the blocked SOR kernel
 };
 Options& options();
@@ -153,6 +154,13 @@ struct hns_grid {
 // implemented in hns_pressure.hip: hns_dev_rbgs_iterate with the option of starting from p = 0 without reading (or clearing) p_a
 extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int* result_in_b,
                                 void* stream, bool from_zero);
+
+// implemented in hns_pressure.hip: one sweep of a multi-GPU rank that mirrors its boundary rows into the peers' ghost voxels
+// itself (hns_flags.hpp: RbgsMirror), and the number of wave records of `g` that touch a local leaf below n_boundary
+namespace hns { struct RbgsMirror; }
+extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_mirror_sweep(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero,
+                                                                           const hns::RbgsMirror* m, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_count_boundary_records(hns_grid* g, int n_boundary, unsigned* d_scratch, unsigned* out, void* stream);
 
 // implemented in hns_pointwise.hip: combustion_oxygen split into its divergence update (needs fuel, waste) and the rest
 extern "C" __attribute__((visibility("hidden"))) int hns_combustion_div(const float* fuel, const float* waste, float* divergence, float expansion, uint64_t n,

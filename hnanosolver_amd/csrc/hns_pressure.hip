@@ -19,6 +19,7 @@
 #include <cstring>
 
 #include "hns_device.hpp"
+#include "hns_flags.hpp"
 
 namespace hns {
 
@@ -634,6 +635,99 @@ __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// red-black SOR of one rank of a multi-GPU run, the halo exchange inside the sweep (hns_dist.hip, "mirror" pressure loop)
+// ---------------------------------------------------------------------------------------------------------------
+//
+// The boundary leaves are first in the local leaf order and their waves run first: a boundary wave waits until every peer
+// has completed the boundary part of its previous sweep (flag; raised early in that sweep, so long true by now): the peer's
+// boundary rows of that sweep are then in this rank's ghost voxels, and the peer no longer reads the ghost voxels of the
+// buffer this sweep writes. It then sweeps like any other wave and stores its rows twice: into p_out, and the voxels a peer
+// can read during ITS next sweep (reach 2) into that peer's ghost copy of the leaf, through the peer's memory mapped here.
+// The last boundary wave of the launch raises this rank's "sweep complete" flag on every peer. No second stream, no pack /
+// transfer / unpack kernels, no ghost sweeps; the arithmetic is k_rbgs_pair's.
+// write-through stores at system scope: in the peer's memory when s_waitcnt vmcnt(0) returns
+__device__ __forceinline__ void store_through(float* p, v4f v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_through(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+
+struct StoreMirror {
+	float* __restrict__ p_out;
+	const RbgsMirror* m;
+	__device__ __forceinline__ void operator()(int leaf, int k, int l, const RowP& o) const {
+		(void)k;
+		float4* q = reinterpret_cast<float4*>(p_out + (size_t)leaf * 512 + l * 8);
+		const float4 lo = make_float4(o.q[0].x, o.q[0].y, o.q[1].x, o.q[1].y), hi = make_float4(o.q[2].x, o.q[2].y, o.q[3].x, o.q[3].y);
+		q[0] = lo;
+		q[1] = hi;
+		if (leaf >= m->n_boundary) return;  // (wave-uniform)
+#if defined(HNS_MIRROR_EXP) && (HNS_MIRROR_EXP & 2)  // no mirror stores
+		return;
+#endif
+		const int e1 = m->first[leaf + 1];
+		for (int e = m->first[leaf]; e < e1; ++e) {
+			const int2 t = m->entry[e];
+			const unsigned bits = m->mask[(size_t)e * 64 + l];
+			float* r = m->peer_out[t.x] + (size_t)t.y * 512 + l * 8;
+			if (bits == 0xFFu) {
+				store_through(r, v4f{lo.x, lo.y, lo.z, lo.w});
+				store_through(r + 4, v4f{hi.x, hi.y, hi.z, hi.w});
+			} else if (bits) {
+				const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+				for (int z = 0; z < 8; ++z)
+					if (bits >> z & 1) store_through(r + z, v[z]);
+			}
+		}
+	}
+};
+
+template <bool ZERO>
+__global__ __launch_bounds__(64) void k_rbgs_pair_mirror(const int* __restrict__ pairs, const float* __restrict__ div, const float* __restrict__ p_in,
+                                                         float* __restrict__ p_out, const float dx2, const float omega, const int last, const RbgsMirror m) {
+	__shared__ __attribute__((aligned(16))) PairTile S;
+	const PairLaneCtx c = pair_lane_ctx(threadIdx.x);
+	unsigned rec = blockIdx.x;
+	if (last >= 0) {
+		const unsigned rows = ((unsigned)last + 1u) >> 3;
+		if ((rec >> 3) < rows) rec = ((rows - 1u - (rec >> 3)) << 3) | (rec & 7u);
+	}
+	const int* __restrict__ r = pairs + (size_t)rec * 56;
+	const int leaf0 = __builtin_amdgcn_readfirstlane(r[0]), leaf1 = __builtin_amdgcn_readfirstlane(r[28]);
+	const bool boundary = leaf0 < m.n_boundary || (unsigned)leaf1 < (unsigned)m.n_boundary;  // wave-uniform
+#if defined(HNS_MIRROR_EXP) && (HNS_MIRROR_EXP & 1)  // timing experiments (profiles/micro/exp): no poll
+	if (false) {
+#else
+	if (boundary) {
+#endif
+		if ((int)threadIdx.x < m.n_peers) flag_wait_relaxed(m.my_flags + kFlagSweep + m.peer_rank[threadIdx.x], m.seq - 1u, m.status);
+		asm volatile("" ::: "memory");  // the loads below stay below the poll
+	}
+	const TileNbr nb = {-1, -1, -1, -1, false};
+	const PairIn in = pair_load<ZERO, false>(c, r, div, p_in, nb);
+	pair_compute<false>(&S, S, c, in, nb, StoreMirror{p_out, &m}, dx2, omega);
+#if defined(HNS_MIRROR_EXP) && (HNS_MIRROR_EXP & 4)  // no count, no signal
+	if (false) {
+#else
+	if (boundary) {
+#endif
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through rows are in the peers' memory before it is counted
+		unsigned done = 0;
+		if (threadIdx.x == 0) done = __hip_atomic_fetch_add(m.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+		done = __builtin_amdgcn_readfirstlane(done);
+		if (done == m.n_boundary_records) {  // the last boundary wave of this launch: every other one's rows have landed too
+			if (threadIdx.x == 0) __hip_atomic_store(m.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if ((int)threadIdx.x < m.n_peers) flag_store_relaxed(m.peer_flag[threadIdx.x], m.seq);
+		}
+	}
+}
+
+__global__ void k_count_boundary_records(const int* __restrict__ pairs, unsigned n_records, int n_boundary, unsigned* out) {
+	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_records) return;
+	const int l0 = pairs[(size_t)i * 56], l1 = pairs[(size_t)i * 56 + 28];
+	if (l0 < n_boundary || (unsigned)l1 < (unsigned)n_boundary) atomicAdd(out, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // red-black SOR, blocked form: kTileY x kTileZ wave records per workgroup, shared faces through LDS
 // ---------------------------------------------------------------------------------------------------------------
 //
@@ -1224,6 +1318,33 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 		dst = tmp;
 	}
 	return launch_status("hns_dev_rbgs_iterate");
+}
+
+// ---- the mirroring sweep of a multi-GPU rank (see k_rbgs_pair_mirror) ----
+int hns_rbgs_count_boundary_records(hns_grid* g, int n_boundary, unsigned* d_scratch, unsigned* out, void* stream) {
+	if (int rc = check_grid(g, "hns_rbgs_count_boundary_records")) return rc;
+	if (!g->d_pairs) return fail(HNS_ERR_RUNTIME, "hns_rbgs_count_boundary_records: the grid has no wave records");
+	hipStream_t st = (hipStream_t)stream;
+	HNS_HIP(hipMemsetAsync(d_scratch, 0, sizeof(unsigned), st));
+	if (g->n_pairs) hipLaunchKernelGGL(k_count_boundary_records, dim3((unsigned)((g->n_pairs + 255) / 256)), dim3(256), 0, st, (const int*)g->d_pairs, (unsigned)g->n_pairs, n_boundary, d_scratch);
+	HNS_HIP(hipMemcpyAsync(out, d_scratch, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+	HNS_HIP(hipStreamSynchronize(st));
+	HNS_HIP(hipMemsetAsync(d_scratch, 0, sizeof(unsigned), st));
+	return HNS_OK;
+}
+
+int hns_rbgs_mirror_sweep(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero, const hns::RbgsMirror* m, void* stream) {
+	if (int rc = check_grid(g, "hns_rbgs_mirror_sweep")) return rc;
+	if (!g->d_pairs || g->n_pairs == 0) return fail(HNS_ERR_RUNTIME, "hns_rbgs_mirror_sweep: the grid has no wave records");
+	// Forward order: the boundary leaves come first in the local leaf order, so their waves run at the START of the launch, next
+	// to everything else (walked backwards they were a tail of slow waves on one XCD: 69 us per sweep instead of 38), and a
+	// rank's "sweep complete" flag goes up long before its sweep ends -- the peers' next sweep never waits for it.
+	const int last = -1;
+	if (src_is_zero)
+		hipLaunchKernelGGL(k_rbgs_pair_mirror<true>, dim3((unsigned)g->n_pairs), dim3(64), 0, (hipStream_t)stream, (const int*)g->d_pairs, div, src, dst, dx2_of(dx), omega, last, *m);
+	else
+		hipLaunchKernelGGL(k_rbgs_pair_mirror<false>, dim3((unsigned)g->n_pairs), dim3(64), 0, (hipStream_t)stream, (const int*)g->d_pairs, div, src, dst, dx2_of(dx), omega, last, *m);
+	return launch_status("hns_rbgs_mirror_sweep");
 }
 
 int hns_dev_time_rbgs(hns_grid* g, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int reps, float* ms_per_launch,

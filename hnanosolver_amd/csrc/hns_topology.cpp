@@ -137,6 +137,7 @@ const char* const kWordsAdvect[] = {"auto", "generic", nullptr};
 const char* const kWordsStencil[] = {"auto", "block", nullptr};
 const char* const kWordsSchedule[] = {"auto", "linear", "chunk", nullptr};
 const char* const kWordsBool[] = {"0", "1", nullptr};
+const char* const kWordsMirror[] = {"0", "1", "guarded", nullptr};
 const OptionDesc kOptions[] = {
     {"rbgs", &Options::rbgs, kWordsRbgs},
     {"advect", &Options::advect_generic, kWordsAdvect},
@@ -150,6 +151,7 @@ const OptionDesc kOptions[] = {
     {"sor_block", &Options::sor_block, nullptr},
     {"schedule_segment", &Options::schedule_segment, nullptr},
     {"dist_wire_us", &Options::dist_wire_us, nullptr},
+    {"dist_mirror", &Options::dist_mirror, kWordsMirror},
 };
 const Options kDefaults;
 }  // namespace

@@ -135,6 +135,42 @@ class DistRank:
         blobs = b"".join(bytes(o.cpu().numpy().tobytes()) for o in out)
         _raise(lib.hns_dist_connect_ipc(self._ptr, C.create_string_buffer(blobs, n * self.world)))
 
+    def try_connect_ipc(self, group=None):
+        """connect_ipc for callers that can fall back to another transport: every step that can fail on one rank alone is
+        followed by an agreement among all ranks, so that either every rank ends up connected or none (-> (False, reason))."""
+        import torch
+        import torch.distributed as dist
+
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+
+        def agreed(ok: bool) -> bool:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return bool(int(t.item()))
+
+        n = _lib.HNS_DIST_IPC_BLOB_BYTES
+        mine = (C.c_ubyte * n)()
+        reason = ""
+        try:
+            _raise(lib.hns_dist_ipc_export(self._ptr, mine))
+            ok = True
+        except Exception as e:  # noqa: BLE001
+            ok, reason = False, f"export: {e}"
+        if not agreed(ok):
+            return False, reason or "a peer could not export its memory"
+        t = torch.frombuffer(bytearray(bytes(mine)), dtype=torch.uint8).to(dev)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=group)
+        blobs = b"".join(bytes(o.cpu().numpy().tobytes()) for o in out)
+        try:
+            _raise(lib.hns_dist_connect_ipc(self._ptr, C.create_string_buffer(blobs, n * self.world)))
+            ok = True
+        except Exception as e:  # noqa: BLE001
+            ok, reason = False, f"connect: {e}"
+        if not agreed(ok):
+            return False, reason or "a peer could not map this rank's memory"
+        return True, ""
+
     @staticmethod
     def connect_local(ranks: Sequence["DistRank"]) -> None:
         arr = (C.c_void_p * len(ranks))(*[r._ptr for r in ranks])
@@ -216,7 +252,7 @@ class SlabBench:
     ONE domain (e.g. BASELINE.json configs[4], the 1024^3-extent plume) split into `world` contiguous leaf ranges."""
 
     def __init__(self, slab_origins: np.ndarray, R: int, rank: int, world: int, iterations: int, dt: float, partition: bool = False,
-                 sweeps_per_exchange: int = 0, connect: bool = True, transport: str = "rccl"):
+                 sweeps_per_exchange: int = 0, connect: bool = True, transport: str = "rccl", reference_transport: str = "rccl"):
         import torch
 
         from . import fields
@@ -225,16 +261,69 @@ class SlabBench:
         slab_origins = np.ascontiguousarray(slab_origins, dtype=np.int32)
         glob = slab_origins if partition else slab_domain(slab_origins, R, world)
         self.iterations, self.dt, self.vs = iterations, dt, 1.0 / R  # same voxel size (and omega) as the single-GPU workload
-        self.rank_obj = DistRank(glob, world, rank, self.vs, n_scalars=1, sweeps_per_exchange=sweeps_per_exchange)
-        if world > 1 and connect:
-            self.rank_obj.connect_ipc() if transport == "ipc" else self.rank_obj.connect_rccl()
-        d = self.rank_obj
-        own = glob[d.first_owned:d.first_owned + d.n_owned].copy()
+        self.stream = int(torch.cuda.current_stream().cuda_stream)
+        self.transport_note = "no peers" if world == 1 else transport
+        first, count = int(partition_bounds(len(glob), world)[rank]), int(np.diff(partition_bounds(len(glob), world))[rank])
+        own = glob[first:first + count].copy()
         if not partition:
             own[:, 0] %= R
         f = fields.synthetic_fields(own, R)
-        d.upload(f["vel"], [f["density"]])
-        self.stream = int(torch.cuda.current_stream().cuda_stream)
+        self._fields = (f["vel"], [f["density"]])
+
+        def make(k):
+            return DistRank(glob, world, rank, self.vs, n_scalars=1, sweeps_per_exchange=k)
+
+        if world > 1 and connect and transport == "auto":
+            self.rank_obj = self._verified_one_sided(make, sweeps_per_exchange, reference_transport)
+        else:
+            # the one-sided transport runs the pressure loop whose sweep kernel delivers its own halo (sweeps_per_exchange = 1)
+            self.rank_obj = make(sweeps_per_exchange or (1 if transport == "ipc" else 0))
+            if world > 1 and connect:
+                self.rank_obj.connect_ipc() if transport == "ipc" else self.rank_obj.connect_rccl()
+        self.rank_obj.upload(*self._fields)
+
+    def _verified_one_sided(self, make, sweeps_per_exchange, reference_transport):
+        """transport = auto: the one-sided transport with the mirroring pressure loop if -- on THIS machine, now -- it connects
+        and two substeps of it leave bit for bit what two substeps over the reference transport (RCCL) leave on every rank;
+        RCCL otherwise. Every decision is taken by all ranks together."""
+        import torch
+        import torch.distributed as dist
+
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+        def agreed(ok: bool) -> bool:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+
+        def two_substeps(d):
+            d.upload(*self._fields)
+            for _ in range(2):
+                d.core_substep(min(self.iterations, 12), self.dt, self.stream)
+            d.synchronize(self.stream)
+            return d.download(pressure=True)
+
+        ref = make(sweeps_per_exchange)
+        ref.connect_rccl() if reference_transport == "rccl" else ref.connect_ipc()
+        want = two_substeps(ref)
+        cand = make(1)
+        ok, why = cand.try_connect_ipc()
+        if ok:
+            try:
+                got = two_substeps(cand)
+                same = all(np.array_equal(got[k], want[k]) for k in ("vel", "pressure")) and np.array_equal(got["scalars"][0], want["scalars"][0])
+                ok, why = same, "" if same else "results differ from the reference transport's"
+            except Exception as e:  # noqa: BLE001
+                ok, why = False, f"substep: {e}"
+            ok = agreed(ok)
+        dist.barrier()  # nobody unmaps or frees while a peer may still be writing
+        if ok:
+            ref.close()
+            self.transport_note = f"one-sided puts into mapped peer memory, SOR sweep delivers its own halo; verified bit for bit against {reference_transport} at start-up"
+            return cand
+        cand.close()
+        self.transport_note = f"{reference_transport} (one-sided transport not used: {why or 'a peer rank failed its check'})"
+        return ref
 
     @property
     def n_owned(self) -> int:

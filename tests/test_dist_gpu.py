@@ -60,8 +60,23 @@ def scattered_leaves():
     return np.ascontiguousarray(o[fields.nanovdb_order(o)])
 
 
-@pytest.mark.parametrize("name,world,k", [("dense32", 2, 4), ("plume", 3, 2), ("scattered", 5, 1), ("plume", 8, 3), ("dense32", 4, 0)])
+@pytest.mark.parametrize("name,world,k", [("dense32", 2, 4), ("plume", 3, 2), ("scattered", 5, 1), ("plume", 8, 3), ("dense32", 4, 0), ("dense32", 2, 1),
+                                          ("plume", 8, 1), ("scattered", 3, -1)])
 def test_local_ranks_match_single_grid(name, world, k):
+    """k = 1: the pressure loop whose sweep kernel writes its boundary rows into the peers' ghost voxels itself
+    (k_rbgs_pair_mirror); k = -1: the same plan with that switched off (option dist_mirror = 0: exchanged every sweep)."""
+    import hnanosolver_amd as H
+
+    if k == -1:
+        H.set_option("dist_mirror", "0")
+        try:
+            return _local_ranks_match_single_grid(name, world, 1)
+        finally:
+            H.set_option("dist_mirror", "1")
+    return _local_ranks_match_single_grid(name, world, k)
+
+
+def _local_ranks_match_single_grid(name, world, k):
     origins, R = {"dense32": (fields.dense_leaves(32), 32), "plume": (fields.plume_leaves(8, 1.5, 0.35), 64), "scattered": (scattered_leaves(), 96)}[name]
     names, iters, substeps = ["density", "temperature"], 7, 2
     _, want = single_grid(origins, R, names, iters, substeps)
@@ -215,7 +230,8 @@ def _run_processes(world, case, k, iters, substeps, tmp_path, timeout=420):
     return [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
 
 
-@pytest.mark.parametrize("case,world,k,iters", [("dense32", 2, 4, 7), ("plume", 3, 2, 7), ("plume12", 4, 3, 9), ("dense64", 2, 0, 50)])
+@pytest.mark.parametrize("case,world,k,iters", [("dense32", 2, 4, 7), ("plume", 3, 2, 7), ("plume12", 4, 3, 9), ("dense64", 2, 0, 50), ("dense64", 2, 1, 50),
+                                                ("plume12", 4, 1, 9), ("plume", 3, 1, 7)])
 def test_one_process_per_rank_over_mapped_peer_memory(case, world, k, iters, tmp_path):
     """The multi-process path for real: `world` PROCESSES (here sharing the one GPU), each a rank with its own streams, the
     halos put into the peer's memory through hipIpc mappings and the ranks meeting through device-side flags while their
