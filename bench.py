@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--sweeps-per-exchange", type=int, default=0, help="N > 1: fused SOR sweeps between two halo refreshes of p (1..4, 0 = library default)")
     ap.add_argument("--transport", choices=["auto", "rccl", "ipc"], default="auto",
                     help="N > 1 halo transport: rccl = RCCL send/recv groups; ipc = one-sided puts into hipIpc-mapped peer memory with the SOR sweep "
-                         "delivering its own halo; auto (default) = ipc if it connects and reproduces two RCCL substeps bit for bit on this machine, else rccl")
+                         "delivering its own halo; auto (default) = ipc if it connects and reproduces three RCCL substeps bit for bit on this machine, else rccl")
     ap.add_argument("--share-one-gpu", action="store_true",
                     help="builder's check on a 1-GPU box: all N ranks on cuda:0, host rendezvous over gloo, --transport ipc (RCCL refuses two ranks on one device)")
     ap.add_argument("--cook", action="store_true", help="time the cook-equivalent hns_compute_sim call (upload + grid build + substep + download) instead")

@@ -284,7 +284,7 @@ class SlabBench:
 
     def _verified_one_sided(self, make, sweeps_per_exchange, reference_transport):
         """transport = auto: the one-sided transport with the mirroring pressure loop if -- on THIS machine, now -- it connects
-        and two substeps of it leave bit for bit what two substeps over the reference transport (RCCL) leave on every rank;
+        and three substeps of it leave bit for bit what three substeps over the reference transport (RCCL) leave on every rank;
         RCCL otherwise. Every decision is taken by all ranks together."""
         import torch
         import torch.distributed as dist
@@ -296,10 +296,10 @@ class SlabBench:
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return bool(int(t.item()))
 
-        def two_substeps(d):
+        def two_substeps(d):  # (three, at the full iteration count: ~150 sweeps over every boundary leaf)
             d.upload(*self._fields)
-            for _ in range(2):
-                d.core_substep(min(self.iterations, 12), self.dt, self.stream)
+            for _ in range(3):
+                d.core_substep(self.iterations, self.dt, self.stream)
             d.synchronize(self.stream)
             return d.download(pressure=True)
 
