@@ -88,21 +88,26 @@ def _local_ranks_match_single_grid(name, world, k):
     assert all(sum(i["bytes_sent"].values()) > 0 for i in info if i["peers"])
 
 
-def test_plume1024_in_8_ranges_matches_single_grid():
+@pytest.mark.parametrize("k", [0, 1])
+def test_plume1024_in_8_ranges_matches_single_grid(k):
     """BASELINE.json configs[4]: the 1024^3-extent sparse plume (65,944 leaves) as the 8-GPU decomposition -- 8 contiguous
     leaf ranges, each with its ghost layer, boundary-first launch ranges and voxel-granular halo messages -- emulated on one
-    device, 50 iterations, against the single-grid run of the same substep."""
+    device, 50 iterations, against the single-grid run of the same substep. k = 0: the exchanged pressure loop (refresh every
+    4th sweep); k = 1: the loop whose sweep kernel writes its boundary rows into the peers' ghost voxels itself."""
     origins, R = fields.config_leaves("plume1024")
     names, iters = ["density"], 50
     _, want = single_grid(origins, R, names, iters, 1)
-    ranks, b = run_local(origins, R, 8, 0, names, iters, 1)
+    ranks, b = run_local(origins, R, 8, k, names, iters, 1)
     check(ranks, b, want, names)
     info = [d.info() for d in ranks]
     assert max(i["peers"] for i in info) <= 7 and min(i["boundary_leaves"] for i in info) > 0
-    # payload accounting: the pressure loop dominates; with k = 4 that is 12 refreshes of depth 8 plus the final depth-1 one
     for i in info:
-        assert i["exchanges"] == 1 + 1 + 1 + 13 + 1 + 1
-        assert i["bytes_sent"]["p"] == 12 * 4 * i["region_voxels_sent"]["p"]
+        if k == 0:  # payload accounting: the pressure loop dominates; with k = 4 that is 12 refreshes of depth 8 plus the final depth-1 one
+            assert i["exchanges"] == 1 + 1 + 1 + 13 + 1 + 1
+            assert i["bytes_sent"]["p"] == 12 * 4 * i["region_voxels_sent"]["p"]
+        else:  # no exchange in the pressure loop: 50 sweeps each mirror the reach-2 region
+            assert i["exchanges"] == 1 + 1 + 1 + 1 + 1  # advection inputs, u*, div, u, phi
+            assert i["bytes_sent"]["p"] == 50 * 4 * i["region_voxels_sent"]["p"]
 
 
 def test_new_fields_between_substeps_and_many_substeps():
