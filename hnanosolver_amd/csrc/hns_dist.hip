@@ -647,6 +647,9 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 	for (int i = 0; i < 4; ++i) {
 		*gs[i] = hns_grid_create_from_leaves(lo.data(), (uint64_t)n_local, voxel_size, HNS_GRID_DEFAULT, &rc);
 		if (!*gs[i]) return bail(rc);
+		// the owned range deals the boundary leaves out to all eight XCDs first (the mirroring pressure loop sweeps this range: its
+		// boundary waves poll, store twice and signal, and as the head of XCD 0's chunk they made that XCD the last to finish)
+		if (i == 2 && sweeps_per_exchange == 1 && options().dist_spread.load() != 0) (*gs[i])->sched_prefix = (uint64_t)d->nB;
 		if ((rc = hns_grid_set_active_range(*gs[i], first[i], count[i])) != HNS_OK) return bail(rc);
 		if ((rc = hns_grid_set_outside_element(*gs[i], outside)) != HNS_OK) return bail(rc);
 	}

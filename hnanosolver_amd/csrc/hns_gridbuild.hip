@@ -88,13 +88,22 @@ __host__ __device__ inline int sched_leaf(int b, int n, int seg) {
 	return body + x * base + (x < rem ? x : rem) + i;
 }
 
+// `pre` (a multiple of 8, 0 = none): the first `pre` leaves are dealt out first, an equal contiguous piece to every XCD, the rest
+// as above behind them -- a multi-GPU rank's boundary leaves (first in its leaf order) then run on all eight XCDs instead of
+// filling the head of XCD 0's chunk (hns_dist.hip: their waves poll and signal, and are slower than the others).
+__host__ __device__ inline int sched_leaf(int b, int n, int seg, int pre) {
+	if (pre <= 0) return sched_leaf(b, n, seg);
+	if (b < pre) return (b & 7) * (pre >> 3) + (b >> 3);
+	return pre + sched_leaf(b - pre, n - pre, seg);
+}
+
 // {leaf, nbr27[27]} per block in launch order: the kernels that work one leaf per workgroup read their whole
 // topology with one fetch.
-__global__ __launch_bounds__(256) void k_build_blk(const int* __restrict__ nbr27, int first, int n_active, int seg, int* __restrict__ sched, int* __restrict__ blk) {
+__global__ __launch_bounds__(256) void k_build_blk(const int* __restrict__ nbr27, int first, int n_active, int seg, int pre, int* __restrict__ sched, int* __restrict__ blk) {
 	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	if (t >= (int64_t)n_active * 28) return;
 	const int b = (int)(t / 28), j = (int)(t % 28);
-	const int l = first + sched_leaf(b, n_active, seg);
+	const int l = first + sched_leaf(b, n_active, seg, pre);
 	if (j == 0) {
 		blk[t] = l;
 		if (sched) sched[b] = l;
@@ -121,7 +130,7 @@ __device__ __forceinline__ int pair_partner(const int* __restrict__ nbr27, int f
 }
 
 // pass 1: partner[b] for schedule position b, and the number of wave heads / lone leaves per 256-position block
-__global__ __launch_bounds__(256) void k_pair_heads(const int* __restrict__ nbr27, int first, int n_active, int seg, int* __restrict__ partner, int* __restrict__ block_heads,
+__global__ __launch_bounds__(256) void k_pair_heads(const int* __restrict__ nbr27, int first, int n_active, int seg, int pre, int* __restrict__ partner, int* __restrict__ block_heads,
                                                     int* __restrict__ totals) {
 	__shared__ int s_cnt[2];
 	if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(256) void k_pair_heads(const int* __restrict__ nbr2
 	const int b = blockIdx.x * 256 + threadIdx.x;
 	int p = -2;
 	if (b < n_active) {
-		p = pair_partner(nbr27, first, n_active, first + sched_leaf(b, n_active, seg));
+		p = pair_partner(nbr27, first, n_active, first + sched_leaf(b, n_active, seg, pre));
 		partner[b] = p;
 	}
 	const unsigned long long heads = __ballot(p != -2), lone = __ballot(p == -1);
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(int* __restrict__ block_he
 }
 
 // pass 3: wave records {leaf0, nbr27, leaf1 or -1, nbr27} (56 ints) in schedule order of their head leaf
-__global__ __launch_bounds__(256) void k_write_pairs(const int* __restrict__ nbr27, int first, int n_active, int seg, const int* __restrict__ partner,
+__global__ __launch_bounds__(256) void k_write_pairs(const int* __restrict__ nbr27, int first, int n_active, int seg, int pre, const int* __restrict__ partner,
                                                      const int* __restrict__ block_base, int* __restrict__ recs) {
 	__shared__ int s_wave[4];
 	const int b = blockIdx.x * 256 + threadIdx.x;
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(256) void k_write_pairs(const int* __restrict__ nbr
 	int pos = block_base[blockIdx.x] + __popcll(heads & ((1ull << lane) - 1ull));
 	for (int i = 0; i < w; ++i) pos += s_wave[i];
 	if (p == -2) return;
-	const int l = first + sched_leaf(b, n_active, seg);
+	const int l = first + sched_leaf(b, n_active, seg, pre);
 	int* r = recs + (size_t)pos * 56;
 	r[0] = l;
 	r[28] = p;
@@ -296,7 +305,8 @@ int hns_grid_upload_schedule(hns_grid* g) {
 	// option "schedule_segment" = N leaves per XCD segment (0: by size)
 	const int seg = sched_opt == kScheduleLinear ? 1 : (sched_opt == kScheduleChunk ? 0 : (seg_opt > 0 ? seg_opt : (n > 40000 ? 128 : 0)));
 	const int linear = seg;  // (name kept below: the kernels take the segment length)
-	g->d_sched = seg == 1 ? nullptr : g->d_sched_mem;
+	const int pre = (int)std::min<uint64_t>(g->sched_prefix, (uint64_t)n) & ~7;
+	g->d_sched = (seg == 1 && pre == 0) ? nullptr : g->d_sched_mem;
 	const int* nbr27 = (const int*)g->d_nbr27;
 	const int n_blocks = (n + 255) / 256;
 	int* partner = (int*)g->d_scratch;  // partner[n] | block_heads[n_blocks] | totals[2]
@@ -304,13 +314,13 @@ int hns_grid_upload_schedule(hns_grid* g) {
 	int* totals = block_heads + n_blocks;
 	int h_totals[2] = {0, 0};
 	HNS_HIP(hipMemsetAsync(totals, 0, 2 * sizeof(int), 0));
-	k_build_blk<<<(unsigned)(((int64_t)n * 28 + 255) / 256), 256, 0, 0>>>(nbr27, first, n, linear, (int*)g->d_sched, (int*)g->d_blk);
-	k_pair_heads<<<n_blocks, 256, 0, 0>>>(nbr27, first, n, linear, partner, block_heads, totals);
+	k_build_blk<<<(unsigned)(((int64_t)n * 28 + 255) / 256), 256, 0, 0>>>(nbr27, first, n, linear, pre, (int*)g->d_sched, (int*)g->d_blk);
+	k_pair_heads<<<n_blocks, 256, 0, 0>>>(nbr27, first, n, linear, pre, partner, block_heads, totals);
 	k_scan_blocks<<<1, 1024, 0, 0>>>(block_heads, n_blocks);
 	HNS_HIP(hipMemcpy(h_totals, totals, sizeof(h_totals), hipMemcpyDeviceToHost));  // also the sync point for the launches above
 	g->n_pairs = (uint64_t)h_totals[0];
 	g->n_singles = (uint64_t)h_totals[1];
-	k_write_pairs<<<n_blocks, 256, 0, 0>>>(nbr27, first, n, linear, partner, block_heads, (int*)g->d_pairs);
+	k_write_pairs<<<n_blocks, 256, 0, 0>>>(nbr27, first, n, linear, pre, partner, block_heads, (int*)g->d_pairs);
 	HNS_HIP(hipDeviceSynchronize());
 	g->tiles_built = false;  // built when a solve first asks for the blocked or resident form (most grids never do)
 	g->n_tile_groups = g->n_tile_rest = 0;

@@ -40,6 +40,7 @@ struct Options {
 	std::atomic<int> cook_pipeline{1};         // "cook_pipeline": hns_compute_sim overlaps transfers with the substep
 	std::atomic<int> dist_wire_us{0};          // "dist_wire_us": loopback transport only, emulated time on the wire per exchange
 	std::atomic<int> dist_mirror{1};           // "dist_mirror": multi-GPU pressure loop with sweeps_per_exchange = 1 over the ipc / local transport delivers its halo inside the sweep kernel
+	std::atomic<int> dist_spread{1};           // "dist_spread": the owned launch range of a sweeps_per_exchange = 1 rank deals its boundary leaves out to all XCDs (read at hns_dist_create)
 	std::atomic<int> sor_block{0};             // "sor_block": 0 = auto, N = leaf pairs per workgroup of the blocked SOR kernel
 };
 Options& options();
@@ -125,6 +126,7 @@ struct hns_grid {
 	void* d_sched = nullptr;
 	void* d_blk = nullptr;
 	void* d_pairs = nullptr;    // launch-ordered wave records {leaf0, nbr27, leaf1 or -1, nbr27} (56 ints): z-adjacent pairs and lone leaves
+	uint64_t sched_prefix = 0;    // leaves at the head of the active range that the launch order deals out to all XCDs first (hns_dist: boundary leaves)
 	void* d_sched_mem = nullptr;  // storage of d_sched (d_sched itself is null under the linear schedule)
 	void* d_scratch = nullptr;    // schedule-build scratch
 	void* d_arena = nullptr;      // the one device allocation all of the above are slices of (arena pool, hns_api.hip)

@@ -152,6 +152,7 @@ const OptionDesc kOptions[] = {
     {"schedule_segment", &Options::schedule_segment, nullptr},
     {"dist_wire_us", &Options::dist_wire_us, nullptr},
     {"dist_mirror", &Options::dist_mirror, kWordsMirror},
+    {"dist_spread", &Options::dist_spread, kWordsBool},
 };
 const Options kDefaults;
 }  // namespace
