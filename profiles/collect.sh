@@ -14,8 +14,10 @@ python3 bench.py > $out/bench_256.json 2> $out/bench_256.err
 for c in 128 64 plume plume1024; do python3 bench.py --config $c --no-cpu-baseline > $out/bench_$c.json 2>> $out/bench_other.err; done
 python3 bench.py --config 512 --steps 5 --no-cpu-baseline > $out/bench_512.json 2>> $out/bench_other.err
 # one rank of a multi-GPU run before any wire time (local / loopback transports of hns_dist), and against emulated wire time
-for a in "256 2 4" "256 2 2" "128 2 4" "plume1024 8 4 --partition"; do python3 profiles/micro/dist_overhead.py $a >> $out/dist_overhead.jsonl 2>> $out/bench_other.err; done
-for w in 0 10 20 40; do python3 profiles/micro/dist_profile.py rank 4 $w 2>> $out/bench_other.err | tail -1 >> $out/dist_wire_sweep.txt; done
+for a in "256 2 4" "256 2 2" "256 2 1" "128 2 4" "128 2 1" "plume1024 8 4 --partition" "plume1024 8 1 --partition"; do python3 profiles/micro/dist_overhead.py $a >> $out/dist_overhead.jsonl 2>> $out/bench_other.err; done
+for w in 0 10 20 40; do python3 profiles/micro/dist_profile.py rank 4 $w 2>> $out/bench_other.err | grep "ms per substep" >> $out/dist_wire_sweep.txt; done
+for k in 1 2 4; do python3 profiles/micro/dist_profile.py rank $k 0 rccl 2>> $out/bench_other.err | grep "ms per substep" >> $out/dist_rccl_loopback.txt; done
+python3 profiles/micro/dist_profile.py rank 1 0 2>> $out/bench_other.err | grep "ms per substep" >> $out/dist_wire_sweep.txt
 python3 profiles/micro/sor_sizes.py > $out/sor_sizes.txt 2>> $out/bench_other.err
 # memory-side PMC of the SOR sweep outside the Infinity Cache (blocked kernel at 512^3, pair kernel on the 66k-leaf plume)
 for c in 512 plume1024; do bash profiles/micro/pmc_sor.sh ${tag}_$c $c > $out/pmc_sor_$c.txt 2>&1; cp $root/gpurun_out/pmc_sor_${tag}_$c/pmc.json $out/pmc_sor_$c.json; done
