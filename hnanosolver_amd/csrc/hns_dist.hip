@@ -566,14 +566,17 @@ int setup_mirror(hns_dist* d, const std::vector<std::vector<int>>& remote_leaf, 
 	memset(&m, 0, sizeof(m));
 	m.n_boundary = nB, m.n_peers = (int)d->peers.size();
 	m.first = (const int*)q, m.entry = (const int2*)(q + b0), m.mask = (const unsigned char*)(q + b0 + b1);
-	m.count = (unsigned*)(q + b0 + b1 + b2);
+	m.count = (unsigned*)(q + b0 + b1 + b2);  // (two words: hns_rbgs_count_boundary_records uses both, the sweeps the first)
 	for (size_t i = 0; i < d->peers.size(); ++i) {
 		m.peer_flag[i] = peer_flags[i] + kFlagSweep + d->rank;
 		m.peer_rank[i] = d->peers[i].rank;
 		d->mir_peer_p[0][i] = peer_pa[i], d->mir_peer_p[1][i] = peer_pb[i];
 	}
 	m.my_flags = d->ipc_flags, m.status = d->ipc_status;
-	HNS_TRY(hns_rbgs_count_boundary_records(d->gO, nB, m.count, &m.n_boundary_records, nullptr));
+	unsigned counted[2] = {0, 0};
+	HNS_TRY(hns_rbgs_count_boundary_records(d->gO, nB, m.count, counted, nullptr));
+	m.n_boundary_records = counted[0];
+	m.head_records = std::min<unsigned>((counted[1] + 7u) & ~7u, (unsigned)d->gO->n_pairs & ~7u);
 	d->mirror = true;
 	return HNS_OK;
 }
@@ -1327,7 +1330,8 @@ struct Step {
 					hipLaunchKernelGGL(k_sweep_wait, dim3(1), dim3(64), 0, st, w);
 				}
 				if (m.n_boundary_records) {
-					HNS_TRY(hns_rbgs_mirror_sweep(d->gO, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), it == 0, &m, st));
+					HNS_TRY(hns_rbgs_mirror_sweep(d->gO, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), it == 0, &m, st,
+					                              options().alternate.load() != 0 && (it & 1)));
 				} else {  // (a rank nobody mirrors, e.g. one without leaves)
 					HNS_TRY(sweep(d->gO, it == 0, st));
 					if (m.n_peers) hipLaunchKernelGGL(k_sweep_signal, dim3(1), dim3(64), 0, st, m);

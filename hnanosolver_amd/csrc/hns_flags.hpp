@@ -66,6 +66,7 @@ struct RbgsMirror {
 	uint32_t seq;               // number of this sweep (all ranks count alike); boundary waves wait for the peers' seq - 1
 	unsigned* count;            // device counter: boundary records done in this launch
 	unsigned n_boundary_records;
+	unsigned head_records;      // a multiple of 8: the records before it (the boundary leaves' among them) keep their place when a sweep walks backwards
 	int* status;
 };
 

@@ -161,8 +161,8 @@ extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_iterate(hns_grid* 
 // itself (hns_flags.hpp: RbgsMirror), and the number of wave records of `g` that touch a local leaf below n_boundary
 namespace hns { struct RbgsMirror; }
 extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_mirror_sweep(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero,
-                                                                           const hns::RbgsMirror* m, void* stream);
-extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_count_boundary_records(hns_grid* g, int n_boundary, unsigned* d_scratch, unsigned* out, void* stream);
+                                                                           const hns::RbgsMirror* m, void* stream, bool backwards);
+extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_count_boundary_records(hns_grid* g, int n_boundary, unsigned* d_scratch, unsigned* out2, void* stream);
 
 // implemented in hns_pointwise.hip: combustion_oxygen split into its divergence update (needs fuel, waste) and the rest
 extern "C" __attribute__((visibility("hidden"))) int hns_combustion_div(const float* fuel, const float* waste, float* divergence, float expansion, uint64_t n,

@@ -686,9 +686,11 @@ __global__ __launch_bounds__(64) void k_rbgs_pair_mirror(const int* __restrict__
 	__shared__ __attribute__((aligned(16))) PairTile S;
 	const PairLaneCtx c = pair_lane_ctx(threadIdx.x);
 	unsigned rec = blockIdx.x;
-	if (last >= 0) {
-		const unsigned rows = ((unsigned)last + 1u) >> 3;
-		if ((rec >> 3) < rows) rec = ((rows - 1u - (rec >> 3)) << 3) | (rec & 7u);
+	if (last >= 0 && rec >= m.head_records) {  // odd sweeps walk the records behind the boundary part backwards (see hns_rbgs_iterate: "alternate")
+		const unsigned rows = ((unsigned)last + 1u - m.head_records) >> 3;
+		unsigned t = rec - m.head_records;
+		if ((t >> 3) < rows) t = ((rows - 1u - (t >> 3)) << 3) | (t & 7u);
+		rec = m.head_records + t;
 	}
 	const int* __restrict__ r = pairs + (size_t)rec * 56;
 	const int leaf0 = __builtin_amdgcn_readfirstlane(r[0]), leaf1 = __builtin_amdgcn_readfirstlane(r[28]);
@@ -720,11 +722,15 @@ __global__ __launch_bounds__(64) void k_rbgs_pair_mirror(const int* __restrict__
 	}
 }
 
+// out[0] = number of records that touch a boundary leaf, out[1] = 1 + index of the last of them
 __global__ void k_count_boundary_records(const int* __restrict__ pairs, unsigned n_records, int n_boundary, unsigned* out) {
 	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_records) return;
 	const int l0 = pairs[(size_t)i * 56], l1 = pairs[(size_t)i * 56 + 28];
-	if (l0 < n_boundary || (unsigned)l1 < (unsigned)n_boundary) atomicAdd(out, 1u);
+	if (l0 < n_boundary || (unsigned)l1 < (unsigned)n_boundary) {
+		atomicAdd(out, 1u);
+		atomicMax(out + 1, i + 1u);
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1321,25 +1327,26 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 }
 
 // ---- the mirroring sweep of a multi-GPU rank (see k_rbgs_pair_mirror) ----
-int hns_rbgs_count_boundary_records(hns_grid* g, int n_boundary, unsigned* d_scratch, unsigned* out, void* stream) {
+int hns_rbgs_count_boundary_records(hns_grid* g, int n_boundary, unsigned* d_scratch, unsigned* out2, void* stream) {
 	if (int rc = check_grid(g, "hns_rbgs_count_boundary_records")) return rc;
 	if (!g->d_pairs) return fail(HNS_ERR_RUNTIME, "hns_rbgs_count_boundary_records: the grid has no wave records");
 	hipStream_t st = (hipStream_t)stream;
-	HNS_HIP(hipMemsetAsync(d_scratch, 0, sizeof(unsigned), st));
+	HNS_HIP(hipMemsetAsync(d_scratch, 0, 2 * sizeof(unsigned), st));
 	if (g->n_pairs) hipLaunchKernelGGL(k_count_boundary_records, dim3((unsigned)((g->n_pairs + 255) / 256)), dim3(256), 0, st, (const int*)g->d_pairs, (unsigned)g->n_pairs, n_boundary, d_scratch);
-	HNS_HIP(hipMemcpyAsync(out, d_scratch, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+	HNS_HIP(hipMemcpyAsync(out2, d_scratch, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
 	HNS_HIP(hipStreamSynchronize(st));
-	HNS_HIP(hipMemsetAsync(d_scratch, 0, sizeof(unsigned), st));
+	HNS_HIP(hipMemsetAsync(d_scratch, 0, 2 * sizeof(unsigned), st));
 	return HNS_OK;
 }
 
-int hns_rbgs_mirror_sweep(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero, const hns::RbgsMirror* m, void* stream) {
+int hns_rbgs_mirror_sweep(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero, const hns::RbgsMirror* m, void* stream, bool backwards) {
 	if (int rc = check_grid(g, "hns_rbgs_mirror_sweep")) return rc;
 	if (!g->d_pairs || g->n_pairs == 0) return fail(HNS_ERR_RUNTIME, "hns_rbgs_mirror_sweep: the grid has no wave records");
-	// Forward order: the boundary leaves come first in the local leaf order, so their waves run at the START of the launch, next
-	// to everything else (walked backwards they were a tail of slow waves on one XCD: 69 us per sweep instead of 38), and a
-	// rank's "sweep complete" flag goes up long before its sweep ends -- the peers' next sweep never waits for it.
-	const int last = -1;
+	// The boundary leaves come first in the local leaf order and their waves always run at the START of the launch, next to
+	// everything else (walked backwards they were a tail of slow waves: 69 us per sweep instead of 38), so a rank's "sweep
+	// complete" flag goes up long before its sweep ends and the peers' next sweep never waits for it. `backwards` reverses
+	// only the records behind them (what "alternate" does for the single-GPU loop: the sweep starts where the last one ended).
+	const int last = backwards ? (int)g->n_pairs - 1 : -1;
 	if (src_is_zero)
 		hipLaunchKernelGGL(k_rbgs_pair_mirror<true>, dim3((unsigned)g->n_pairs), dim3(64), 0, (hipStream_t)stream, (const int*)g->d_pairs, div, src, dst, dx2_of(dx), omega, last, *m);
 	else
