@@ -61,7 +61,7 @@ def scattered_leaves():
 
 
 @pytest.mark.parametrize("name,world,k", [("dense32", 2, 4), ("plume", 3, 2), ("scattered", 5, 1), ("plume", 8, 3), ("dense32", 4, 0), ("dense32", 2, 1),
-                                          ("plume", 8, 1), ("scattered", 3, -1)])
+                                          ("plume", 8, 1), ("scattered", 3, -1), ("dense32", 4, 1)])
 def test_local_ranks_match_single_grid(name, world, k):
     """k = 1: the pressure loop whose sweep kernel writes its boundary rows into the peers' ghost voxels itself
     (k_rbgs_pair_mirror); k = -1: the same plan with that switched off (option dist_mirror = 0: exchanged every sweep)."""
