@@ -242,8 +242,11 @@ __global__ void k_ipc_landed(const IpcPeers peers, const uint32_t* __restrict__ 
 __global__ void k_sweep_signal(const RbgsMirror m) {
 	if ((int)threadIdx.x < m.n_peers) flag_store(m.peer_flag[threadIdx.x], m.seq);
 }
-__global__ void k_sweep_wait(const RbgsMirror m) {
-	if ((int)threadIdx.x < m.n_peers) flag_wait(m.my_flags + kFlagSweep + m.peer_rank[threadIdx.x], m.seq, m.status);
+__global__ void k_sweep_wait(const RbgsMirror m) {  // (raises this rank's flag for m.seq first: its sweeps up to m.seq have ended)
+	if ((int)threadIdx.x < m.n_peers) {
+		flag_store(m.peer_flag[threadIdx.x], m.seq);
+		flag_wait(m.my_flags + kFlagSweep + m.peer_rank[threadIdx.x], m.seq, m.status);
+	}
 }
 
 }  // namespace hns
@@ -1332,6 +1335,9 @@ struct Step {
 				if (m.n_boundary_records) {
 					HNS_TRY(hns_rbgs_mirror_sweep(d->gO, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), it == 0, &m, st,
 					                              options().alternate.load() != 0 && (it & 1)));
+					// (locally connected ranks share ONE stream: a rank's flag must not wait for its next launch, which sits behind the
+					// peers' launches that wait for the flag)
+					if (d->single_stream && m.n_peers) hipLaunchKernelGGL(k_sweep_signal, dim3(1), dim3(64), 0, st, m);
 				} else {  // (a rank nobody mirrors, e.g. one without leaves)
 					HNS_TRY(sweep(d->gO, it == 0, st));
 					if (m.n_peers) hipLaunchKernelGGL(k_sweep_signal, dim3(1), dim3(64), 0, st, m);
@@ -1362,9 +1368,7 @@ struct Step {
 				// front of the sweeps it waits for)
 				RbgsMirror m = d->mir;
 				m.seq = d->sweep_seq;
-#if !(defined(HNS_MIRROR_EXP) && (HNS_MIRROR_EXP & 4))  // (timing experiment builds without the flags: nothing to wait for)
 				hipLaunchKernelGGL(k_sweep_wait, dim3(1), dim3(64), 0, st, m);
-#endif
 			}
 			if (d->timing && d->tev_used + 2 <= d->tev.size()) {  // the timed region ends when the last refresh of p has landed (complete() above)
 				HNS_HIP(hipEventRecord(d->tev[d->tev_used + 1], st));

@@ -642,9 +642,10 @@ __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs,
 // has completed the boundary part of its previous sweep (flag; raised early in that sweep, so long true by now): the peer's
 // boundary rows of that sweep are then in this rank's ghost voxels, and the peer no longer reads the ghost voxels of the
 // buffer this sweep writes. It then sweeps like any other wave and stores its rows twice: into p_out, and the voxels a peer
-// can read during ITS next sweep (reach 2) into that peer's ghost copy of the leaf, through the peer's memory mapped here.
-// The last boundary wave of the launch raises this rank's "sweep complete" flag on every peer. No second stream, no pack /
-// transfer / unpack kernels, no ghost sweeps; the arithmetic is k_rbgs_pair's.
+// can read during ITS next sweep (reach 2) into that peer's ghost copy of the leaf, through the peer's memory mapped here,
+// and waits for those stores before it ends. The rank's "sweep complete" flag goes up on every peer when its NEXT launch
+// starts (first workgroup). No second stream, no pack / transfer / unpack kernels, no ghost sweeps; the arithmetic is
+// k_rbgs_pair's.
 // write-through stores at system scope: in the peer's memory when s_waitcnt vmcnt(0) returns
 __device__ __forceinline__ void store_through(float* p, v4f v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void store_through(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
@@ -659,9 +660,6 @@ struct StoreMirror {
 		q[0] = lo;
 		q[1] = hi;
 		if (leaf >= m->n_boundary) return;  // (wave-uniform)
-#if defined(HNS_MIRROR_EXP) && (HNS_MIRROR_EXP & 2)  // no mirror stores
-		return;
-#endif
 		const int e1 = m->first[leaf + 1];
 		for (int e = m->first[leaf]; e < e1; ++e) {
 			const int2 t = m->entry[e];
@@ -693,33 +691,23 @@ __global__ __launch_bounds__(64) void k_rbgs_pair_mirror(const int* __restrict__
 		rec = m.head_records + t;
 	}
 	const int* __restrict__ r = pairs + (size_t)rec * 56;
+	// this launch has started, so the previous sweep of this rank is complete (every boundary wave waited for its write-through
+	// rows before it ended): tell the peers, before anything here waits for them
+	if (blockIdx.x == 0 && (int)threadIdx.x < m.n_peers) flag_store_relaxed(m.peer_flag[threadIdx.x], m.seq - 1u);
 	const int leaf0 = __builtin_amdgcn_readfirstlane(r[0]), leaf1 = __builtin_amdgcn_readfirstlane(r[28]);
 	const bool boundary = leaf0 < m.n_boundary || (unsigned)leaf1 < (unsigned)m.n_boundary;  // wave-uniform
-#if defined(HNS_MIRROR_EXP) && (HNS_MIRROR_EXP & 1)  // timing experiments (profiles/micro/exp): no poll
-	if (false) {
-#else
 	if (boundary) {
-#endif
 		if ((int)threadIdx.x < m.n_peers) flag_wait_relaxed(m.my_flags + kFlagSweep + m.peer_rank[threadIdx.x], m.seq - 1u, m.status);
 		asm volatile("" ::: "memory");  // the loads below stay below the poll
 	}
 	const TileNbr nb = {-1, -1, -1, -1, false};
 	const PairIn in = pair_load<ZERO, false>(c, r, div, p_in, nb);
 	pair_compute<false>(&S, S, c, in, nb, StoreMirror{p_out, &m}, dx2, omega);
-#if defined(HNS_MIRROR_EXP) && (HNS_MIRROR_EXP & 4)  // no count, no signal
-	if (false) {
-#else
-	if (boundary) {
-#endif
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through rows are in the peers' memory before it is counted
-		unsigned done = 0;
-		if (threadIdx.x == 0) done = __hip_atomic_fetch_add(m.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-		done = __builtin_amdgcn_readfirstlane(done);
-		if (done == m.n_boundary_records) {  // the last boundary wave of this launch: every other one's rows have landed too
-			if (threadIdx.x == 0) __hip_atomic_store(m.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if ((int)threadIdx.x < m.n_peers) flag_store_relaxed(m.peer_flag[threadIdx.x], m.seq);
-		}
-	}
+	// its write-through rows are in the peers' memory when a boundary wave ends: the NEXT launch of this rank (or the wait in
+	// front of the gradient kernel) then raises this sweep's flag. (Counting the boundary waves and raising the flag from the
+	// last one -- inside the same launch, so that the peers never wait -- cost 1.6 us per sweep: every boundary wave held its
+	// slot for an atomic round trip.)
+	if (boundary) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // out[0] = number of records that touch a boundary leaf, out[1] = 1 + index of the last of them
