@@ -1026,6 +1026,7 @@ int hns_dist_download(hns_dist* d, float* vel3, float* const* scalars, float* pr
 	hipStream_t st = (hipStream_t)stream;
 	const int nO = d->nB + d->nI;
 	if (nO == 0) return HNS_OK;
+	if (d->cs) HNS_HIP(hipStreamSynchronize(d->cs));  // the boundary leaves' values are written on the communication stream
 	for (int f = -2; f < d->n_scalars; ++f) {
 		const int nc = f == -1 ? 3 : 1;
 		float* dst = f == -2 ? pressure : (f == -1 ? vel3 : (scalars ? scalars[f] : nullptr));

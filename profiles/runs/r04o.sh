@@ -1,0 +1,6 @@
+for i in 1 2; do timeout 900 python -m pytest tests/test_dist_gpu.py -q 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -2 | tr '\n' ' '; echo; done
+timeout 300 python3 profiles/micro/dist_lone.py plume1024 8 4 1 --partition 2>/dev/null | cut -c1-60
+timeout 300 python3 profiles/micro/dist_lone.py plume1024 8 4 4 --partition 2>/dev/null | cut -c1-60
+timeout 300 python3 profiles/micro/dist_lone.py 256 2 0 1 2>/dev/null | cut -c1-60
+timeout 300 python3 profiles/micro/dist_lone.py 256 2 0 4 2>/dev/null | cut -c1-60
+timeout 300 python3 profiles/micro/dist_lone.py 128 2 0 1 2>/dev/null | cut -c1-60
