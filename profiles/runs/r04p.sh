@@ -1,0 +1,5 @@
+mkdir -p gpurun_out/r04p; rm -f gpurun_out/r04p/*
+timeout 1500 python -m pytest tests/ -x -q -m gpu > gpurun_out/r04p/pytest.txt 2>&1; echo rc $? >> gpurun_out/r04p/pytest.txt
+grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" gpurun_out/r04p/pytest.txt | tail -3
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 600 python bench.py 2>&1 | tail -1 | cut -c1-250
