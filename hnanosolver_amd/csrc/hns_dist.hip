@@ -239,10 +239,10 @@ __global__ void k_ipc_landed(const IpcPeers peers, const uint32_t* __restrict__ 
 
 // mirror pressure loop: a rank without boundary waves still tells its peers that its sweep is complete; and, after the last
 // sweep of a solve, a rank waits for its peers' before the gradient kernel reads the ghost voxels they wrote
-__global__ void k_sweep_signal(const RbgsMirror m) {
+__global__ void k_sweep_signal(const PhaseMirror m) {
 	if ((int)threadIdx.x < m.n_peers) flag_store(m.peer_flag[threadIdx.x], m.seq);
 }
-__global__ void k_sweep_wait(const RbgsMirror m) {  // (raises this rank's flag for m.seq first: its sweeps up to m.seq have ended)
+__global__ void k_sweep_wait(const PhaseMirror m) {  // (raises this rank's flag for m.seq first: its sweeps up to m.seq have ended)
 	if ((int)threadIdx.x < m.n_peers) {
 		flag_store(m.peer_flag[threadIdx.x], m.seq);
 		flag_wait(m.my_flags + kFlagSweep + m.peer_rank[threadIdx.x], m.seq, m.status);
@@ -365,8 +365,8 @@ struct hns_dist {
 		void* opened[3] = {nullptr, nullptr, nullptr};
 		uint64_t unit_bytes = 0, rbuf_off[2] = {0, 0};
 		int recv_direct[4] = {-1, -1, -1, -1}, recv_voxels[4] = {0, 0, 0, 0};
-		uint64_t recv_p_leaf_off = 0;
-		uint32_t recv_p_leaves = 0;
+		uint64_t recv_leaf_off[4] = {0, 0, 0, 0};  // where (in its tables allocation) the peer keeps the local indices of its ghost leaves of each region type
+		uint32_t recv_leaves[4] = {0, 0, 0, 0};
 	};
 	std::vector<IpcPeer> ipc_peers;  // parallel to `peers`
 	uint32_t* ipc_flags = nullptr;   // fine-grained device memory, written by the peers
@@ -378,8 +378,14 @@ struct hns_dist {
 	// boundary rows into the peers' ghost voxels (hns_pressure.hip: k_rbgs_pair_mirror)
 	bool mirror = false;
 	void* mir_tables = nullptr;
-	RbgsMirror mir;             // everything but the destination arrays and the sweep number
-	float* mir_peer_p[2][kMirrorMaxPeers];  // p_a / p_b of every peer
+	PhaseMirror mir;            // everything but the region tables, the output arrays and the launch number
+	struct MirTables {          // per halo region type (X_ADV, X_D1, X_DIV, X_P)
+		const int* first = nullptr;
+		const int2* entry = nullptr;
+		const unsigned char* mask = nullptr;  // null: whole leaves
+	} mir_type[4];
+	unsigned n_boundary_records = 0;
+	bool chain = false;         // ... and every other kernel of the substep delivers its own halo too (no communication stream at all)
 	uint32_t sweep_seq = 0;
 	// statistics of the last substep
 	uint64_t bytes_sent[X_COUNT] = {0, 0, 0, 0}, messages_sent = 0, exchanges = 0;
@@ -532,56 +538,85 @@ int ensure_flags(hns_dist* d) {
 	return HNS_OK;
 }
 
-// remote_leaf[i][j]: peer i's local index of its ghost copy of the j-th leaf of this rank's send region of type X_P;
-// peer_pa / peer_pb / peer_flags: that peer's p arrays and flag page as addressable from this process
-int setup_mirror(hns_dist* d, const std::vector<std::vector<int>>& remote_leaf, const std::vector<float*>& peer_pa, const std::vector<float*>& peer_pb,
+// remote_leaf[t][i][j]: peer i's local index of its ghost copy of the j-th leaf of this rank's send region of type t;
+// peer_arena / peer_unit / peer_flags: that peer's field memory, its bytes per scalar field and its flag page as addressable here
+int setup_mirror(hns_dist* d, const std::vector<std::vector<int>> (&remote_leaf)[X_COUNT], const std::vector<char*>& peer_arena, const std::vector<uint64_t>& peer_unit,
                  const std::vector<uint32_t*>& peer_flags) {
-	if (d->peers.size() > (size_t)kMirrorMaxPeers || d->world > kFlagSlots) return HNS_OK;  // (stay on the exchanged pressure loop)
+	if (d->peers.size() > (size_t)kMirrorMaxPeers || d->world > kFlagSlots) return HNS_OK;  // (stay on the exchanged substep)
 	HNS_TRY(ensure_flags(d));
 	const int nB = d->nB;
-	std::vector<std::vector<std::pair<int2, const unsigned char*>>> per_leaf((size_t)nB);
-	for (size_t i = 0; i < d->peers.size(); ++i) {
-		const Region& r = d->peers[i].send[X_P];
-		if (remote_leaf[i].size() != r.leaf.size()) return fail(HNS_ERR_RUNTIME, "hns_dist: send/receive plans of two ranks disagree");
-		for (size_t j = 0; j < r.leaf.size(); ++j) {
-			if (r.leaf[j] < 0 || r.leaf[j] >= nB) return fail(HNS_ERR_RUNTIME, "hns_dist: a mirrored leaf is not a boundary leaf");
-			per_leaf[(size_t)r.leaf[j]].push_back({int2{(int)i, remote_leaf[i][j]}, r.mask.data() + j * 64});
+	std::vector<int> first[X_COUNT];
+	std::vector<int2> entry[X_COUNT];
+	std::vector<unsigned char> mask[X_COUNT];
+	size_t bytes = 256;
+	for (int t = 0; t < X_COUNT; ++t) {
+		std::vector<std::vector<std::pair<int2, const unsigned char*>>> per_leaf((size_t)nB);
+		bool whole = true;
+		for (size_t i = 0; i < d->peers.size(); ++i) {
+			const Region& r = d->peers[i].send[t];
+			if (remote_leaf[t][i].size() != r.leaf.size()) return fail(HNS_ERR_RUNTIME, "hns_dist: send/receive plans of two ranks disagree");
+			whole = whole && (r.whole || r.leaf.empty());
+			for (size_t j = 0; j < r.leaf.size(); ++j) {
+				if (r.leaf[j] < 0 || r.leaf[j] >= nB) return fail(HNS_ERR_RUNTIME, "hns_dist: a mirrored leaf is not a boundary leaf");
+				per_leaf[(size_t)r.leaf[j]].push_back({int2{(int)i, remote_leaf[t][i][j]}, r.mask.data() + j * 64});
+			}
 		}
-	}
-	std::vector<int> first((size_t)nB + 1, 0);
-	std::vector<int2> entry;
-	std::vector<unsigned char> mask;
-	for (int l = 0; l < nB; ++l) {
-		first[(size_t)l] = (int)entry.size();
-		for (auto& e : per_leaf[(size_t)l]) {
-			entry.push_back(e.first);
-			mask.insert(mask.end(), e.second, e.second + 64);
+		first[t].assign((size_t)nB + 1, 0);
+		for (int l = 0; l < nB; ++l) {
+			first[t][(size_t)l] = (int)entry[t].size();
+			for (auto& e : per_leaf[(size_t)l]) {
+				entry[t].push_back(e.first);
+				if (!whole) mask[t].insert(mask[t].end(), e.second, e.second + 64);
+			}
 		}
+		first[t][(size_t)nB] = (int)entry[t].size();
+		bytes += pad256(sizeof(int) * first[t].size()) + pad256(sizeof(int2) * entry[t].size()) + pad256(mask[t].size());
 	}
-	first[(size_t)nB] = (int)entry.size();
-	const size_t b0 = pad256(sizeof(int) * first.size()), b1 = pad256(sizeof(int2) * std::max<size_t>(entry.size(), 1)), b2 = pad256(std::max<size_t>(mask.size(), 1));
-	if (hipMalloc(&d->mir_tables, b0 + b1 + b2 + 256) != hipSuccess) return fail(HNS_ERR_HIP, "hns_dist: allocating the mirror tables failed");
+	if (hipMalloc(&d->mir_tables, bytes) != hipSuccess) return fail(HNS_ERR_HIP, "hns_dist: allocating the mirror tables failed");
 	char* q = (char*)d->mir_tables;
-	HNS_HIP(hipMemcpy(q, first.data(), sizeof(int) * first.size(), hipMemcpyHostToDevice));
-	if (!entry.empty()) HNS_HIP(hipMemcpy(q + b0, entry.data(), sizeof(int2) * entry.size(), hipMemcpyHostToDevice));
-	if (!mask.empty()) HNS_HIP(hipMemcpy(q + b0 + b1, mask.data(), mask.size(), hipMemcpyHostToDevice));
-	RbgsMirror& m = d->mir;
+	auto put = [&](const void* src, size_t n) -> char* {
+		char* r = q;
+		if (n && hipMemcpy(q, src, n, hipMemcpyHostToDevice) != hipSuccess) r = nullptr;
+		q += pad256(n);
+		return r;
+	};
+	unsigned* scratch = (unsigned*)q;
+	q += 256;
+	for (int t = 0; t < X_COUNT; ++t) {
+		d->mir_type[t].first = (const int*)put(first[t].data(), sizeof(int) * first[t].size());
+		d->mir_type[t].entry = (const int2*)put(entry[t].data(), sizeof(int2) * entry[t].size());
+		d->mir_type[t].mask = mask[t].empty() ? nullptr : (const unsigned char*)put(mask[t].data(), mask[t].size());
+		if (!d->mir_type[t].first || !d->mir_type[t].entry) return fail(HNS_ERR_HIP, "hns_dist: uploading the mirror tables failed");
+	}
+	PhaseMirror& m = d->mir;
 	memset(&m, 0, sizeof(m));
 	m.n_boundary = nB, m.n_peers = (int)d->peers.size();
-	m.first = (const int*)q, m.entry = (const int2*)(q + b0), m.mask = (const unsigned char*)(q + b0 + b1);
-	m.count = (unsigned*)(q + b0 + b1 + b2);  // (two words: hns_rbgs_count_boundary_records uses both, the sweeps the first)
 	for (size_t i = 0; i < d->peers.size(); ++i) {
+		m.peer_arena[i] = peer_arena[i], m.peer_unit[i] = peer_unit[i];
 		m.peer_flag[i] = peer_flags[i] + kFlagSweep + d->rank;
 		m.peer_rank[i] = d->peers[i].rank;
-		d->mir_peer_p[0][i] = peer_pa[i], d->mir_peer_p[1][i] = peer_pb[i];
 	}
 	m.my_flags = d->ipc_flags, m.status = d->ipc_status;
 	unsigned counted[2] = {0, 0};
-	HNS_TRY(hns_rbgs_count_boundary_records(d->gO, nB, m.count, counted, nullptr));
-	m.n_boundary_records = counted[0];
+	HNS_TRY(hns_rbgs_count_boundary_records(d->gO, nB, scratch, counted, nullptr));
+	d->n_boundary_records = counted[0];
 	m.head_records = std::min<unsigned>((counted[1] + 7u) & ~7u, (unsigned)d->gO->n_pairs & ~7u);
 	d->mirror = true;
+	// every kernel of the substep in one launch each (32-bit addressed advection kernels: fields below 4 GiB)
+	// (decided from what every rank knows alike: all ranks must take the same path)
+	d->chain = options().dist_chain.load() != 0 && (uint64_t)d->n_global * 6144u <= 0xFFFF0000ull;
 	return HNS_OK;
+}
+
+// the arguments of one chained launch: region type `t`, output arrays `outs` (device fields of this rank, components per voxel)
+PhaseMirror phase_args(hns_dist* d, int t, const std::vector<std::pair<const float*, int>>& outs) {
+	PhaseMirror m = d->mir;
+	m.first = d->mir_type[t].first, m.entry = d->mir_type[t].entry, m.mask = d->mir_type[t].mask;
+	int k = 0, comps = 0;
+	for (auto& f : outs) m.out_unit[k++] = (int)((size_t)((const char*)f.first - (const char*)d->arena) / d->unit_bytes), comps += f.second;
+	m.seq = ++d->sweep_seq;
+	for (Peer& p : d->peers) d->bytes_sent[t] += sizeof(float) * (size_t)p.send[t].voxels * (size_t)comps;
+	return m;
 }
 
 bool mirror_wanted(const hns_dist* d) { return d->k == 1 && d->world > 1 && options().dist_mirror.load() != 0; }
@@ -794,19 +829,22 @@ int hns_dist_connect_loopback(hns_dist* d) {
 	if (d->comm || !d->local_ranks.empty()) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_loopback: already connected");
 	HNS_TRY(ensure_comm_stream(d));
 	d->loopback = true;
-	if (mirror_wanted(d)) {  // the mirroring pressure loop, looped back: boundary rows go into this rank's own ghost leaves, flags to itself
+	if (mirror_wanted(d)) {  // the chained substep, looped back: boundary values go into this rank's own ghost leaves, flags to itself
 		HNS_TRY(ensure_flags(d));
-		std::vector<std::vector<int>> remote(d->peers.size());
-		std::vector<float*> pa, pb;
+		std::vector<std::vector<int>> remote[X_COUNT];
+		std::vector<char*> arenas;
+		std::vector<uint64_t> units;
 		std::vector<uint32_t*> fl;
+		for (int t = 0; t < X_COUNT; ++t) remote[t].resize(d->peers.size());
 		for (size_t i = 0; i < d->peers.size(); ++i) {
 			const Peer& p = d->peers[i];
-			for (size_t j = 0; j < p.send[X_P].leaf.size(); ++j)
-				remote[i].push_back(p.recv[X_P].leaf.empty() ? d->nB + d->nI : p.recv[X_P].leaf[j % p.recv[X_P].leaf.size()]);
-			pa.push_back(d->p_a), pb.push_back(d->p_b);
+			for (int t = 0; t < X_COUNT; ++t)
+				for (size_t j = 0; j < p.send[t].leaf.size(); ++j)
+					remote[t][i].push_back(p.recv[t].leaf.empty() ? d->nB + d->nI : p.recv[t].leaf[j % p.recv[t].leaf.size()]);
+			arenas.push_back((char*)d->arena), units.push_back((uint64_t)d->unit_bytes);
 			fl.push_back(d->ipc_flags + (p.rank - d->rank));  // (so that the flag this rank raises "on the peer" is the one it waits for)
 		}
-		if (d->nG > 0) HNS_TRY(setup_mirror(d, remote, pa, pb, fl));
+		if (d->nG > 0) HNS_TRY(setup_mirror(d, remote, arenas, units, fl));
 	}
 	return HNS_OK;
 }
@@ -836,8 +874,8 @@ struct IpcBlob {  // what a rank tells the others (hns_dist_ipc_export): plain d
 		int32_t rank;
 		int32_t recv_direct[4], recv_voxels[4];
 		uint64_t rbuf_off[2];
-		uint64_t recv_p_leaf_off;  // where (in the tables allocation) the local indices of the ghost leaves of region X_P are
-		uint32_t recv_p_leaves, pad;
+		uint64_t recv_leaf_off[4];  // where (in the tables allocation) the local indices of the ghost leaves of each region type are
+		uint32_t recv_leaves[4];
 	} peer[kIpcMaxPeers];
 };
 static_assert(sizeof(IpcBlob) <= HNS_DIST_IPC_BLOB_BYTES, "HNS_DIST_IPC_BLOB_BYTES is too small");
@@ -861,7 +899,8 @@ int hns_dist_ipc_export(hns_dist* d, void* out_blob) {
 		b.peer[i].rank = p.rank;
 		for (int t = 0; t < X_COUNT; ++t) b.peer[i].recv_direct[t] = p.recv[t].direct, b.peer[i].recv_voxels[t] = p.recv[t].voxels;
 		for (int k = 0; k < 2; ++k) b.peer[i].rbuf_off[k] = (uint64_t)((char*)p.rbuf[k] - (char*)d->tables);
-		b.peer[i].recv_p_leaf_off = (uint64_t)((char*)p.recv[X_P].d_leaf - (char*)d->tables), b.peer[i].recv_p_leaves = (uint32_t)p.recv[X_P].leaf.size();
+		for (int t = 0; t < X_COUNT; ++t)
+			b.peer[i].recv_leaf_off[t] = (uint64_t)((char*)p.recv[t].d_leaf - (char*)d->tables), b.peer[i].recv_leaves[t] = (uint32_t)p.recv[t].leaf.size();
 	}
 	memset(out_blob, 0, HNS_DIST_IPC_BLOB_BYTES);
 	memcpy(out_blob, &b, sizeof(b));
@@ -895,22 +934,24 @@ int hns_dist_connect_ipc(hns_dist* d, const void* blobs) {
 		HNS_HIP(hipIpcOpenMemHandle(&q.opened[1], b.tables, hipIpcMemLazyEnablePeerAccess));
 		HNS_HIP(hipIpcOpenMemHandle(&q.opened[2], b.flags, hipIpcMemLazyEnablePeerAccess));
 		q.arena = (char*)q.opened[0], q.tables = (char*)q.opened[1], q.flags = (uint32_t*)q.opened[2];
-		q.recv_p_leaf_off = me->recv_p_leaf_off, q.recv_p_leaves = me->recv_p_leaves;
+		for (int t = 0; t < X_COUNT; ++t) q.recv_leaf_off[t] = me->recv_leaf_off[t], q.recv_leaves[t] = me->recv_leaves[t];
 	}
 	d->ipc = true;
 	if (mirror_wanted(d)) {
-		std::vector<std::vector<int>> remote(d->peers.size());
-		std::vector<float*> pa, pb;
+		std::vector<std::vector<int>> remote[X_COUNT];
+		std::vector<char*> arenas;
+		std::vector<uint64_t> units;
 		std::vector<uint32_t*> fl;
+		for (int t = 0; t < X_COUNT; ++t) remote[t].resize(d->peers.size());
 		for (size_t i = 0; i < d->peers.size(); ++i) {
 			const hns_dist::IpcPeer& q = d->ipc_peers[i];
-			remote[i].resize(q.recv_p_leaves);
-			if (q.recv_p_leaves) HNS_HIP(hipMemcpy(remote[i].data(), q.tables + q.recv_p_leaf_off, sizeof(int) * q.recv_p_leaves, hipMemcpyDeviceToHost));
-			pa.push_back((float*)(q.arena + (size_t)((char*)d->p_a - (char*)d->arena) / d->unit_bytes * q.unit_bytes));
-			pb.push_back((float*)(q.arena + (size_t)((char*)d->p_b - (char*)d->arena) / d->unit_bytes * q.unit_bytes));
-			fl.push_back(q.flags);
+			for (int t = 0; t < X_COUNT; ++t) {
+				remote[t][i].resize(q.recv_leaves[t]);
+				if (q.recv_leaves[t]) HNS_HIP(hipMemcpy(remote[t][i].data(), q.tables + q.recv_leaf_off[t], sizeof(int) * q.recv_leaves[t], hipMemcpyDeviceToHost));
+			}
+			arenas.push_back(q.arena), units.push_back(q.unit_bytes), fl.push_back(q.flags);
 		}
-		HNS_TRY(setup_mirror(d, remote, pa, pb, fl));
+		HNS_TRY(setup_mirror(d, remote, arenas, units, fl));
 	}
 	return HNS_OK;
 }
@@ -935,16 +976,19 @@ int hns_dist_connect_local(hns_dist* const* ranks, int world) {
 		for (int r = 0; r < world; ++r) HNS_TRY(ensure_flags(ranks[r]));
 		for (int r = 0; r < world; ++r) {
 			hns_dist* d = ranks[r];
-			std::vector<std::vector<int>> remote(d->peers.size());
-			std::vector<float*> pa, pb;
+			std::vector<std::vector<int>> remote[X_COUNT];
+			std::vector<char*> arenas;
+			std::vector<uint64_t> units;
 			std::vector<uint32_t*> fl;
+			for (int t = 0; t < X_COUNT; ++t) remote[t].resize(d->peers.size());
 			for (size_t i = 0; i < d->peers.size(); ++i) {
 				hns_dist* q = ranks[d->peers[i].rank];
 				for (const Peer& c : q->peers)
-					if (c.rank == d->rank) remote[i] = c.recv[X_P].leaf;
-				pa.push_back(q->p_a), pb.push_back(q->p_b), fl.push_back(q->ipc_flags);
+					if (c.rank == d->rank)
+						for (int t = 0; t < X_COUNT; ++t) remote[t][i] = c.recv[t].leaf;
+				arenas.push_back((char*)q->arena), units.push_back((uint64_t)q->unit_bytes), fl.push_back(q->ipc_flags);
 			}
-			HNS_TRY(setup_mirror(d, remote, pa, pb, fl));
+			HNS_TRY(setup_mirror(d, remote, arenas, units, fl));
 		}
 	}
 	return HNS_OK;
@@ -1290,10 +1334,34 @@ struct Step {
 		return hns_dev_advect_scalars(g, d->u, in.data(), d->phi_next.data(), d->n_scalars, nullptr, 0, dt, inv_dx, s);
 	}
 
+	// One chained launch (hns_flags.hpp: PhaseMirror): `launch` runs the kernel over the owned leaves with the arguments `m`.
+	template <class Launch>
+	int chained(const PhaseMirror& m, Launch launch) {
+		if (options().dist_mirror.load() == 2 && m.n_peers) {
+			// "guarded": ONE wave waits for the peers' previous launch in front of this one, so that no boundary workgroup ever
+			// spins. For ranks that share a GPU (tests, bench.py --share-one-gpu): there the boundary waves of several processes
+			// waiting inside their kernels can occupy every wave slot of the device, and the process they all wait for is never
+			// scheduled (four 16k-leaf plume ranks: every bounded wait ran out). ~5 us per launch.
+			PhaseMirror w = m;
+			w.seq = m.seq - 1u;
+			hipLaunchKernelGGL(k_sweep_wait, dim3(1), dim3(64), 0, st, w);
+		}
+		if (d->gO->n_active) {
+			HNS_TRY(launch());
+			// (locally connected ranks share ONE stream: a rank's flag must not wait for its next launch, which sits behind the
+			// peers' launches that wait for the flag)
+			if (d->single_stream && m.n_peers) hipLaunchKernelGGL(k_sweep_signal, dim3(1), dim3(64), 0, st, m);
+		} else if (m.n_peers) {  // a rank without leaves still takes part in the chain of flags
+			hipLaunchKernelGGL(k_sweep_signal, dim3(1), dim3(64), 0, st, m);
+		}
+		return launch_status("hns_dist: chained launch");
+	}
+
 	int run(int ph) {
 		const float inv_dx = 1.0f / d->voxel_size;
 		const int blocks = (iterations + d->k - 1) / d->k;
 		typedef std::vector<std::pair<float*, int>> Fields;
+		typedef std::vector<std::pair<const float*, int>> Outs;
 		hns_dist* D = d;
 		auto nothing = [](hipStream_t) { return HNS_OK; };
 		if (ph == 0) {  // the advection inputs: phi was posted by the previous substep unless new fields were uploaded
@@ -1301,15 +1369,24 @@ struct Step {
 			Fields f;
 			if (!d->u_ghosts_fresh) f.emplace_back(d->u, 3);
 			for (float* p : d->phi) f.emplace_back(p, 1);
+			if (f.empty()) return HNS_OK;
 			return post(d, X_ADV, f, st, nothing);
 		}
 		HNS_TRY(complete(d, st));
 		if (ph == 1) {
+			if (d->chain) {
+				const PhaseMirror m = phase_args(d, X_D1, Outs{{d->adv, 3}});
+				return chained(m, [&] { return hns_chain_advect_vector(d->gO, d->u, d->adv, dt, inv_dx, &m, st); });
+			}
 			const float dtv = dt;
 			HNS_TRY(post(d, X_D1, Fields{{d->adv, 3}}, st, [=](hipStream_t s) { return hns_dev_advect_vector(D->gB, D->u, D->adv, nullptr, 0, dtv, inv_dx, s); }));
 			return hns_dev_advect_vector(d->gI, d->u, d->adv, nullptr, 0, dt, inv_dx, st);
 		}
 		if (ph == 2) {
+			if (d->chain) {
+				const PhaseMirror m = phase_args(d, X_DIV, Outs{{d->div, 1}});
+				return chained(m, [&] { return hns_chain_divergence(d->gO, d->adv, d->div, inv_dx, &m, st); });
+			}
 			HNS_TRY(post(d, X_DIV, Fields{{d->div, 1}}, st, [=](hipStream_t s) { return hns_dev_divergence(D->gB, D->adv, D->div, inv_dx, s); }));
 			return hns_dev_divergence(d->gI, d->adv, d->div, inv_dx, st);
 		}
@@ -1320,30 +1397,14 @@ struct Step {
 				if (d->timing && d->tev_used + 2 <= d->tev.size()) HNS_HIP(hipEventRecord(d->tev[d->tev_used], st));
 			}
 			if (d->mirror) {  // the sweep delivers its boundary rows itself (k_rbgs_pair_mirror): no exchange, no second stream
-				RbgsMirror m = d->mir;
-				const int which = dst == d->p_a ? 0 : 1;
-				for (int i = 0; i < m.n_peers; ++i) m.peer_out[i] = d->mir_peer_p[which][i];
-				m.seq = ++d->sweep_seq;
-				if (options().dist_mirror.load() == 2 && m.n_peers) {
-					// "guarded": ONE wave waits for the peers' previous sweep in front of the launch, so that no boundary wave ever
-					// spins. For ranks that share a GPU (tests, bench.py --share-one-gpu): there the boundary waves of several
-					// processes waiting inside their sweeps can occupy every wave slot of the device, and the process they all
-					// wait for is never scheduled (four 16k-leaf plume ranks: every bounded wait ran out). ~5 us per sweep.
-					RbgsMirror w = m;
-					w.seq = m.seq - 1u;
-					hipLaunchKernelGGL(k_sweep_wait, dim3(1), dim3(64), 0, st, w);
-				}
-				if (m.n_boundary_records) {
-					HNS_TRY(hns_rbgs_mirror_sweep(d->gO, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), it == 0, &m, st,
-					                              options().alternate.load() != 0 && (it & 1)));
-					// (locally connected ranks share ONE stream: a rank's flag must not wait for its next launch, which sits behind the
-					// peers' launches that wait for the flag)
-					if (d->single_stream && m.n_peers) hipLaunchKernelGGL(k_sweep_signal, dim3(1), dim3(64), 0, st, m);
-				} else {  // (a rank nobody mirrors, e.g. one without leaves)
-					HNS_TRY(sweep(d->gO, it == 0, st));
+				const PhaseMirror m = phase_args(d, X_P, Outs{{dst, 1}});
+				const bool zero = it == 0, backwards = options().alternate.load() != 0 && (it & 1);
+				if (d->n_boundary_records || d->gO->n_active == 0) {
+					HNS_TRY(chained(m, [&] { return hns_rbgs_mirror_sweep(d->gO, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), zero, &m, st, backwards); }));
+				} else {  // (a rank nobody mirrors: the plain sweep, and its flag from a kernel of its own)
+					HNS_TRY(sweep(d->gO, zero, st));
 					if (m.n_peers) hipLaunchKernelGGL(k_sweep_signal, dim3(1), dim3(64), 0, st, m);
 				}
-				for (Peer& p : d->peers) d->bytes_sent[X_P] += sizeof(float) * (size_t)p.send[X_P].voxels;
 				const bool last_sweep = it + 1 == iterations;
 				std::swap(src, dst);
 				++it;
@@ -1364,10 +1425,10 @@ struct Step {
 			return HNS_OK;
 		}
 		if (ph == 3 + blocks) {
-			if (d->mirror && d->mir.n_peers) {  // the gradient reads what the peers' last sweep wrote into the ghost voxels
+			if (d->mirror && !d->chain && d->mir.n_peers) {  // the gradient reads what the peers' last sweep wrote into the ghost voxels
 				// (here and not behind the last sweep: locally connected ranks share one stream, and a rank's wait must not sit in
 				// front of the sweeps it waits for)
-				RbgsMirror m = d->mir;
+				PhaseMirror m = d->mir;
 				m.seq = d->sweep_seq;
 				hipLaunchKernelGGL(k_sweep_wait, dim3(1), dim3(64), 0, st, m);
 			}
@@ -1376,12 +1437,28 @@ struct Step {
 				d->tev_used += 2;
 				d->timed_sweeps += iterations;
 			}
+			if (d->chain) {  // (its boundary workgroups wait for the peers' last sweep themselves)
+				const PhaseMirror m = phase_args(d, X_ADV, Outs{{d->u, 3}});
+				return chained(m, [&] { return hns_chain_subtract_pressure_gradient(d->gO, d->adv, d->p_result, d->u, inv_dx, &m, st); });
+			}
 			HNS_TRY(post(d, X_ADV, Fields{{d->u, 3}}, st,
 			             [=](hipStream_t s) { return hns_dev_subtract_pressure_gradient(D->gB, D->adv, D->p_result, D->u, nullptr, 0, inv_dx, s); }));
 			return hns_dev_subtract_pressure_gradient(d->gI, d->adv, d->p_result, d->u, nullptr, 0, inv_dx, st);
 		}
 		// last phase: advect the scalars, and already post them for the advection that opens the next substep
 		d->u_ghosts_fresh = true;
+		if (d->chain) {
+			if (d->n_scalars) {
+				Outs outs;
+				for (float* p : d->phi_next) outs.emplace_back(p, 1);
+				const PhaseMirror m = phase_args(d, X_ADV, outs);
+				std::vector<const float*> in(d->phi.begin(), d->phi.end());
+				HNS_TRY(chained(m, [&] { return hns_chain_advect_scalars(d->gO, d->u, in.data(), d->phi_next.data(), d->n_scalars, dt, inv_dx, &m, st); }));
+				std::swap(d->phi, d->phi_next);
+			}
+			d->phi_in_flight = true;  // (here: the peers' ghost copies of phi are already being written, nothing to open the next substep with)
+			return HNS_OK;
+		}
 		Fields f;
 		for (float* p : d->phi_next) f.emplace_back(p, 1);  // the boundary leaves' new values travel while the interior is advected
 		if (d->n_scalars) HNS_TRY(post(d, X_ADV, f, st, [=](hipStream_t s) { return advect_scalars(D->gB, inv_dx, s); }));

@@ -40,6 +40,7 @@ struct Options {
 	std::atomic<int> cook_pipeline{1};         // "cook_pipeline": hns_compute_sim overlaps transfers with the substep
 	std::atomic<int> dist_wire_us{0};          // "dist_wire_us": loopback transport only, emulated time on the wire per exchange
 	std::atomic<int> dist_mirror{1};           // "dist_mirror": multi-GPU pressure loop with sweeps_per_exchange = 1 over the ipc / local transport delivers its halo inside the sweep kernel
+	std::atomic<int> dist_chain{1};            // "dist_chain": with dist_mirror, EVERY kernel of the substep of such a rank is one launch that delivers its own halo (read when the ranks connect)
 	std::atomic<int> dist_spread{1};           // "dist_spread": the owned launch range of a sweeps_per_exchange = 1 rank deals its boundary leaves out to all XCDs (read at hns_dist_create)
 	std::atomic<int> sor_block{0};             // "sor_block": 0 = auto, N = leaf pairs per workgroup of the blocked SOR kernel
 };
@@ -87,6 +88,12 @@ __device__ __forceinline__ unsigned launch_pos(const GridDev& g, unsigned b) {
 	if (!g.rev) return b;
 	const unsigned rows = (unsigned)g.n_active >> 3;
 	return (b >> 3) < rows ? (((rows - 1u - (b >> 3)) << 3) | (b & 7u)) : b;
+}
+
+// the leaf workgroup b works on (kernels with one workgroup per leaf)
+__device__ __forceinline__ int launch_leaf(const GridDev& g, unsigned b) {
+	const int pos = (int)launch_pos(g, b);
+	return g.sched ? g.sched[pos] : g.first + pos;
 }
 
 // a captured pressure loop (hipGraphExec_t) and the arguments it was captured for
@@ -158,10 +165,17 @@ extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_iterate(hns_grid* 
                                 void* stream, bool from_zero);
 
 // implemented in hns_pressure.hip: one sweep of a multi-GPU rank that mirrors its boundary rows into the peers' ghost voxels
-// itself (hns_flags.hpp: RbgsMirror), and the number of wave records of `g` that touch a local leaf below n_boundary
-namespace hns { struct RbgsMirror; }
+// itself (hns_flags.hpp: PhaseMirror), and the number of wave records of `g` that touch a local leaf below n_boundary
+namespace hns { struct PhaseMirror; }
 extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_mirror_sweep(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero,
-                                                                           const hns::RbgsMirror* m, void* stream, bool backwards);
+                                                                           const hns::PhaseMirror* m, void* stream, bool backwards);
+extern "C" __attribute__((visibility("hidden"))) int hns_chain_divergence(hns_grid* g, const float* vel3, float* div, float inv_dx, const hns::PhaseMirror* m, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int hns_chain_subtract_pressure_gradient(hns_grid* g, const float* vel3, const float* p, float* out3, float inv_dx,
+                                                                                          const hns::PhaseMirror* m, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int hns_chain_advect_vector(hns_grid* g, const float* vel3, float* out3, float dt, float inv_dx, const hns::PhaseMirror* m,
+                                                                             void* stream);
+extern "C" __attribute__((visibility("hidden"))) int hns_chain_advect_scalars(hns_grid* g, const float* vel3, const float* const* in, float* const* out, int n, float dt,
+                                                                              float inv_dx, const hns::PhaseMirror* m, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_count_boundary_records(hns_grid* g, int n_boundary, unsigned* d_scratch, unsigned* out2, void* stream);
 
 // implemented in hns_pointwise.hip: combustion_oxygen split into its divergence update (needs fuel, waste) and the rest

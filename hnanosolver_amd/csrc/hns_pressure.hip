@@ -646,41 +646,22 @@ __global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs,
 // and waits for those stores before it ends. The rank's "sweep complete" flag goes up on every peer when its NEXT launch
 // starts (first workgroup). No second stream, no pack / transfer / unpack kernels, no ghost sweeps; the arithmetic is
 // k_rbgs_pair's.
-// write-through stores at system scope: in the peer's memory when s_waitcnt vmcnt(0) returns
-__device__ __forceinline__ void store_through(float* p, v4f v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void store_through(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
-
 struct StoreMirror {
 	float* __restrict__ p_out;
-	const RbgsMirror* m;
+	const PhaseMirror* m;
 	__device__ __forceinline__ void operator()(int leaf, int k, int l, const RowP& o) const {
 		(void)k;
 		float4* q = reinterpret_cast<float4*>(p_out + (size_t)leaf * 512 + l * 8);
 		const float4 lo = make_float4(o.q[0].x, o.q[0].y, o.q[1].x, o.q[1].y), hi = make_float4(o.q[2].x, o.q[2].y, o.q[3].x, o.q[3].y);
 		q[0] = lo;
 		q[1] = hi;
-		if (leaf >= m->n_boundary) return;  // (wave-uniform)
-		const int e1 = m->first[leaf + 1];
-		for (int e = m->first[leaf]; e < e1; ++e) {
-			const int2 t = m->entry[e];
-			const unsigned bits = m->mask[(size_t)e * 64 + l];
-			float* r = m->peer_out[t.x] + (size_t)t.y * 512 + l * 8;
-			if (bits == 0xFFu) {
-				store_through(r, v4f{lo.x, lo.y, lo.z, lo.w});
-				store_through(r + 4, v4f{hi.x, hi.y, hi.z, hi.w});
-			} else if (bits) {
-				const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-				for (int z = 0; z < 8; ++z)
-					if (bits >> z & 1) store_through(r + z, v[z]);
-			}
-		}
+		chain_store_row(*m, 0, leaf, l, lo, hi);
 	}
 };
 
 template <bool ZERO>
 __global__ __launch_bounds__(64) void k_rbgs_pair_mirror(const int* __restrict__ pairs, const float* __restrict__ div, const float* __restrict__ p_in,
-                                                         float* __restrict__ p_out, const float dx2, const float omega, const int last, const RbgsMirror m) {
+                                                         float* __restrict__ p_out, const float dx2, const float omega, const int last, const PhaseMirror m) {
 	__shared__ __attribute__((aligned(16))) PairTile S;
 	const PairLaneCtx c = pair_lane_ctx(threadIdx.x);
 	unsigned rec = blockIdx.x;
@@ -691,23 +672,15 @@ __global__ __launch_bounds__(64) void k_rbgs_pair_mirror(const int* __restrict__
 		rec = m.head_records + t;
 	}
 	const int* __restrict__ r = pairs + (size_t)rec * 56;
-	// this launch has started, so the previous sweep of this rank is complete (every boundary wave waited for its write-through
-	// rows before it ended): tell the peers, before anything here waits for them
-	if (blockIdx.x == 0 && (int)threadIdx.x < m.n_peers) flag_store_relaxed(m.peer_flag[threadIdx.x], m.seq - 1u);
 	const int leaf0 = __builtin_amdgcn_readfirstlane(r[0]), leaf1 = __builtin_amdgcn_readfirstlane(r[28]);
-	const bool boundary = leaf0 < m.n_boundary || (unsigned)leaf1 < (unsigned)m.n_boundary;  // wave-uniform
-	if (boundary) {
-		if ((int)threadIdx.x < m.n_peers) flag_wait_relaxed(m.my_flags + kFlagSweep + m.peer_rank[threadIdx.x], m.seq - 1u, m.status);
-		asm volatile("" ::: "memory");  // the loads below stay below the poll
-	}
+	const int lowest = ((unsigned)leaf1 < (unsigned)leaf0) ? leaf1 : leaf0;  // a boundary record: either leaf below n_boundary (leaf1 may be -1)
+	chain_begin(m, lowest);
 	const TileNbr nb = {-1, -1, -1, -1, false};
 	const PairIn in = pair_load<ZERO, false>(c, r, div, p_in, nb);
 	pair_compute<false>(&S, S, c, in, nb, StoreMirror{p_out, &m}, dx2, omega);
-	// its write-through rows are in the peers' memory when a boundary wave ends: the NEXT launch of this rank (or the wait in
-	// front of the gradient kernel) then raises this sweep's flag. (Counting the boundary waves and raising the flag from the
-	// last one -- inside the same launch, so that the peers never wait -- cost 1.6 us per sweep: every boundary wave held its
-	// slot for an atomic round trip.)
-	if (boundary) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	// (Counting the boundary waves and raising the flag from the last one -- inside the same launch, so that the peers never wait
+	// -- cost 1.6 us per sweep: every boundary wave held its slot for an atomic round trip.)
+	chain_end(m, lowest);
 }
 
 // out[0] = number of records that touch a boundary leaf, out[1] = 1 + index of the last of them
@@ -962,11 +935,15 @@ __global__ __launch_bounds__(512) void k_subtract_gradient(const GridDev g, cons
 // (float f of the leaf: voxel f / 3, component f % 3, taps along that axis only). Same expression per component:
 // ((p(+) - p(-)) * 0.5f) * inv_dx. The 512-thread form issues ~12 load/store instructions per wave of 64 voxels, mostly
 // 12-byte and scattered 4-byte accesses; this one issues 20 per 512 voxels.
-__global__ __launch_bounds__(64) void k_subtract_gradient_s(const GridDev g, const float* u, const float* __restrict__ p, float* out, const float inv_dx) {
+// M = NoMirror, or PhaseMirror for a chained multi-GPU rank (hns_flags.hpp): the boundary leaves' new velocity also goes, whole
+// leaves, into the peers' ghost copies
+template <class M>
+__global__ __launch_bounds__(64) void k_subtract_gradient_s(const GridDev g, const float* u, const float* __restrict__ p, float* out, const float inv_dx, const M m) {
 	__shared__ __attribute__((aligned(16))) float P[kTile];
 	const int l = threadIdx.x;
 	const int* __restrict__ rec = g.blk + (size_t)launch_pos(g, blockIdx.x) * 28;
 	const int leaf = __builtin_amdgcn_readfirstlane(rec[0]);
+	chain_begin(m, leaf);
 	{
 		const float4* q = reinterpret_cast<const float4*>(p + (size_t)leaf * 512 + l * 8);
 		const float4 a = q[0], b = q[1];
@@ -1004,7 +981,9 @@ __global__ __launch_bounds__(64) void k_subtract_gradient_s(const GridDev g, con
 			r[e] = r[e] - ((P[plus] - P[minus]) * 0.5f) * inv_dx;
 		}
 		dst[l + 64 * j] = make_float4(r[0], r[1], r[2], r[3]);
+		chain_store_leaf16<3>(m, 0, leaf, 4 * (l + 64 * j), make_float4(r[0], r[1], r[2], r[3]));
 	}
+	chain_end(m, leaf);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1049,11 +1028,13 @@ __device__ __forceinline__ void face_duty(int l, int& slot, int& src, int& R) {
 }
 
 // divergence (reference Kernel.cu:499-519): (xp - xm + yp - ym + zp - zm) * inv_dx with xp = (c.x + u(+x).x) * 0.5f, ...
-__global__ __launch_bounds__(64) void k_divergence_row(const GridDev g, const float* __restrict__ u, float* __restrict__ div, const float inv_dx) {
+template <class M>
+__global__ __launch_bounds__(64) void k_divergence_row(const GridDev g, const float* __restrict__ u, float* __restrict__ div, const float inv_dx, const M m) {
 	__shared__ __attribute__((aligned(16))) RowTile TX, TY;  // ux rows (x faces), uy rows (y faces)
 	const int l = threadIdx.x, x = l >> 3, y = l & 7;
 	const int* __restrict__ rec = g.blk + (size_t)launch_pos(g, blockIdx.x) * 28;
 	const int leaf = __builtin_amdgcn_readfirstlane(rec[0]);
+	chain_begin(m, leaf);
 	const int n_zm = __builtin_amdgcn_readfirstlane(rec[1 + 12]), n_zp = __builtin_amdgcn_readfirstlane(rec[1 + 14]);
 	float r[24];
 	glb_row3(u, leaf, l, r);
@@ -1096,6 +1077,8 @@ __global__ __launch_bounds__(64) void k_divergence_row(const GridDev g, const fl
 	float4* q = reinterpret_cast<float4*>(div + (size_t)leaf * 512 + l * 8);
 	q[0] = make_float4(d[0], d[1], d[2], d[3]);
 	q[1] = make_float4(d[4], d[5], d[6], d[7]);
+	chain_store_row(m, 0, leaf, l, make_float4(d[0], d[1], d[2], d[3]), make_float4(d[4], d[5], d[6], d[7]));
+	chain_end(m, leaf);
 }
 
 }  // namespace hns
@@ -1116,9 +1099,24 @@ int hns_dev_divergence(hns_grid* g, const float* vel3, float* div, float inv_dx,
 		// backwards: advect_vector has just written the velocity front to back, so its tail is what the Infinity Cache holds
 		// (256^3: 74 -> 66 us). Option "rev" = 0 walks every kernel forwards.
 		gd.rev = options().rev.load();
-		hipLaunchKernelGGL(k_divergence_row, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, vel3, div, inv_dx);
+		hipLaunchKernelGGL(k_divergence_row<NoMirror>, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, vel3, div, inv_dx, NoMirror{});
 	}
 	return launch_status("hns_dev_divergence");
+}
+
+// the same kernels as ONE launch of a chained multi-GPU rank (hns_flags.hpp: PhaseMirror): boundary leaves first, their
+// results also stored into the peers' ghost voxels
+int hns_chain_divergence(hns_grid* g, const float* vel3, float* div, float inv_dx, const hns::PhaseMirror* m, void* stream) {
+	if (int rc = check_grid(g, "hns_chain_divergence")) return rc;
+	if (g->n_active == 0 || !g->d_blk) return fail(HNS_ERR_RUNTIME, "hns_chain_divergence: empty launch range");
+	hipLaunchKernelGGL(k_divergence_row<PhaseMirror>, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, g->dev(), vel3, div, inv_dx, *m);
+	return launch_status("hns_chain_divergence");
+}
+int hns_chain_subtract_pressure_gradient(hns_grid* g, const float* vel3, const float* p, float* out3, float inv_dx, const hns::PhaseMirror* m, void* stream) {
+	if (int rc = check_grid(g, "hns_chain_subtract_pressure_gradient")) return rc;
+	if (g->n_active == 0 || !g->d_blk) return fail(HNS_ERR_RUNTIME, "hns_chain_subtract_pressure_gradient: empty launch range");
+	hipLaunchKernelGGL(k_subtract_gradient_s<PhaseMirror>, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, g->dev(), vel3, p, out3, inv_dx, *m);
+	return launch_status("hns_chain_subtract_pressure_gradient");
 }
 
 int hns_dev_rbgs_color(hns_grid* g, const float* div, float* p, float dx, float omega, int color, void* stream) {
@@ -1327,7 +1325,7 @@ int hns_rbgs_count_boundary_records(hns_grid* g, int n_boundary, unsigned* d_scr
 	return HNS_OK;
 }
 
-int hns_rbgs_mirror_sweep(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero, const hns::RbgsMirror* m, void* stream, bool backwards) {
+int hns_rbgs_mirror_sweep(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero, const hns::PhaseMirror* m, void* stream, bool backwards) {
 	if (int rc = check_grid(g, "hns_rbgs_mirror_sweep")) return rc;
 	if (!g->d_pairs || g->n_pairs == 0) return fail(HNS_ERR_RUNTIME, "hns_rbgs_mirror_sweep: the grid has no wave records");
 	// The boundary leaves come first in the local leaf order and their waves always run at the START of the launch, next to
@@ -1384,7 +1382,7 @@ int hns_dev_subtract_pressure_gradient(hns_grid* g, const float* vel3, const flo
 	else if (block_form || !g->d_blk)
 		hipLaunchKernelGGL(k_subtract_gradient<false>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, p, out3, sdf, inv_dx);
 	else
-		hipLaunchKernelGGL(k_subtract_gradient_s, grid, dim3(64), 0, (hipStream_t)stream, g->dev(), vel3, p, out3, inv_dx);
+		hipLaunchKernelGGL(k_subtract_gradient_s<NoMirror>, grid, dim3(64), 0, (hipStream_t)stream, g->dev(), vel3, p, out3, inv_dx, NoMirror{});
 	return launch_status("hns_dev_subtract_pressure_gradient");
 }
 
