@@ -12,7 +12,6 @@
 #include <cstring>
 
 #include "hns_device.hpp"
-#include "hns_flags.hpp"
 
 namespace hns {
 
@@ -265,14 +264,10 @@ __device__ __forceinline__ unsigned halo_off(const unsigned* s_b4, int h) {
 }
 
 // 32-bit addressed form (no collision field): same loads and arithmetic as the generic kernel below
-// M = NoMirror, or PhaseMirror for a chained multi-GPU rank (hns_flags.hpp): the voxels of a boundary leaf that a peer's
-// divergence reads (reach 1) also go into that peer's ghost copy of the leaf
-template <class M>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_advect_vector_n(const GridDev g, const float* __restrict__ u, float* __restrict__ out, const float scaled_dt, const M m) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_advect_vector_n(const GridDev g, const float* __restrict__ u, float* __restrict__ out, const float scaled_dt) {
 	__shared__ int s_nbr[27];
 	__shared__ int s_base[27];
 	__shared__ unsigned s_b4[27];
-	chain_begin(m, launch_leaf(g, blockIdx.x));  // (the barrier in stage_leaf_base orders the wait before every ghost read)
 	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4);
 	const int n = threadIdx.x;
 	const int idx = L.leaf * 512 + n;
@@ -324,9 +319,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 	vc.y = fmaxf(mn.y, fminf(vc.y, mx.y));
 	vc.z = fmaxf(mn.z, fminf(vc.z, mx.z));
 	st3(out, idx, vc);
-	const float v3[3] = {vc.x, vc.y, vc.z};
-	chain_store_voxel<3>(m, 0, L.leaf, n, v3);
-	chain_end(m, L.leaf);
 }
 
 template <bool COLL>
@@ -535,12 +527,10 @@ __device__ __forceinline__ void interp_from_taps(const Taps& T, int oob, int (&i
 }
 
 // 32-bit addressed form (no collision field). Out-of-domain taps read element g.oob, as in the generic kernel.
-template <class M>
-__global__ __launch_bounds__(512) void k_advect_scalars_n(const GridDev g, const float* __restrict__ u, const ScalarPtrs P, const float scaled_dt, const M m) {
+__global__ __launch_bounds__(512) void k_advect_scalars_n(const GridDev g, const float* __restrict__ u, const ScalarPtrs P, const float scaled_dt) {
 	__shared__ int s_nbr[27];
 	__shared__ int s_base[27];
 	__shared__ unsigned s_b4[27];
-	chain_begin(m, launch_leaf(g, blockIdx.x));
 	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4);
 	const int n = threadIdx.x;
 	const int idx = L.leaf * 512 + n;
@@ -614,11 +604,8 @@ __global__ __launch_bounds__(512) void k_advect_scalars_n(const GridDev g, const
 		}
 		mn = fminf(mn, phiF);
 		mx = fmaxf(mx, phiF);
-		const float res = fmaxf(mn, fminf(phiCorr, mx));
-		P.out[s][idx] = res;
-		chain_store_voxel<1>(m, s, L.leaf, n, &res);
+		P.out[s][idx] = fmaxf(mn, fminf(phiCorr, mx));
 	}
-	chain_end(m, L.leaf);
 }
 
 template <bool COLL>
@@ -711,7 +698,7 @@ int hns_dev_advect_vector(hns_grid* g, const float* vel3, float* out3, const flo
 	if (has_collision && sdf)
 		hipLaunchKernelGGL(k_advect_vector<true>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, out3, sdf, scaled_dt, inv_dx);
 	else if (narrow_fields(g))
-		hipLaunchKernelGGL(k_advect_vector_n<NoMirror>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, out3, scaled_dt, NoMirror{});
+		hipLaunchKernelGGL(k_advect_vector_n, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, out3, scaled_dt);
 	else
 		hipLaunchKernelGGL(k_advect_vector<false>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, out3, sdf, scaled_dt, inv_dx);
 	return launch_status("hns_dev_advect_vector");
@@ -760,32 +747,12 @@ int hns_dev_advect_scalars(hns_grid* g, const float* vel3, const float* const* i
 			// backwards: the gradient kernel has just written the velocity front to back; starting on its cached tail also
 			// leaves the head cached for the next substep's advect_vector (256^3: -1 % here, -4 % there). Option "rev" = 0: forwards.
 			gd.rev = options().rev.load();
-			hipLaunchKernelGGL(k_advect_scalars_n<NoMirror>, grid, block, 0, (hipStream_t)stream, gd, vel3, P, scaled_dt, NoMirror{});
+			hipLaunchKernelGGL(k_advect_scalars_n, grid, block, 0, (hipStream_t)stream, gd, vel3, P, scaled_dt);
 		}
 		else
 			hipLaunchKernelGGL(k_advect_scalars<false>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, P, sdf, scaled_dt);
 	}
 	return launch_status("hns_dev_advect_scalars");
-}
-
-// the same kernels as ONE launch of a chained multi-GPU rank (hns_flags.hpp: PhaseMirror): boundary leaves first, their
-// results also stored into the peers' ghost voxels. 32-bit addressed forms only (no collision field, fields below 4 GiB).
-int hns_chain_advect_vector(hns_grid* g, const float* vel3, float* out3, float dt, float inv_dx, const hns::PhaseMirror* m, void* stream) {
-	if (int rc = check_grid(g, "hns_chain_advect_vector")) return rc;
-	if (g->n_active == 0 || !narrow_fields(g)) return fail(HNS_ERR_RUNTIME, "hns_chain_advect_vector: empty launch range or fields of 4 GiB and more");
-	hipLaunchKernelGGL(k_advect_vector_n<PhaseMirror>, dim3((unsigned)g->n_active), dim3(512), 0, (hipStream_t)stream, g->dev(), vel3, out3, dt * inv_dx, *m);
-	return launch_status("hns_chain_advect_vector");
-}
-int hns_chain_advect_scalars(hns_grid* g, const float* vel3, const float* const* in, float* const* out, int n, float dt, float inv_dx, const hns::PhaseMirror* m,
-                             void* stream) {
-	if (int rc = check_grid(g, "hns_chain_advect_scalars")) return rc;
-	if (g->n_active == 0 || n <= 0 || n > HNS_MAX_SCALARS || n > 8 || !narrow_fields(g))
-		return fail(HNS_ERR_RUNTIME, "hns_chain_advect_scalars: empty launch range, too many fields or fields of 4 GiB and more");
-	ScalarPtrs P;
-	P.n = n;
-	for (int s = 0; s < HNS_MAX_SCALARS; ++s) P.in[s] = s < n ? in[s] : nullptr, P.out[s] = s < n ? out[s] : nullptr;
-	hipLaunchKernelGGL(k_advect_scalars_n<PhaseMirror>, dim3((unsigned)g->n_active), dim3(512), 0, (hipStream_t)stream, g->dev(), vel3, P, dt * inv_dx, *m);
-	return launch_status("hns_chain_advect_scalars");
 }
 
 }  // extern "C"

@@ -237,6 +237,40 @@ __global__ void k_ipc_landed(const IpcPeers peers, const uint32_t* __restrict__ 
 	}
 }
 
+// Chained substep, the two advection kernels: they run as they are (512 threads per leaf at a 64-register cap: the chain code
+// inside them cost three spilled registers and 25 % of their speed, measured) between a one-wave gate (k_sweep_wait: "peers,
+// my previous launch is complete" + wait for theirs) and this kernel, which copies what the peers read of the boundary
+// leaves' new values into the peers' ghost voxels: one wave per boundary leaf, lane = z-row.
+template <int NC>
+__global__ __launch_bounds__(64) void k_chain_mirror(const PhaseMirror m, const int n_out, const float* f0, const float* f1, const float* f2, const float* f3,
+                                                     const float* f4, const float* f5, const float* f6, const float* f7) {
+	const int leaf = blockIdx.x, l = threadIdx.x;
+	const float* fields[8] = {f0, f1, f2, f3, f4, f5, f6, f7};
+	const int e1 = m.first[leaf + 1];
+	for (int e = m.first[leaf]; e < e1; ++e) {
+		const int2 t = m.entry[e];
+		const unsigned bits = m.mask ? m.mask[(size_t)e * 64 + l] : 0xFFu;
+		if (!bits) continue;
+#pragma unroll 1
+		for (int o = 0; o < n_out; ++o) {
+			const float* src = fields[o] + ((size_t)leaf * 512 + l * 8) * NC;
+			float* dst = chain_out(m, t.x, o) + ((size_t)t.y * 512 + l * 8) * NC;
+			if (bits == 0xFFu) {
+#pragma unroll
+				for (int q = 0; q < 2 * NC; ++q) store_through(dst + 4 * q, *reinterpret_cast<const float4*>(src + 4 * q));
+			} else {
+#pragma unroll
+				for (int z = 0; z < 8; ++z)
+					if (bits >> z & 1) {
+#pragma unroll
+						for (int c = 0; c < NC; ++c) store_through(dst + z * NC + c, src[z * NC + c]);
+					}
+			}
+		}
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // mirror pressure loop: a rank without boundary waves still tells its peers that its sweep is complete; and, after the last
 // sweep of a solve, a rank waits for its peers' before the gradient kernel reads the ghost voxels they wrote
 __global__ void k_sweep_signal(const PhaseMirror m) {
@@ -1336,8 +1370,8 @@ struct Step {
 
 	// One chained launch (hns_flags.hpp: PhaseMirror): `launch` runs the kernel over the owned leaves with the arguments `m`.
 	template <class Launch>
-	int chained(const PhaseMirror& m, Launch launch) {
-		if (options().dist_mirror.load() == 2 && m.n_peers) {
+	int chained(const PhaseMirror& m, Launch launch, bool gate = false) {
+		if ((gate || options().dist_mirror.load() == 2) && m.n_peers) {
 			// "guarded": ONE wave waits for the peers' previous launch in front of this one, so that no boundary workgroup ever
 			// spins. For ranks that share a GPU (tests, bench.py --share-one-gpu): there the boundary waves of several processes
 			// waiting inside their kernels can occupy every wave slot of the device, and the process they all wait for is never
@@ -1376,7 +1410,13 @@ struct Step {
 		if (ph == 1) {
 			if (d->chain) {
 				const PhaseMirror m = phase_args(d, X_D1, Outs{{d->adv, 3}});
-				return chained(m, [&] { return hns_chain_advect_vector(d->gO, d->u, d->adv, dt, inv_dx, &m, st); });
+				return chained(m, [&] {  // gate | the kernel as it is | copy of the boundary leaves' reach-1 voxels into the peers' ghosts
+					HNS_TRY(hns_dev_advect_vector(d->gO, d->u, d->adv, nullptr, 0, dt, inv_dx, st));
+					if (d->nB && m.n_peers)
+						hipLaunchKernelGGL(k_chain_mirror<3>, dim3((unsigned)d->nB), dim3(64), 0, st, m, 1, (const float*)d->adv, (const float*)nullptr, (const float*)nullptr,
+						                   (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
+					return HNS_OK;
+				}, true);
 			}
 			const float dtv = dt;
 			HNS_TRY(post(d, X_D1, Fields{{d->adv, 3}}, st, [=](hipStream_t s) { return hns_dev_advect_vector(D->gB, D->u, D->adv, nullptr, 0, dtv, inv_dx, s); }));
@@ -1453,7 +1493,14 @@ struct Step {
 				for (float* p : d->phi_next) outs.emplace_back(p, 1);
 				const PhaseMirror m = phase_args(d, X_ADV, outs);
 				std::vector<const float*> in(d->phi.begin(), d->phi.end());
-				HNS_TRY(chained(m, [&] { return hns_chain_advect_scalars(d->gO, d->u, in.data(), d->phi_next.data(), d->n_scalars, dt, inv_dx, &m, st); }));
+				HNS_TRY(chained(m, [&] {
+					HNS_TRY(hns_dev_advect_scalars(d->gO, d->u, in.data(), d->phi_next.data(), d->n_scalars, nullptr, 0, dt, inv_dx, st));
+					const float* f[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+					for (int s = 0; s < d->n_scalars && s < 8; ++s) f[s] = d->phi_next[(size_t)s];
+					if (d->nB && m.n_peers)
+						hipLaunchKernelGGL(k_chain_mirror<1>, dim3((unsigned)d->nB), dim3(64), 0, st, m, d->n_scalars, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+					return HNS_OK;
+				}, true));
 				std::swap(d->phi, d->phi_next);
 			}
 			d->phi_in_flight = true;  // (here: the peers' ghost copies of phi are already being written, nothing to open the next substep with)

@@ -87,6 +87,7 @@ __device__ __forceinline__ float* chain_out(const PhaseMirror& m, int peer, int 
 // first thing in every workgroup (before any ghost voxel is read; multi-wave workgroups need a barrier after it)
 __device__ __forceinline__ void chain_begin(const NoMirror&, int) {}
 __device__ __forceinline__ void chain_begin(const PhaseMirror& m, int leaf) {
+	leaf = __builtin_amdgcn_readfirstlane(leaf);  // (workgroup-uniform: keeps everything derived from it in scalar registers)
 	// this launch has started, so the previous launch of this rank is complete (every boundary workgroup waited for its
 	// write-through stores before it ended): tell the peers, before anything here waits for them
 	if (blockIdx.x == 0 && (int)threadIdx.x < m.n_peers) flag_store_relaxed(m.peer_flag[threadIdx.x], m.seq - 1u);
@@ -96,12 +97,13 @@ __device__ __forceinline__ void chain_begin(const PhaseMirror& m, int leaf) {
 // last thing in every workgroup
 __device__ __forceinline__ void chain_end(const NoMirror&, int) {}
 __device__ __forceinline__ void chain_end(const PhaseMirror& m, int leaf) {
-	if (leaf < m.n_boundary) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if (__builtin_amdgcn_readfirstlane(leaf) < m.n_boundary) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 // a z-row (8 floats) of float output `out`
 __device__ __forceinline__ void chain_store_row(const NoMirror&, int, int, int, float4, float4) {}
 __device__ __forceinline__ void chain_store_row(const PhaseMirror& m, int out, int leaf, int row, float4 lo, float4 hi) {
-	if (leaf >= m.n_boundary) return;  // (workgroup-uniform)
+	leaf = __builtin_amdgcn_readfirstlane(leaf);  // (workgroup-uniform: the table walk below stays in scalar registers)
+	if (leaf >= m.n_boundary) return;
 	const int e1 = m.first[leaf + 1];
 	for (int e = m.first[leaf]; e < e1; ++e) {
 		const int2 t = m.entry[e];
@@ -123,6 +125,7 @@ template <int NC>
 __device__ __forceinline__ void chain_store_voxel(const NoMirror&, int, int, int, const float*) {}
 template <int NC>
 __device__ __forceinline__ void chain_store_voxel(const PhaseMirror& m, int out, int leaf, int n, const float* v) {
+	leaf = __builtin_amdgcn_readfirstlane(leaf);
 	if (leaf >= m.n_boundary) return;
 	const int e1 = m.first[leaf + 1];
 	for (int e = m.first[leaf]; e < e1; ++e) {
@@ -138,6 +141,7 @@ template <int NC>
 __device__ __forceinline__ void chain_store_leaf16(const NoMirror&, int, int, int, float4) {}
 template <int NC>
 __device__ __forceinline__ void chain_store_leaf16(const PhaseMirror& m, int out, int leaf, int o, float4 v) {
+	leaf = __builtin_amdgcn_readfirstlane(leaf);
 	if (leaf >= m.n_boundary) return;
 	const int e1 = m.first[leaf + 1];
 	for (int e = m.first[leaf]; e < e1; ++e) {

@@ -172,10 +172,6 @@ extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_mirror_sweep(hns_g
 extern "C" __attribute__((visibility("hidden"))) int hns_chain_divergence(hns_grid* g, const float* vel3, float* div, float inv_dx, const hns::PhaseMirror* m, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int hns_chain_subtract_pressure_gradient(hns_grid* g, const float* vel3, const float* p, float* out3, float inv_dx,
                                                                                           const hns::PhaseMirror* m, void* stream);
-extern "C" __attribute__((visibility("hidden"))) int hns_chain_advect_vector(hns_grid* g, const float* vel3, float* out3, float dt, float inv_dx, const hns::PhaseMirror* m,
-                                                                             void* stream);
-extern "C" __attribute__((visibility("hidden"))) int hns_chain_advect_scalars(hns_grid* g, const float* vel3, const float* const* in, float* const* out, int n, float dt,
-                                                                              float inv_dx, const hns::PhaseMirror* m, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_count_boundary_records(hns_grid* g, int n_boundary, unsigned* d_scratch, unsigned* out2, void* stream);
 
 // implemented in hns_pointwise.hip: combustion_oxygen split into its divergence update (needs fuel, waste) and the rest

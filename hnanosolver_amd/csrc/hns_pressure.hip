@@ -1109,7 +1109,9 @@ int hns_dev_divergence(hns_grid* g, const float* vel3, float* div, float inv_dx,
 int hns_chain_divergence(hns_grid* g, const float* vel3, float* div, float inv_dx, const hns::PhaseMirror* m, void* stream) {
 	if (int rc = check_grid(g, "hns_chain_divergence")) return rc;
 	if (g->n_active == 0 || !g->d_blk) return fail(HNS_ERR_RUNTIME, "hns_chain_divergence: empty launch range");
-	hipLaunchKernelGGL(k_divergence_row<PhaseMirror>, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, g->dev(), vel3, div, inv_dx, *m);
+	GridDev gd = g->dev();
+	gd.rev = options().rev.load();  // (as hns_dev_divergence; walked backwards the boundary leaves come last, which the chain does not mind)
+	hipLaunchKernelGGL(k_divergence_row<PhaseMirror>, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, vel3, div, inv_dx, *m);
 	return launch_status("hns_chain_divergence");
 }
 int hns_chain_subtract_pressure_gradient(hns_grid* g, const float* vel3, const float* p, float* out3, float inv_dx, const hns::PhaseMirror* m, void* stream) {
