@@ -283,7 +283,7 @@ class SlabBench:
         self.rank_obj.upload(*self._fields)
 
     def _verified_one_sided(self, make, sweeps_per_exchange, reference_transport):
-        """transport = auto: the one-sided transport with the mirroring pressure loop if -- on THIS machine, now -- it connects
+        """transport = auto: the one-sided transport with the chained substep (every kernel delivers its own halo) if -- on THIS machine, now -- it connects
         and three substeps of it leave bit for bit what three substeps over the reference transport (RCCL) leave on every rank;
         RCCL otherwise. Every decision is taken by all ranks together."""
         import torch
@@ -319,7 +319,7 @@ class SlabBench:
         dist.barrier()  # nobody unmaps or frees while a peer may still be writing
         if ok:
             ref.close()
-            self.transport_note = f"one-sided puts into mapped peer memory, SOR sweep delivers its own halo; verified bit for bit against {reference_transport} at start-up"
+            self.transport_note = f"every kernel stores its boundary values into the peers' mapped ghost voxels itself, no exchanges; verified bit for bit against {reference_transport} at start-up"
             return cand
         cand.close()
         self.transport_note = f"{reference_transport} (one-sided transport not used: {why or 'a peer rank failed its check'})"
