@@ -132,13 +132,16 @@ __device__ __forceinline__ void row_candidates(const Row8& xp, const Row8& xm, c
 	for (int z = 0; z < 8; ++z) cand[z] = sor_update(xp.v[z], xm.v[z], yp.v[z], ym.v[z], c[z + 2], c[z], d[z], c[z + 1], dx2, omega);
 }
 
+// M = NoMirror, or PhaseMirror for a chained multi-GPU rank (hns_flags.hpp): the form for small ragged ranks (see rbgs_form)
+template <class M>
 __global__ __launch_bounds__(64) void k_rbgs_wave(const GridDev g, const float* __restrict__ div, const float* __restrict__ p_in,
-                                                  float* __restrict__ p_out, const float dx2, const float omega) {
+                                                  float* __restrict__ p_out, const float dx2, const float omega, const M m) {
 	__shared__ __attribute__((aligned(16))) float T[W_FLOATS];
 	const int l = threadIdx.x;
 	// per-block record {leaf, nbr27[27]} in launch order: one dependent scalar fetch instead of sched -> nbr27
 	const int* __restrict__ rec = g.blk + (size_t)blockIdx.x * 28;
 	const int leaf = __builtin_amdgcn_readfirstlane(rec[0]);
+	chain_begin(m, leaf);
 	const int n_xm = __builtin_amdgcn_readfirstlane(rec[1 + 4]), n_xp = __builtin_amdgcn_readfirstlane(rec[1 + 22]);
 	const int n_ym = __builtin_amdgcn_readfirstlane(rec[1 + 10]), n_yp = __builtin_amdgcn_readfirstlane(rec[1 + 16]);
 	const int n_zm = __builtin_amdgcn_readfirstlane(rec[1 + 12]), n_zp = __builtin_amdgcn_readfirstlane(rec[1 + 14]);
@@ -257,7 +260,9 @@ __global__ __launch_bounds__(64) void k_rbgs_wave(const GridDev g, const float* 
 		float4* q = reinterpret_cast<float4*>(p_out + (size_t)leaf * 512 + l * 8);
 		q[0] = o0;
 		q[1] = o1;
+		chain_store_row(m, 0, leaf, l, o0, o1);
 	}
+	chain_end(m, leaf);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1160,7 +1165,7 @@ static int launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* di
 		hipLaunchKernelGGL(k_rbgs_color, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, dst, dx2, omega, 0);
 		hipLaunchKernelGGL(k_rbgs_color, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, dst, dx2, omega, 1);
 	} else if (form == kRbgsWave) {
-		hipLaunchKernelGGL(k_rbgs_wave, dim3((unsigned)g->n_active), dim3(64), 0, st, gd, div, src, dst, dx2, omega);
+		hipLaunchKernelGGL(k_rbgs_wave<NoMirror>, dim3((unsigned)g->n_active), dim3(64), 0, st, gd, div, src, dst, dx2, omega, NoMirror{});
 	} else if (form == kRbgsTile) {
 		// complete groups through the blocked kernel, the records outside them through the one-wave kernel (disjoint leaves, both
 		// read src and write dst: any order)
@@ -1330,6 +1335,13 @@ int hns_rbgs_count_boundary_records(hns_grid* g, int n_boundary, unsigned* d_scr
 int hns_rbgs_mirror_sweep(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero, const hns::PhaseMirror* m, void* stream, bool backwards) {
 	if (int rc = check_grid(g, "hns_rbgs_mirror_sweep")) return rc;
 	if (!g->d_pairs || g->n_pairs == 0) return fail(HNS_ERR_RUNTIME, "hns_rbgs_mirror_sweep: the grid has no wave records");
+	// small ragged ranks: one leaf per wave, as on a single GPU (rbgs_form; the 66k-leaf plume in 8 ranges: 22 -> 17 us per sweep)
+	const int opt = options().rbgs.load();
+	if (opt == kRbgsWave || (opt == kRbgsAuto && g->d_blk && (g->n_active <= 2048 || (g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs)))) {
+		if (src_is_zero) HNS_HIP(hipMemsetAsync(const_cast<float*>(src), 0, sizeof(float) * 512 * (size_t)g->topo.n_leaves, (hipStream_t)stream));  // this form reads its input
+		hipLaunchKernelGGL(k_rbgs_wave<PhaseMirror>, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, g->dev(), div, src, dst, dx2_of(dx), omega, *m);
+		return launch_status("hns_rbgs_mirror_sweep");
+	}
 	// The boundary leaves come first in the local leaf order and their waves always run at the START of the launch, next to
 	// everything else (walked backwards they were a tail of slow waves: 69 us per sweep instead of 38), so a rank's "sweep
 	// complete" flag goes up long before its sweep ends and the peers' next sweep never waits for it. `backwards` reverses
