@@ -261,6 +261,35 @@ def test_one_process_per_rank_over_mapped_peer_memory(case, world, k, iters, tmp
         assert int(g["messages"]) > 0 or k == 1  # (k = 1: after the first substep every kernel delivers its own halo, no messages)
 
 
+@pytest.mark.parametrize("extra", [[], ["--config", "plume", "--partition"]])
+def test_bench_py_as_two_processes_sharing_the_gpu(extra, tmp_path):
+    """bench.py's N > 1 path end to end, launched the way the driver launches it (torch.distributed.run, one process per
+    rank) with both ranks on the one GPU: transport selection (the chained one-sided path checked against the exchanged one
+    in place), the timed loop, the JSON line. RCCL itself refuses two ranks on one device, so the reference transport of the
+    start-up check is the exchanged ipc path here (--share-one-gpu)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--share-one-gpu", "--steps", "3", "--warmup", "1", "--iterations", "10"] + (extra or ["--config", "64"])
+    p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["value"] > 0 and j["unit"] == "substeps/s"
+    assert j["scaling"] == ("strong" if extra else "weak")
+    assert "verified bit for bit" in j["config"]["parallelism"], j["config"]["parallelism"]
+    assert j["config"]["halo"]["sweeps_per_exchange"] == 1 and j["config"]["halo"]["bytes_sent"]["p"] > 0
+
+
 def test_unconnected_ranks_refuse_to_step():
     import hnanosolver_amd as H
 
