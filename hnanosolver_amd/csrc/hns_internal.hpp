@@ -42,6 +42,7 @@ struct Options {
 	std::atomic<int> dist_mirror{1};           // "dist_mirror": multi-GPU pressure loop with sweeps_per_exchange = 1 over the ipc / local transport delivers its halo inside the sweep kernel
 	std::atomic<int> dist_chain{1};            // "dist_chain": with dist_mirror, EVERY kernel of the substep of such a rank is one launch that delivers its own halo (read when the ranks connect)
 	std::atomic<int> dist_spread{1};           // "dist_spread": the owned launch range of a sweeps_per_exchange = 1 rank deals its boundary leaves out to all XCDs (read at hns_dist_create)
+	std::atomic<int> sor_lds_pad{0};           // "sor_lds_pad": extra dynamic LDS bytes per wave of the pair kernel (an occupancy experiment: fewer waves in flight per XCD)
 	std::atomic<int> sor_block{0};             // "sor_block": 0 = auto, N = leaf pairs per workgroup of the blocked SOR kernel
 };
 Options& options();

@@ -149,6 +149,7 @@ const OptionDesc kOptions[] = {
     {"cook_cache", &Options::cook_cache, kWordsBool},
     {"cook_pipeline", &Options::cook_pipeline, kWordsBool},
     {"sor_block", &Options::sor_block, nullptr},
+    {"sor_lds_pad", &Options::sor_lds_pad, nullptr},
     {"schedule_segment", &Options::schedule_segment, nullptr},
     {"dist_wire_us", &Options::dist_wire_us, nullptr},
     {"dist_mirror", &Options::dist_mirror, kWordsMirror},

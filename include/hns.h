@@ -72,6 +72,7 @@ int hns_trim_memory(void);
  *   "cook_cache"    1 | 0 (operator calls keep their device buffers with the grid)
  *   "cook_pipeline" 1 | 0 (hns_compute_sim overlaps its transfers with the substep)
  *   "sor_block"     0 = auto | N leaf pairs per workgroup of the SOR kernel
+ *   "sor_lds_pad"   N: extra LDS bytes per wave of the pair SOR kernel (fewer waves in flight; an experiment)
  *   "dist_wire_us"  N: the loopback transport of hns_dist holds every exchange N microseconds (emulated wire time)
  *   "dist_chain"    1 | 0: with dist_mirror, every kernel of the substep of such a rank delivers its own halo (no exchanges at all
  *                   after the first substep); 0 = only the SOR sweeps do (read when the ranks connect; all ranks must agree)
