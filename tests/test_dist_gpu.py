@@ -237,8 +237,7 @@ def _run_processes(world, case, k, iters, substeps, tmp_path, timeout=420):
     return [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
 
 
-@pytest.mark.parametrize("case,world,k,iters", [("dense32", 2, 4, 7), ("plume", 3, 2, 7), ("plume12", 4, 3, 9), ("dense64", 2, 0, 50), ("dense64", 2, 1, 50),
-                                                ("plume12", 4, 1, 9), ("plume", 3, 1, 7)])
+@pytest.mark.parametrize("case,world,k,iters", [("plume", 3, 2, 7), ("plume12", 4, 3, 9), ("dense64", 2, 0, 50), ("dense64", 2, 1, 50), ("plume12", 4, 1, 9)])
 def test_one_process_per_rank_over_mapped_peer_memory(case, world, k, iters, tmp_path):
     """The multi-process path for real: `world` PROCESSES (here sharing the one GPU), each a rank with its own streams, the
     halos put into the peer's memory through hipIpc mappings and the ranks meeting through device-side flags while their
