@@ -57,6 +57,41 @@ __device__ __forceinline__ float lerp_f(float a, float b, float w) { return a + 
 __device__ __forceinline__ float lerp_c(float a, float b, float w) { return __fmaf_rn(w, b - a, a); }
 
 
+// ---- launch order ------------------------------------------------------------------------------------------------
+// Block -> leaf order. The dispatcher places workgroup b on XCD b % 8 (observed, not contractual), each XCD has a
+// private 4 MiB L2, and a leaf's halo is its neighbours' payload: every XCD gets one contiguous chunk of the leaf
+// list (sizes differ by at most one leaf), so halo reads hit the L2 that already holds those leaves. Speed only; any
+// order is correct. Option "schedule" = linear disables it.
+// `seg`: leaves per contiguous segment; consecutive segments go to consecutive XCDs. seg = 1 is plain leaf order, seg <= 0
+// (or >= n/8) one chunk per XCD; in between, the eight XCDs walk through neighbouring stretches of memory together (DRAM
+// pages, Infinity Cache) while a leaf's z / y neighbours still sit in its own L2.
+__host__ __device__ inline int sched_leaf(int b, int n, int seg) {
+	if (seg == 1) return b;
+	int body = 0;
+	if (seg > 1) {
+		const int rows = n / (8 * seg);
+		body = rows * 8 * seg;
+		if (b < body) {
+			const int x = b & 7, i = b >> 3;
+			return ((i / seg) * 8 + x) * seg + i % seg;
+		}
+		b -= body, n -= body;
+	}
+	const int base = n >> 3, rem = n & 7;
+	const int x = b & 7, i = b >> 3;  // rows i < base hold all eight XCDs; the last row only x < rem, and b - 8*base == x there
+	return body + x * base + (x < rem ? x : rem) + i;
+}
+
+// `pre` (a multiple of 8, 0 = none): the first `pre` leaves are dealt out first, an equal contiguous piece to every XCD, the rest
+// as above behind them -- a multi-GPU rank's boundary leaves (first in its leaf order) then run on all eight XCDs instead of
+// filling the head of XCD 0's chunk (hns_dist.hip: their waves poll and signal, and are slower than the others).
+__host__ __device__ inline int sched_leaf(int b, int n, int seg, int pre) {
+	if (pre <= 0) return sched_leaf(b, n, seg);
+	if (b < pre) return (b & 7) * (pre >> 3) + (b >> 3);
+	return pre + sched_leaf(b - pre, n - pre, seg);
+}
+
+
 // ---- face-neighbour values through LDS ------------------------------------------------------------------------------
 // Kernels that need the six face neighbours of every voxel of a leaf (BFECC clamps, pressure gradient) would issue six
 // wave-wide loads per thread, and on gfx950 the L1 charges a load instruction 16 cycles per wave whatever it touches. A

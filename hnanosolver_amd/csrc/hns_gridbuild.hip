@@ -64,38 +64,7 @@ __global__ __launch_bounds__(256) void k_build_nbr27(GridDev g, int* __restrict_
 // launch order
 // ---------------------------------------------------------------------------------------------------------------
 
-// Block -> leaf order. The dispatcher places workgroup b on XCD b % 8 (observed, not contractual), each XCD has a
-// private 4 MiB L2, and a leaf's halo is its neighbours' payload: every XCD gets one contiguous chunk of the leaf
-// list (sizes differ by at most one leaf), so halo reads hit the L2 that already holds those leaves. Speed only; any
-// order is correct. Option "schedule" = linear disables it.
-// `seg`: leaves per contiguous segment; consecutive segments go to consecutive XCDs. seg = 1 is plain leaf order, seg <= 0
-// (or >= n/8) one chunk per XCD; in between, the eight XCDs walk through neighbouring stretches of memory together (DRAM
-// pages, Infinity Cache) while a leaf's z / y neighbours still sit in its own L2.
-__host__ __device__ inline int sched_leaf(int b, int n, int seg) {
-	if (seg == 1) return b;
-	int body = 0;
-	if (seg > 1) {
-		const int rows = n / (8 * seg);
-		body = rows * 8 * seg;
-		if (b < body) {
-			const int x = b & 7, i = b >> 3;
-			return ((i / seg) * 8 + x) * seg + i % seg;
-		}
-		b -= body, n -= body;
-	}
-	const int base = n >> 3, rem = n & 7;
-	const int x = b & 7, i = b >> 3;  // rows i < base hold all eight XCDs; the last row only x < rem, and b - 8*base == x there
-	return body + x * base + (x < rem ? x : rem) + i;
-}
-
-// `pre` (a multiple of 8, 0 = none): the first `pre` leaves are dealt out first, an equal contiguous piece to every XCD, the rest
-// as above behind them -- a multi-GPU rank's boundary leaves (first in its leaf order) then run on all eight XCDs instead of
-// filling the head of XCD 0's chunk (hns_dist.hip: their waves poll and signal, and are slower than the others).
-__host__ __device__ inline int sched_leaf(int b, int n, int seg, int pre) {
-	if (pre <= 0) return sched_leaf(b, n, seg);
-	if (b < pre) return (b & 7) * (pre >> 3) + (b >> 3);
-	return pre + sched_leaf(b - pre, n - pre, seg);
-}
+// (sched_leaf: the block -> leaf order, lives in hns_device.hpp: hns_sorblock.hip orders its leaf blocks with it too)
 
 // {leaf, nbr27[27]} per block in launch order: the kernels that work one leaf per workgroup read their whole
 // topology with one fetch.
@@ -323,6 +292,7 @@ int hns_grid_upload_schedule(hns_grid* g) {
 	k_write_pairs<<<n_blocks, 256, 0, 0>>>(nbr27, first, n, linear, pre, partner, block_heads, (int*)g->d_pairs);
 	HNS_HIP(hipDeviceSynchronize());
 	g->tiles_built = false;  // built when a solve first asks for the blocked or resident form (most grids never do)
+	g->sb_built = false;     // (likewise the block records of hns_sorblock.hip)
 	g->n_tile_groups = g->n_tile_rest = 0;
 	return HNS_OK;
 }
@@ -451,6 +421,11 @@ void hns_grid_free_device(hns_grid* g) {
 	g->graphs.clear();
 	if (g->cap_stream) (void)hipStreamDestroy((hipStream_t)g->cap_stream);
 	g->cap_stream = nullptr;
+	if (g->d_sb_tab) hns_arena_put(g->d_sb_tab, g->sb_bytes, g->device);
+	g->d_sb_tab = nullptr;
+	g->sb_bytes = 0;
+	g->n_sb = 0;
+	g->sb_built = false;
 	hns_arena_put(g->d_arena, g->arena_bytes, g->device);
 	g->d_arena = nullptr;
 	g->arena_bytes = 0;

@@ -25,10 +25,10 @@ inline int fail(int code, const char* msg) {
 // ---- options (hns_set_option) -------------------------------------------------------------------------------------
 // Alternative kernel forms and data-movement strategies kept for A/B measurement and as cross-checks of the default one.
 // Every entry point reads the current value when it is called, so a test or benchmark can switch forms between calls.
-enum { kRbgsAuto = 0, kRbgsColor = 1, kRbgsWave = 2, kRbgsPair = 3, kRbgsResident = 4, kRbgsTile = 5 };
+enum { kRbgsAuto = 0, kRbgsColor = 1, kRbgsWave = 2, kRbgsPair = 3, kRbgsResident = 4, kRbgsTile = 5, kRbgsBlock = 6 };
 enum { kScheduleAuto = 0, kScheduleLinear = 1, kScheduleChunk = 2 };
 struct Options {
-	std::atomic<int> rbgs{kRbgsAuto};          // "rbgs": auto | color | wave | pair | resident | tile
+	std::atomic<int> rbgs{kRbgsAuto};          // "rbgs": auto | color | wave | pair | resident | tile | block
 	std::atomic<int> advect_generic{0};        // "advect": auto | generic (64-bit addressed kernels)
 	std::atomic<int> stencil_block{0};         // "stencil": auto | block (512-thread divergence / gradient)
 	std::atomic<int> schedule{kScheduleAuto};  // "schedule": auto | linear | chunk (read when launch tables are built)
@@ -43,7 +43,9 @@ struct Options {
 	std::atomic<int> dist_chain{1};            // "dist_chain": with dist_mirror, EVERY kernel of the substep of such a rank is one launch that delivers its own halo (read when the ranks connect)
 	std::atomic<int> dist_spread{1};           // "dist_spread": the owned launch range of a sweeps_per_exchange = 1 rank deals its boundary leaves out to all XCDs (read at hns_dist_create)
 	std::atomic<int> sor_lds_pad{0};           // "sor_lds_pad": extra dynamic LDS bytes per wave of the pair kernel (an occupancy experiment: fewer waves in flight per XCD)
-	std::atomic<int> sor_block{0};             // "sor_block": 0 = auto, N = leaf pairs per workgroup of the blocked SOR kernel
+	std::atomic<int> sor_block_lb{0};          // "sor_block_lb": temporally blocked SOR (hns_sorblock.hip), block edge in leaves: 0 = by size, 1, 2
+	std::atomic<int> sor_block_k{0};           // "sor_block_k": ... iterations per launch: 0 = by shape, 2, 4 (4: one-leaf blocks only)
+	std::atomic<int> sor_block_seg{0};         // "sor_block_seg": ... blocks per XCD segment of its launch order (0: one chunk per XCD; read when the block table is built)
 };
 Options& options();
 
@@ -147,6 +149,13 @@ struct hns_grid {
 	void* d_tile_mem = nullptr;
 	uint64_t n_tile_groups = 0, n_tile_rest = 0;
 	bool tiles_built = false;  // d_tile_* / d_wave_of_leaf are filled on first use (hns_grid_build_tiles)
+	// temporally blocked SOR kernel (hns_sorblock.hip): records of the 16^3-voxel blocks in launch order (64 leaves under each tile),
+	// built on first use into an arena allocation of their own
+	void* d_sb_tab = nullptr;
+	size_t sb_bytes = 0;
+	uint64_t n_sb = 0;
+	bool sb_built = false;
+	int sb_seg = 0;
 	// resident SOR kernel (whole pressure loop in one launch): wave record of every leaf, one progress flag per wave record, and
 	// a host-visible word a wave raises when it gives up waiting (hns_pressure.hip: k_rbgs_resident)
 	void* d_wave_of_leaf = nullptr;
@@ -191,4 +200,8 @@ int hns_grid_upload(hns_grid* g);           // device build of every table from 
 void hns_grid_free_device(hns_grid* g);
 int hns_grid_upload_schedule(hns_grid* g);  // launch-order tables for the current n_active
 int hns_grid_build_tiles(hns_grid* g);      // tile groups of the blocked SOR kernel for the current wave records
+// implemented in hns_sorblock.hip: the temporally blocked SOR form (k iterations per launch)
+int hns_grid_build_blocks(hns_grid* g);     // records of the 16^3-voxel blocks
+int hns_rbgs_block_shape(hns_grid* g, int* k_max);  // block edge in leaves this grid is swept with (0: not by this form) and the iterations per launch
+int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const float* div, const float* src, float* dst, float dx2, float omega, void* stream);
 int hns_grid_host_tables(const hns_grid* g);  // make topo.nbr27 / topo.hash valid on the host

@@ -17,6 +17,7 @@
 //     traffic instead of the >=16 B of two in-place launches.
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 
 #include "hns_device.hpp"
 #include "hns_flags.hpp"
@@ -1154,6 +1155,12 @@ static int rbgs_form(hns_grid* g, int opt) {
 	return kRbgsPair;
 }
 
+// Grids the temporally blocked form sweeps by default (option "rbgs" = auto)
+static bool rbgs_auto_block(const hns_grid* g) {
+	(void)g;
+	return false;
+}
+
 // one full (red, black) iteration src -> dst. src_is_zero (pair form only): the caller vouches that src is 0 on every
 // leaf (first iteration of a solve) and the kernel skips reading it.
 static int launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* div, const float* src, float* dst, float dx2, float omega, int form,
@@ -1244,6 +1251,31 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 					                   dx2_of(dx), omega, iterations, (unsigned*)g->d_flags, (unsigned*)g->d_flags + g->n_pairs, g->h_status);
 				return launch_status("hns_dev_rbgs_iterate");
 			}
+		}
+	}
+	// Temporally blocked form (hns_sorblock.hip): k iterations per launch, p read and written once per launch. An odd iteration
+	// left over goes through the one-iteration form below.
+	{
+		const int opt = options().rbgs.load();
+		int k_max = 0;
+		const int lb = (iterations >= 2 && !options().graph.load() && (opt == kRbgsBlock || (opt == kRbgsAuto && rbgs_auto_block(g)))) ? hns_rbgs_block_shape(g, &k_max) : 0;
+		if (lb) {
+			float* src = p_a;
+			float* dst = p_b;
+			int left = iterations, launches = 0;
+			bool zero = from_zero;
+			while (left >= 2) {
+				const int k = (k_max >= 4 && left >= 4) ? 4 : 2;
+				if (int rc = hns_rbgs_block_launch(g, lb, k, zero, div, src, dst, dx2, omega, stream)) return rc;
+				std::swap(src, dst);
+				left -= k, ++launches, zero = false;
+			}
+			if (left) {
+				if (int rc = launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, rbgs_form(g, kRbgsAuto), (hipStream_t)stream)) return rc;
+				++launches;
+			}
+			if (result_in_b) *result_in_b = launches & 1;
+			return launch_status("hns_dev_rbgs_iterate");
 		}
 	}
 	const int form = rbgs_form(g, options().rbgs.load());

@@ -1,0 +1,424 @@
+// hns_sorblock.hip -- red-black SOR, temporally blocked: K whole (red, black) iterations per launch (gfx950 / CDNA4).
+//
+// Reference: redBlackGaussSeidelUpdate(_opt), src/Cuda/Kernel.cu:521-623, driven 2 launches per iteration by
+// src/Cuda/HNanoSolver.cu:256-272 / src/Cuda/PressureProjection.cu:51-60. The arithmetic per voxel is exactly
+// Kernel.cu:621-622 (same association, -ffp-contract=off), and every update reads exactly the values the reference's
+// launch sequence would have produced, so the result is bit-identical to k_rbgs_color (the two-launch form).
+//
+// Why: the one-launch-per-iteration kernels (hns_pressure.hip) move the compulsory 12 B/voxel/iteration, which bounds
+// them at the fabric rate on large grids (256^3: 38 us per iteration), and pay one kernel boundary plus one wave's load
+// latency per iteration on small ones (128^3: 8 us per iteration for 1.5 us worth of traffic). A colour sweep moves
+// information one voxel, so K iterations of a block of voxels depend on the block plus a halo of H = 2K voxels only:
+// a workgroup loads that tile ONCE, runs all 2K colour sweeps in LDS / registers, and stores the block -- p is read and
+// written once per K iterations, div is read once, there is one kernel boundary per K iterations.
+//
+// Shape: a block is LB^3 leaves (8*LB voxels on a side), the tile T = 8*LB + 2H voxels on a side. One THREAD per z-row
+// of the tile (T*T rows, the waves of a workgroup sorted by the parity of x+y); a thread keeps its row of p and of div*dx^2 in registers for the whole launch, split by
+// colour: R[] = its red voxels, B[] = its black ones (which z they are depends on the parity of x+y). The four lateral
+// neighbours of a voxel have the other colour, at the same index of their rows' arrays: a sweep of one colour reads the
+// four neighbouring rows' OTHER-colour arrays from LDS (ds_read_b128, 48-byte row stride: conflict-free for consecutive
+// rows), takes the z neighbours from its own registers, and writes its updated array back for the next sweep. One
+// workgroup barrier per sweep. After sweep s the values within s voxels of the tile's rim are stale (they lacked a
+// neighbour); after 2K sweeps exactly the halo is, and the block inside it is what the reference computes.
+// Voxels of absent leaves load as 0 (hardware bounds check of a buffer descriptor), are never updated, and their stores
+// are dropped by the same check: "outside the domain p = 0" (Stencils.hpp:83) without a branch.
+#include "hns_device.hpp"
+
+namespace hns {
+
+typedef float sb4f __attribute__((ext_vector_type(4)));
+typedef int sb4i __attribute__((ext_vector_type(4)));
+__device__ sb4f sb_load4(sb4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ void sb_store4(sb4f data, sb4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+
+__device__ __forceinline__ sb4i sb_rsrc(const float* p, unsigned bytes) {
+	const unsigned long long a = (unsigned long long)p;
+	sb4i r;
+	r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+	r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));  // stride 0: raw buffer
+	r.z = __builtin_amdgcn_readfirstlane((int)bytes);                            // bytes covered: offsets at or past it read 0 / are not stored
+	r.w = 0x00020000;
+	return r;
+}
+
+template <int LB, int K>
+struct SbGeo {
+	static constexpr int H = 2 * K;              // halo depth, voxels
+	static constexpr int T = 8 * LB + 2 * H;     // tile edge, voxels
+	static constexpr int C = LB + 2;             // leaf cells per axis under the tile
+	static constexpr int HALF = T / 2;           // voxels of one colour in a row = rows of one parity per x
+	static constexpr int ROWS = T * T / 2;       // rows of one parity (LDS row numbers: x * HALF + (y >> 1))
+	static constexpr int TC = T - 2;             // rows per axis that are ever updated (the rim rows are only read)
+	static constexpr int HC = TC / 2;            // ... of one parity per x
+	static constexpr int CROWS = TC * HC;        // ... of one parity: one thread each
+	static constexpr int RIM = 2 * TC;           // rim rows of one parity (without the tile's four corner rows, which nothing reads)
+	static constexpr int SEC = (CROWS + 63) / 64 * 64;  // threads of one parity section (whole waves)
+	static constexpr int NT = 2 * SEC;           // threads
+	static constexpr int NQ = (HALF + 3) / 4;    // 16-byte pieces of a colour array
+	static constexpr int HS4 = 3;                // LDS stride of a colour array in float4 (48 bytes)
+	static constexpr int NCH = T / 4;            // 16-byte pieces of a row in memory
+	static constexpr int REC = LB == 1 ? 28 : 64;  // ints per block record
+	static_assert(H % 4 == 0 && H <= 8, "rows must start on a 16-byte piece and stay within the neighbouring leaf");
+	static_assert(NQ <= HS4 && NT <= 1024 && RIM <= CROWS, "tile too large");
+};
+
+constexpr float kInv6 = 0.166666667f;  // Kernel.cu:609
+
+#ifdef HNS_SB_TRACE  // timing experiments only (profiles/micro/sb_trace.py): s_memtime stamps of the first thread of the first 64 workgroups
+__device__ unsigned long long g_sb_trace[64 * 16];
+#define SB_STAMP(n)                                                                              \
+	do {                                                                                         \
+		if (blockIdx.x < 64 && (threadIdx.x == 0)) g_sb_trace[blockIdx.x * 16 + (n)] = __builtin_readcyclecounter(); \
+	} while (0)
+#else
+#define SB_STAMP(n) \
+	do {            \
+	} while (0)
+#endif
+
+// a thread's z-row for the length of the launch, split by colour (static indexing only: the arrays live in registers)
+template <int HALF, int C>
+struct SbRow {
+	float R[HALF], B[HALF];    // p of the red / black voxels of the row
+	float dR[HALF], dB[HALF];  // div * dx^2 of the same voxels
+	unsigned ok[C];            // per leaf cell along z: all ones if the leaf exists, else 0
+};
+
+// LDS: [parity of x+y][colour][row][HS4 float4]. Rows of one parity are numbered x * HALF + (y >> 1): the lanes of a wave hold
+// consecutive rows of ONE parity, so which z are red is the same for the whole wave (PAR is a template parameter: no
+// per-lane selects anywhere) and ds_read_b128 at the 48-byte row stride is conflict-free.
+template <int LB, int K>
+struct SbLds {
+	float4 a[2][2][SbGeo<LB, K>::ROWS * SbGeo<LB, K>::HS4];
+};
+
+// One colour sweep S (1-based; odd = red = colour 0, Kernel.cu:601) of the whole tile, for the rows with parity PAR of x+y.
+// i = LDS number of the row among the rows of its parity, x * HALF + (y >> 1); b = y & 1.
+template <int LB, int K, int S, bool PAR, bool MASKED, class Row>
+__device__ __forceinline__ void sb_sweep(Row& r, SbLds<LB, K>& L, const int i, const int b, const int dist, const float omega) {
+	using G = SbGeo<LB, K>;
+	constexpr int H = G::H, HALF = G::HALF, HS4 = G::HS4;
+	constexpr bool red = (S & 1) != 0;
+	float(&X)[HALF] = red ? r.R : r.B;          // the colour being updated
+	const float(&Y)[HALF] = red ? r.B : r.R;    // its neighbours' colour
+	const float(&dX)[HALF] = red ? r.dR : r.dB;
+	const float4* LY = L.a[PAR ? 0 : 1][red ? 1 : 0];  // the lateral neighbours are rows of the other parity
+	float4* LX = L.a[PAR ? 1 : 0][red ? 0 : 1];
+	// z neighbours of X[j] in the own row: red voxel j of a row with even x+y sits at z = 2j (between black j-1 and j), with odd
+	// x+y at z = 2j+1 (between black j and j+1); black voxels the other way round
+	constexpr bool up = red ? PAR : !PAR;
+	// voxels further than S from the rim along z (a superset by one: the extra candidate is stale either way)
+	// (in whole 16-byte pieces only: partial pieces make the compiler split the LDS accesses into narrower, conflicting ones)
+	constexpr int qlo = (S / 2) / 4, qhi = (HALF - S / 2 + 3) / 4;
+	constexpr int jlo = 4 * qlo, jhi = 4 * qhi < HALF ? 4 * qhi : HALF;
+	if (dist >= S) {
+		// rows (x+1, y), (x-1, y): same number +- HALF; (x, y+1): number + b; (x, y-1): number + b - 1
+		const float4* pxp = LY + (i + HALF) * HS4;
+		const float4* pxm = LY + (i - HALF) * HS4;
+		const float4* pyp = LY + (i + b) * HS4;
+		const float4* pym = LY + (i + b - 1) * HS4;
+#pragma unroll
+		for (int q = qlo; q < qhi; ++q) {
+			const float4 xp4 = pxp[q], xm4 = pxm[q], yp4 = pyp[q], ym4 = pym[q];
+			const float xp[4] = {xp4.x, xp4.y, xp4.z, xp4.w}, xm[4] = {xm4.x, xm4.y, xm4.z, xm4.w};
+			const float yp[4] = {yp4.x, yp4.y, yp4.z, yp4.w}, ym[4] = {ym4.x, ym4.y, ym4.z, ym4.w};
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				const int j = 4 * q + e;
+				if (j < jlo || j >= jhi) continue;
+				const float below = j > 0 ? Y[j > 0 ? j - 1 : 0] : 0.0f, above = j + 1 < HALF ? Y[j + 1 < HALF ? j + 1 : 0] : 0.0f;
+				const float zm = up ? Y[j] : below, zp = up ? above : Y[j];
+				const float pGS = ((xp[e] + xm[e] + yp[e] + ym[e] + zp + zm) - dX[j]) * kInv6;  // Kernel.cu:621 (dX = div * dx^2)
+				const float cand = X[j] + omega * (pGS - X[j]);                                   // Kernel.cu:622
+				const int cz = (2 * j - H + 8) >> 3;  // leaf cell of this voxel along z: the same for both parities
+				// a voxel of an absent leaf stays +0 (as a bit mask, not a select: the compiler turns selects here into a branch per voxel)
+				X[j] = MASKED ? __uint_as_float(__float_as_uint(cand) & r.ok[cz]) : cand;
+			}
+			// (one 16-byte piece of the four lateral rows at a time: hoisting all of a sweep's LDS reads costs 32 more registers,
+			// and at 96 the second workgroup no longer fits the CU)
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		if (S < 2 * K) {
+#pragma unroll
+			for (int q = qlo; q < qhi; ++q) {
+				const int j = 4 * q;
+				LX[i * HS4 + q] = make_float4(X[j], j + 1 < HALF ? X[j + 1 < HALF ? j + 1 : 0] : 0.0f, j + 2 < HALF ? X[j + 2 < HALF ? j + 2 : 0] : 0.0f,
+				                              j + 3 < HALF ? X[j + 3 < HALF ? j + 3 : 0] : 0.0f);
+			}
+		}
+	}
+	if (S < 2 * K) __syncthreads();
+	SB_STAMP(4 + S);
+}
+
+template <int LB, int K, int S, bool PAR, bool MASKED>
+struct SbSweeps {
+	template <class Row>
+	static __device__ __forceinline__ void run(Row& r, SbLds<LB, K>& L, const int i, const int b, const int dist, const float omega) {
+		sb_sweep<LB, K, S, PAR, MASKED>(r, L, i, b, dist, omega);
+		if constexpr (S < 2 * K) SbSweeps<LB, K, S + 1, PAR, MASKED>::run(r, L, i, b, dist, omega);
+	}
+};
+
+// everything one thread does, for a row with parity PAR of x+y (wave-uniform)
+template <int LB, int K, bool ZERO, bool PAR>
+__device__ __forceinline__ void sb_body(SbLds<LB, K>& L, const int t, const int* __restrict__ recs, const float* __restrict__ div, const float* __restrict__ p_in,
+                                        float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega) {
+	using G = SbGeo<LB, K>;
+	constexpr int H = G::H, T = G::T, C = G::C, HALF = G::HALF, NQ = G::NQ, NCH = G::NCH, HS4 = G::HS4;
+	SB_STAMP(0);
+	// thread t of the section: the t-th row of this parity among the rows inside the rim, x = 1.., y = 1..
+	const bool valid = t < G::CROWS;  // (the last wave of a section has lanes without a row)
+	const int xq = valid ? t / G::HC : 0;
+	const int x = 1 + xq, y = valid ? 1 + 2 * (t - xq * G::HC) + ((x + 1 + (PAR ? 1 : 0)) & 1) : 1;
+	const int b = y & 1;
+	const int i = x * HALF + (y >> 1);
+	const int dist = valid ? min(min(x, T - 1 - x), min(y, T - 1 - y)) : -1;  // rows at distance >= s from the rim take part in sweep s
+	const int cx = (x - H + 8) >> 3, cy = (y - H + 8) >> 3;
+	const unsigned row_bytes = (unsigned)(((((x - H) & 7) << 3) | ((y - H) & 7)) * 32);  // the row inside its leaf
+	const int* __restrict__ rec = recs + (size_t)blockIdx.x * G::REC + (LB == 1 ? 1 : 0) + (cx * C + cy) * C;
+	unsigned base[C];  // byte offset of this row in the leaf of each cell along z; an absent leaf (-1) lands beyond the field
+	SbRow<HALF, C> r;
+#pragma unroll
+	for (int cz = 0; cz < C; ++cz) {
+		const int id = valid ? rec[cz] : -1;
+		r.ok[cz] = id >= 0 ? 0xFFFFFFFFu : 0u;
+		base[cz] = (unsigned)id * 2048u + row_bytes;
+	}
+	SB_STAMP(1);
+	const sb4i rp = sb_rsrc(p_in, field_bytes), rd = sb_rsrc(div, field_bytes), ro = sb_rsrc(p_out, field_bytes);
+	sb4f pc[NCH], dc[NCH];
+#pragma unroll
+	for (int j = 0; j < NCH; ++j) {
+		const int cz = (4 * j - H + 8) >> 3, zl = (4 * j - H) & 7;
+		const unsigned off = base[cz] + (unsigned)(zl * 4);
+		dc[j] = sb_load4(rd, (int)off, 0, 0);
+		if (ZERO) pc[j] = sb4f{0.0f, 0.0f, 0.0f, 0.0f};
+		else pc[j] = sb_load4(rp, (int)off, 0, 0);
+	}
+	// Rim duty of the first RIM threads of the section: one rim row of this parity each -- p only, straight into LDS (nobody
+	// updates a rim row). Side 0: x = 0, 1: x = T-1, 2: y = 0, 3: y = T-1; the m-th row of the right parity along the side.
+	if (t < G::RIM) {
+		const int side = t / G::HC, m = t - side * G::HC;
+		const int along = 2 * m + (((side & 1) != 0) == PAR ? 2 : 1);  // sides 0, 2: along + 0 has parity PAR; sides 1, 3: along + T-1 (odd)
+		const int rx = side == 0 ? 0 : (side == 1 ? T - 1 : along), ry = side == 2 ? 0 : (side == 3 ? T - 1 : along);
+		const int rcx = (rx - H + 8) >> 3, rcy = (ry - H + 8) >> 3;
+		const unsigned rrow = (unsigned)(((((rx - H) & 7) << 3) | ((ry - H) & 7)) * 32);
+		const int* __restrict__ rrec = recs + (size_t)blockIdx.x * G::REC + (LB == 1 ? 1 : 0) + (rcx * C + rcy) * C;
+		unsigned rbase[C];
+#pragma unroll
+		for (int cz = 0; cz < C; ++cz) rbase[cz] = (unsigned)rrec[cz] * 2048u + rrow;
+		sb4f rc[NCH];
+#pragma unroll
+		for (int j = 0; j < NCH; ++j) rc[j] = ZERO ? sb4f{0.0f, 0.0f, 0.0f, 0.0f} : sb_load4(rp, (int)(rbase[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
+		float4* LR = L.a[PAR ? 1 : 0][0] + (rx * HALF + (ry >> 1)) * HS4;
+		float4* LK = L.a[PAR ? 1 : 0][1] + (rx * HALF + (ry >> 1)) * HS4;
+		float rr[HALF + 4], rb[HALF + 4];
+#pragma unroll
+		for (int j = 0; j < NCH; ++j) {
+			rr[2 * j] = PAR ? rc[j].y : rc[j].x, rb[2 * j] = PAR ? rc[j].x : rc[j].y;
+			rr[2 * j + 1] = PAR ? rc[j].w : rc[j].z, rb[2 * j + 1] = PAR ? rc[j].z : rc[j].w;
+		}
+#pragma unroll
+		for (int q = 0; q < NQ; ++q) {
+			LR[q] = make_float4(rr[4 * q], rr[4 * q + 1], 4 * q + 2 < HALF ? rr[4 * q + 2] : 0.0f, 4 * q + 3 < HALF ? rr[4 * q + 3] : 0.0f);
+			LK[q] = make_float4(rb[4 * q], rb[4 * q + 1], 4 * q + 2 < HALF ? rb[4 * q + 2] : 0.0f, 4 * q + 3 < HALF ? rb[4 * q + 3] : 0.0f);
+		}
+	}
+	SB_STAMP(2);
+	// split by colour: even z of a row with even x+y are red (colour = (x + y + z) & 1, Kernel.cu:599-601)
+#pragma unroll
+	for (int j = 0; j < NCH; ++j) {
+		r.R[2 * j] = PAR ? pc[j].y : pc[j].x, r.B[2 * j] = PAR ? pc[j].x : pc[j].y;
+		r.R[2 * j + 1] = PAR ? pc[j].w : pc[j].z, r.B[2 * j + 1] = PAR ? pc[j].z : pc[j].w;
+		const float d0 = dc[j].x * dx2, d1 = dc[j].y * dx2, d2 = dc[j].z * dx2, d3 = dc[j].w * dx2;  // Kernel.cu:621: divVal * dx2
+		r.dR[2 * j] = PAR ? d1 : d0, r.dB[2 * j] = PAR ? d0 : d1;
+		r.dR[2 * j + 1] = PAR ? d3 : d2, r.dB[2 * j + 1] = PAR ? d2 : d3;
+	}
+	SB_STAMP(3);
+	if (valid) {
+		float4* LR = L.a[PAR ? 1 : 0][0] + i * HS4;
+		float4* LK = L.a[PAR ? 1 : 0][1] + i * HS4;
+#pragma unroll
+		for (int q = 0; q < NQ; ++q) {
+			const int j = 4 * q;
+			LR[q] = make_float4(r.R[j], r.R[j + 1], j + 2 < HALF ? r.R[j + 2 < HALF ? j + 2 : 0] : 0.0f, j + 3 < HALF ? r.R[j + 3 < HALF ? j + 3 : 0] : 0.0f);
+			LK[q] = make_float4(r.B[j], r.B[j + 1], j + 2 < HALF ? r.B[j + 2 < HALF ? j + 2 : 0] : 0.0f, j + 3 < HALF ? r.B[j + 3 < HALF ? j + 3 : 0] : 0.0f);
+		}
+	}
+	// (the barrier behind the staging; and: is every leaf under the tile present? Then no voxel needs masking)
+	bool mine = true;
+#pragma unroll
+	for (int cz = 0; cz < C; ++cz) mine = mine && (r.ok[cz] != 0u || !valid);
+	const bool all_present = __syncthreads_and(mine) != 0;
+	SB_STAMP(4);
+	if (all_present)
+		SbSweeps<LB, K, 1, PAR, false>::run(r, L, i, b, dist, omega);
+	else
+		SbSweeps<LB, K, 1, PAR, true>::run(r, L, i, b, dist, omega);
+	SB_STAMP(5 + 2 * K);
+	if (dist >= H) {  // the rows of the block itself
+#pragma unroll
+		for (int j = H / 4; j < NCH - H / 4; ++j) {
+			const int cz = (4 * j - H + 8) >> 3, zl = (4 * j - H) & 7;
+			sb4f v;
+			v.x = PAR ? r.B[2 * j] : r.R[2 * j], v.y = PAR ? r.R[2 * j] : r.B[2 * j];
+			v.z = PAR ? r.B[2 * j + 1] : r.R[2 * j + 1], v.w = PAR ? r.R[2 * j + 1] : r.B[2 * j + 1];
+			sb_store4(v, ro, (int)(base[cz] + (unsigned)(zl * 4)), 0, 0);
+		}
+	}
+#ifdef HNS_SB_TRACE
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+	SB_STAMP(6 + 2 * K);
+}
+
+// recs: one record per workgroup, in launch order. LB = 1: {leaf, nbr27[27]} (the grid's d_blk); LB = 2: the 4 x 4 x 4 leaves
+// under the tile, cell (cx, cy, cz) at (cx*4 + cy)*4 + cz, -1 = absent. ZERO: p_in is known to be 0 (first launch of a solve,
+// HNanoSolver.cu:113) and is not read. The first half of the workgroup's waves takes the rows with even x+y, the second half
+// those with odd x+y; both halves meet at the same number of barriers.
+template <int LB, int K, bool ZERO>
+__global__ __launch_bounds__((SbGeo<LB, K>::NT), (SbGeo<LB, K>::NT >= 512 ? 4 : 1)) void k_rbgs_block(const int* __restrict__ recs, const float* __restrict__ div, const float* __restrict__ p_in,
+                                                                float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega) {
+	using G = SbGeo<LB, K>;
+	__shared__ SbLds<LB, K> L;
+	const int t = threadIdx.x;
+	if (__builtin_amdgcn_readfirstlane(t >= G::SEC))
+		sb_body<LB, K, ZERO, true>(L, t - G::SEC, recs, div, p_in, p_out, field_bytes, dx2, omega);
+	else
+		sb_body<LB, K, ZERO, false>(L, t, recs, div, p_in, p_out, field_bytes, dx2, omega);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// block tables for LB = 2: aligned 16^3-voxel blocks (2 x 2 x 2 leaves, any of them may be absent)
+// ---------------------------------------------------------------------------------------------------------------
+
+// flag[l] = 1 if leaf l is the first existing leaf (corner order x, y, z) of its block
+__global__ __launch_bounds__(256) void k_sb_leader(GridDev g, int* __restrict__ flag) {
+	const int l = blockIdx.x * 256 + threadIdx.x;
+	if (l >= g.n_leaves) return;
+	const int4 o = g.origins[l];
+	const int bx = o.x & ~15, by = o.y & ~15, bz = o.z & ~15;
+	const int me = (((o.x >> 3) & 1) << 2) | (((o.y >> 3) & 1) << 1) | ((o.z >> 3) & 1);
+	int lead = 1;
+	for (int c = 0; c < me; ++c)
+		if (d_find_leaf(g, bx + 8 * (c >> 2), by + 8 * ((c >> 1) & 1), bz + 8 * (c & 1)) >= 0) lead = 0;
+	flag[l] = lead;
+}
+
+// exclusive scan of flag[0..n) by ONE workgroup; leaders[pos] = l for flagged l; *total = number of flags
+__global__ __launch_bounds__(1024) void k_sb_compact(const int* __restrict__ flag, int n, int* __restrict__ leaders, int* __restrict__ total) {
+	__shared__ int s_part[1024];
+	const int per = (n + 1023) / 1024;
+	const int lo = threadIdx.x * per, hi = min(n, lo + per);
+	int sum = 0;
+	for (int i = lo; i < hi; ++i) sum += flag[i];
+	s_part[threadIdx.x] = sum;
+	__syncthreads();
+	for (int d = 1; d < 1024; d <<= 1) {
+		const int v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+		__syncthreads();
+		s_part[threadIdx.x] += v;
+		__syncthreads();
+	}
+	int run = s_part[threadIdx.x] - sum;
+	for (int i = lo; i < hi; ++i)
+		if (flag[i]) leaders[run++] = i;
+	if (threadIdx.x == 1023) *total = s_part[1023];
+}
+
+// record of launch position b: the 64 leaves under the tile of block order[b]
+__global__ __launch_bounds__(256) void k_sb_table(GridDev g, const int* __restrict__ leaders, int n_blocks, int seg, int* __restrict__ tab) {
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= (int64_t)n_blocks * 64) return;
+	const int b = (int)(i >> 6), c = (int)(i & 63);
+	const int4 o = g.origins[leaders[sched_leaf(b, n_blocks, seg)]];
+	const int64_t x = (int64_t)(o.x & ~15) + 8 * ((c >> 4) - 1), y = (int64_t)(o.y & ~15) + 8 * (((c >> 2) & 3) - 1), z = (int64_t)(o.z & ~15) + 8 * ((c & 3) - 1);
+	int leaf = -1;
+	if (x >= INT32_MIN && x <= INT32_MAX && y >= INT32_MIN && y <= INT32_MAX && z >= INT32_MIN && z <= INT32_MAX) leaf = d_find_leaf(g, (int)x, (int)y, (int)z);
+	tab[i] = leaf;
+}
+
+}  // namespace hns
+
+using namespace hns;
+
+// Block records of the 16^3 form for the whole grid, built on first use (most small grids never ask). The table comes
+// out of the arena pool and goes back with the grid.
+int hns_grid_build_blocks(hns_grid* g) {
+	std::lock_guard<std::mutex> lock(g->graph_mutex);
+	const int seg = options().sor_block_seg.load();
+	if (g->sb_built && g->sb_seg == seg) return HNS_OK;
+	if (g->d_sb_tab) hns_arena_put(g->d_sb_tab, g->sb_bytes, g->device);
+	g->d_sb_tab = nullptr;
+	g->sb_bytes = 0;
+	g->n_sb = 0;
+	g->sb_built = true;
+	g->sb_seg = seg;
+	const int n = (int)g->topo.n_leaves;
+	if (n == 0 || !g->d_tile_mem) return HNS_OK;
+	int* flag = (int*)g->d_tile_mem;  // scratch shared with hns_grid_build_tiles (same lock): flag[n] | leaders[n] | total
+	int* leaders = flag + n;
+	int* total = leaders + n;
+	GridDev gd = g->dev();
+	k_sb_leader<<<(n + 255) / 256, 256, 0, 0>>>(gd, flag);
+	k_sb_compact<<<1, 1024, 0, 0>>>(flag, n, leaders, total);
+	int nb = 0;
+	HNS_HIP(hipMemcpy(&nb, total, sizeof(int), hipMemcpyDeviceToHost));
+	if (nb <= 0) return fail(HNS_ERR_RUNTIME, "hns_grid_build_blocks: no block leader found");
+	if (int rc = hns_arena_get(sizeof(int) * 64 * (size_t)nb, g->device, &g->d_sb_tab, &g->sb_bytes)) return rc;
+	k_sb_table<<<(unsigned)(((int64_t)nb * 64 + 255) / 256), 256, 0, 0>>>(gd, leaders, nb, seg, (int*)g->d_sb_tab);
+	HNS_HIP(hipDeviceSynchronize());
+	g->n_sb = (uint64_t)nb;
+	return HNS_OK;
+}
+
+// Can this grid be swept by the blocked form, and with which block edge (in leaves)? 0 = no.
+int hns_rbgs_block_shape(hns_grid* g, int* k_max) {
+	*k_max = 0;
+	// whole grids only (a multi-GPU rank sweeps launch ranges), fields addressable with 32-bit byte offsets
+	if (g->first_active != 0 || g->n_active != (uint64_t)g->topo.n_leaves || g->n_active == 0 || g->topo.n_leaves > 2000000) return 0;
+	int lb = options().sor_block_lb.load(), k = options().sor_block_k.load();
+	if (lb == 0) lb = g->n_active <= 1024 ? 1 : 2;
+	if (lb != 1 && lb != 2) return 0;
+	if (lb == 1 && !g->d_blk) return 0;
+	if (lb == 2 && (hns_grid_build_blocks(g) != HNS_OK || g->n_sb == 0)) return 0;
+	if (k == 0) k = lb == 1 ? 4 : 2;
+	if (k != 2 && !(k == 4 && lb == 1)) k = 2;
+	*k_max = k;
+	return lb;
+}
+
+// one launch: k iterations src -> dst
+int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const float* div, const float* src, float* dst, float dx2, float omega, void* stream) {
+	hipStream_t st = (hipStream_t)stream;
+	const unsigned bytes = (unsigned)((size_t)g->topo.n_leaves * 2048u);
+#define SB_LAUNCH(LB_, K_, recs, nblk)                                                                                                            \
+	do {                                                                                                                                           \
+		if (src_is_zero)                                                                                                                           \
+			hipLaunchKernelGGL((k_rbgs_block<LB_, K_, true>), dim3((unsigned)(nblk)), dim3(SbGeo<LB_, K_>::NT), 0, st, (const int*)(recs), div, src, dst, bytes, dx2, omega); \
+		else                                                                                                                                       \
+			hipLaunchKernelGGL((k_rbgs_block<LB_, K_, false>), dim3((unsigned)(nblk)), dim3(SbGeo<LB_, K_>::NT), 0, st, (const int*)(recs), div, src, dst, bytes, dx2, omega); \
+	} while (0)
+	if (lb == 1 && k == 2) SB_LAUNCH(1, 2, g->d_blk, g->n_active);
+	else if (lb == 1 && k == 4) SB_LAUNCH(1, 4, g->d_blk, g->n_active);
+	else if (lb == 2 && k == 2) SB_LAUNCH(2, 2, g->d_sb_tab, g->n_sb);
+	else return fail(HNS_ERR_INVALID_ARGUMENT, "hns_rbgs_block_launch: unsupported block shape");
+#undef SB_LAUNCH
+	return HNS_OK;
+}
+
+#ifdef HNS_SB_TRACE
+extern "C" int hns_sb_occupancy(int which) {
+	int n = -1;
+	if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rbgs_block<2, 2, false>, SbGeo<2, 2>::NT, 0);
+	if (which == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rbgs_block<1, 2, false>, SbGeo<1, 2>::NT, 0);
+	if (which == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rbgs_block<1, 4, false>, SbGeo<1, 4>::NT, 0);
+	return n;
+}
+extern "C" int hns_sb_trace_read(unsigned long long* out) {
+	HNS_HIP(hipDeviceSynchronize());
+	HNS_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(hns::g_sb_trace), sizeof(unsigned long long) * 64 * 16));
+	return HNS_OK;
+}
+#endif

@@ -132,7 +132,7 @@ struct OptionDesc {
 	std::atomic<int> Options::*field;
 	const char* const* words;  // value words, index = stored value; nullptr: a non-negative integer
 };
-const char* const kWordsRbgs[] = {"auto", "color", "wave", "pair", "resident", "tile", nullptr};
+const char* const kWordsRbgs[] = {"auto", "color", "wave", "pair", "resident", "tile", "block", nullptr};
 const char* const kWordsAdvect[] = {"auto", "generic", nullptr};
 const char* const kWordsStencil[] = {"auto", "block", nullptr};
 const char* const kWordsSchedule[] = {"auto", "linear", "chunk", nullptr};
@@ -148,7 +148,9 @@ const OptionDesc kOptions[] = {
     {"graph", &Options::graph, kWordsBool},
     {"cook_cache", &Options::cook_cache, kWordsBool},
     {"cook_pipeline", &Options::cook_pipeline, kWordsBool},
-    {"sor_block", &Options::sor_block, nullptr},
+    {"sor_block_lb", &Options::sor_block_lb, nullptr},
+    {"sor_block_k", &Options::sor_block_k, nullptr},
+    {"sor_block_seg", &Options::sor_block_seg, nullptr},
     {"sor_lds_pad", &Options::sor_lds_pad, nullptr},
     {"schedule_segment", &Options::schedule_segment, nullptr},
     {"dist_wire_us", &Options::dist_wire_us, nullptr},
