@@ -64,11 +64,11 @@ struct SbGeo {
 
 constexpr float kInv6 = 0.166666667f;  // Kernel.cu:609
 
-#ifdef HNS_SB_TRACE  // timing experiments only (profiles/micro/sb_trace.py): s_memtime stamps of the first thread of the first 64 workgroups
+#ifdef HNS_SB_TRACE  // timing experiments only (profiles/micro/sb_trace.py): s_memtime stamps of the first thread of workgroups HNS_SB_TRACE .. +63
 __device__ unsigned long long g_sb_trace[64 * 16];
 #define SB_STAMP(n)                                                                              \
 	do {                                                                                         \
-		if (blockIdx.x < 64 && (threadIdx.x == 0)) g_sb_trace[blockIdx.x * 16 + (n)] = __builtin_readcyclecounter(); \
+		if (blockIdx.x >= HNS_SB_TRACE && blockIdx.x < HNS_SB_TRACE + 64 && (threadIdx.x == 0)) g_sb_trace[(blockIdx.x - HNS_SB_TRACE) * 16 + (n)] = __builtin_readcyclecounter(); \
 	} while (0)
 #else
 #define SB_STAMP(n) \
@@ -117,9 +117,14 @@ __device__ __forceinline__ void sb_sweep(Row& r, SbLds<LB, K>& L, const int i, c
 		const float4* pxm = LY + (i - HALF) * HS4;
 		const float4* pyp = LY + (i + b) * HS4;
 		const float4* pym = LY + (i + b - 1) * HS4;
+		// (software-pipelined: the four ds_read_b128 of the next 16-byte piece are in flight while this piece's candidates are
+		// computed; the scheduling barriers keep the compiler from hoisting ALL of a sweep's reads, which costs 32 more registers)
+		float4 nx[4] = {pxp[qlo], pxm[qlo], pyp[qlo], pym[qlo]};
 #pragma unroll
 		for (int q = qlo; q < qhi; ++q) {
-			const float4 xp4 = pxp[q], xm4 = pxm[q], yp4 = pyp[q], ym4 = pym[q];
+			const float4 xp4 = nx[0], xm4 = nx[1], yp4 = nx[2], ym4 = nx[3];
+			if (q + 1 < qhi) nx[0] = pxp[q + 1], nx[1] = pxm[q + 1], nx[2] = pyp[q + 1], nx[3] = pym[q + 1];
+			__builtin_amdgcn_sched_barrier(0);
 			const float xp[4] = {xp4.x, xp4.y, xp4.z, xp4.w}, xm[4] = {xm4.x, xm4.y, xm4.z, xm4.w};
 			const float yp[4] = {yp4.x, yp4.y, yp4.z, yp4.w}, ym[4] = {ym4.x, ym4.y, ym4.z, ym4.w};
 #pragma unroll
@@ -134,8 +139,6 @@ __device__ __forceinline__ void sb_sweep(Row& r, SbLds<LB, K>& L, const int i, c
 				// a voxel of an absent leaf stays +0 (as a bit mask, not a select: the compiler turns selects here into a branch per voxel)
 				X[j] = MASKED ? __uint_as_float(__float_as_uint(cand) & r.ok[cz]) : cand;
 			}
-			// (one 16-byte piece of the four lateral rows at a time: hoisting all of a sweep's LDS reads costs 32 more registers,
-			// and at 96 the second workgroup no longer fits the CU)
 			__builtin_amdgcn_sched_barrier(0);
 		}
 		if (S < 2 * K) {
@@ -379,11 +382,13 @@ int hns_rbgs_block_shape(hns_grid* g, int* k_max) {
 	// whole grids only (a multi-GPU rank sweeps launch ranges), fields addressable with 32-bit byte offsets
 	if (g->first_active != 0 || g->n_active != (uint64_t)g->topo.n_leaves || g->n_active == 0 || g->topo.n_leaves > 2000000) return 0;
 	int lb = options().sor_block_lb.load(), k = options().sor_block_k.load();
-	if (lb == 0) lb = g->n_active <= 1024 ? 1 : 2;
+	// by size (profiles/r03_sor_forms.txt): one-leaf blocks while the grid cannot fill the chip with 16^3 blocks, four iterations per
+	// launch while even those leave most of it idle
+	if (lb == 0) lb = g->n_active <= 768 ? 1 : 2;
 	if (lb != 1 && lb != 2) return 0;
 	if (lb == 1 && !g->d_blk) return 0;
 	if (lb == 2 && (hns_grid_build_blocks(g) != HNS_OK || g->n_sb == 0)) return 0;
-	if (k == 0) k = lb == 1 ? 4 : 2;
+	if (k == 0) k = (lb == 1 && g->n_active <= 300) ? 4 : 2;
 	if (k != 2 && !(k == 4 && lb == 1)) k = 2;
 	*k_max = k;
 	return lb;

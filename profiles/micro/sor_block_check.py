@@ -54,14 +54,20 @@ def check():
 
 def timing(cfgs, opts):
     for c in cfgs:
-        origins, R = fields.config_leaves(c)
+        if c.startswith("d"):  # dN: dense N^3
+            R = int(c[1:])
+            origins = fields.dense_leaves(R)
+        else:
+            origins, R = fields.config_leaves(c)
         grid = api.create_grid_from_leaves(origins, 1.0 / R)
         N = len(origins) * 512
         div = torch.randn(N, device="cuda")
         p_a = torch.zeros(N, device="cuda"); p_b = torch.zeros(N, device="cuda")
-        for form in ({"rbgs": "auto"}, {"rbgs": "block", "sor_block_lb": 1, "sor_block_k": 2}, {"rbgs": "block", "sor_block_lb": 1, "sor_block_k": 4},
+        for form in ({"rbgs": "pair"}, {"rbgs": "wave"}, {"rbgs": "block", "sor_block_lb": 1, "sor_block_k": 2}, {"rbgs": "block", "sor_block_lb": 1, "sor_block_k": 4},
                      {"rbgs": "block", "sor_block_lb": 2, "sor_block_k": 2}):
-            if form.get("sor_block_lb") == 1 and len(origins) > 40000:
+            if form.get("sor_block_lb") == 1 and len(origins) > 5000:
+                continue
+            if form["rbgs"] == "wave" and len(origins) > 20000:
                 continue
             for k, v in {**form, **opts}.items():
                 H.set_option(k, str(v))

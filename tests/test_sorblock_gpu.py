@@ -1,0 +1,93 @@
+"""Temporally blocked red-black SOR (hnanosolver_amd/csrc/hns_sorblock.hip: K iterations per launch on a block of leaves with a
+2K-voxel halo) against the oracle's restatement of redBlackGaussSeidelUpdate (reference src/Cuda/Kernel.cu:591-623, two launches
+per iteration) and against the library's own two-launch form: bit for bit, on dense, ragged and scattered leaf sets with negative
+coordinates, for even and odd iteration counts, warm-started and from zero."""
+import numpy as np
+import pytest
+import torch
+
+import hnanosolver_amd as H
+from hnanosolver_amd import api, device as D, fields
+from oracle_lib import OracleGrid
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1, 2), (1, 4), (2, 2)]  # (block edge in leaves, iterations per launch)
+
+
+def leaf_sets():
+    rng = np.random.default_rng(5)
+    o = np.unique(rng.integers(-6, 6, size=(400, 3)).astype(np.int32) * 8, axis=0)
+    scatter = np.ascontiguousarray(o[fields.nanovdb_order(o)])
+    # straddles the 128^3 lower-node and 4096^3 upper-node borders at negative coordinates
+    shifted = fields.dense_leaves(24).astype(np.int64) + np.array([-4104, -16, 120])
+    shifted = shifted.astype(np.int32)
+    shifted = np.ascontiguousarray(shifted[fields.nanovdb_order(shifted)])
+    return {"dense32": fields.dense_leaves(32), "dense40": fields.dense_leaves(40), "plume": fields.plume_leaves(16, 1.5, 0.3), "scatter": scatter,
+            "node_borders": shifted, "one_leaf": np.array([[8, -8, 0]], dtype=np.int32)}
+
+
+@pytest.fixture(autouse=True)
+def restore_options():
+    yield
+    for k in ("rbgs", "sor_block_lb", "sor_block_k"):
+        H.set_option(k, None)
+
+
+def solve(grid, div, p0, iters, **opts):
+    for k, v in opts.items():
+        H.set_option(k, str(v))
+    p_a = p0.clone()
+    p_b = torch.full_like(p0, 7.0)  # stale content of the second buffer must not matter
+    out = D.rbgs_iterate(grid, div, p_a, p_b, 0.013, 1.93, iters).clone()
+    for k in opts:
+        H.set_option(k, None)
+    return out
+
+
+@pytest.mark.parametrize("name", list(leaf_sets()))
+def test_blocked_sor_matches_two_launch_form_and_oracle(name):
+    origins = leaf_sets()[name]
+    grid = api.create_grid_from_leaves(origins, 0.013)
+    n = len(origins) * 512
+    g = torch.Generator(device="cpu").manual_seed(3)
+    div = torch.randn(n, generator=g).cuda()
+    p0 = (torch.rand(n, generator=g) * 2 - 1).cuda()
+    oracle = OracleGrid(origins)
+    for iters in (2, 3, 4, 7, 10):
+        want = solve(grid, div, p0, iters, rbgs="color")
+        if iters in (3, 4):
+            ref = oracle.rbgs_iterations(div.cpu().numpy(), 0.013, 1.93, iters, p0.cpu().numpy())
+            assert np.array_equal(want.cpu().numpy(), ref), (name, iters, "two-launch form vs oracle")
+        for lb, k in SHAPES:
+            got = solve(grid, div, p0, iters, rbgs="block", sor_block_lb=lb, sor_block_k=k)
+            assert torch.equal(want, got), (name, iters, lb, k, float((want - got).abs().max()))
+
+
+def test_default_form_by_size_is_bit_identical():
+    """whatever `rbgs = auto` picks for a grid size (one-leaf blocks, 16^3 blocks, the pair form) gives the two-launch bits"""
+    for R in (16, 48, 96):
+        origins = fields.dense_leaves(R)
+        grid = api.create_grid_from_leaves(origins, 1.0 / R)
+        n = len(origins) * 512
+        g = torch.Generator(device="cpu").manual_seed(R)
+        div = torch.randn(n, generator=g).cuda()
+        p0 = torch.zeros(n, device="cuda")
+        for iters in (5, 8):
+            assert torch.equal(solve(grid, div, p0, iters, rbgs="color"), solve(grid, div, p0, iters)), (R, iters)
+
+
+def test_blocked_sor_known_answer_harmonic_fixed_point():
+    """a discrete-harmonic p with div = 0 is a fixed point of every sweep wherever all six neighbours exist (tests/kats.py):
+    inside a dense box, away from the outside-is-zero rim, K iterations per launch must leave it untouched"""
+    R = 32
+    origins = fields.dense_leaves(R)
+    grid = api.create_grid_from_leaves(origins, 1.0 / R)
+    c = fields.leaves_to_coords(origins).astype(np.float32)
+    p = (c[:, 0] - 2 * c[:, 1] + 3 * c[:, 2]).astype(np.float32)  # linear: harmonic, small integers, sums exact
+    p0 = torch.from_numpy(p).cuda()
+    div = torch.zeros_like(p0)
+    inner = torch.from_numpy(((c >= 8) & (c < R - 8)).all(1)).cuda()
+    for lb, k in SHAPES:
+        got = solve(grid, div, p0, 4, rbgs="block", sor_block_lb=lb, sor_block_k=k)
+        assert torch.equal(got[inner], p0[inner]), (lb, k)
