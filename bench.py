@@ -14,9 +14,10 @@ e.g. plume1024 = BASELINE.json's 1024^3-extent sparse grid, split across the ran
 voxels of u / div / p / phi over RCCL where the single-GPU code has a kernel boundary that a stencil crosses, under the
 interior kernels (csrc/hns_dist.hip; hnanosolver_amd/dist.py is the host mirror). `value` = slab-substeps/s summed over ranks = N x (global substeps/s).
 
-Rank 0 prints ONE JSON line. `roofline`: dominant kernel k_rbgs_pair, algorithmic 12 B/voxel per launch (read p, read
-div, write p once each), launch time from hipEvents recorded on the launch stream around the pressure loop of every
-timed step. `roofline.kernels` carries the same figures for all five kernels of the substep (each bracketed by hipEvents
+Rank 0 prints ONE JSON line. `roofline`: the SOR kernel (`kernel` names the form the library picked for this grid size),
+algorithmic 12 B/voxel per red+black iteration (read p, read div, write p once each; a launch of the temporally blocked form
+holds several iterations and is priced per iteration all the same), time per iteration from hipEvents recorded on the launch
+stream around the pressure loop of every timed step. `roofline.kernels` carries the same figures for all five kernels of the substep (each bracketed by hipEvents
 on the launch stream, in a short pass of its own after the timed region) and `roofline.substep` the whole substep
 against 688 B/voxel. `traffic` is NOT measured by this
 run (bench.py cannot run rocprofv3 on itself): it is the PMC-derived HBM bytes per launch from the builder's committed
@@ -251,7 +252,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    p_ms, launches = pressure_time()
+    p_ms, launches = pressure_time()  # (launches: red+black iterations inside the bracketed pressure loops)
+    sor_form, sor_launches, sor_k = D.rbgs_plan(grid, args.iterations) if world == 1 else ("", args.iterations, 1)
     stages, n_sub = stage_times() if stage_times else ({}, 0)
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -274,7 +276,7 @@ def main():
                 per = ms / n_sub / (args.iterations if st == "pressure" else 1)  # ms per launch
                 alg = STAGE_BYTES[st] * n_vox_rank
                 gbs = alg / (per * 1e-3) / 1e9 if per > 0 else None
-                kernels[STAGE_KERNEL[st]] = {"stage": st, "ms_per_launch": per, "launches_per_substep": args.iterations if st == "pressure" else 1,
+                kernels[STAGE_KERNEL[st] if st != "pressure" else sor_form.split(":")[0]] = {"stage": st, "ms_per_launch": per, "launches_per_substep": args.iterations if st == "pressure" else 1,  # (pressure: per red+black iteration)
                                              "algorithmic_bytes_per_launch": alg, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS if gbs else None}
         sub_bytes = (BYTES_PER_VOXEL_SUBSTEP - 600 + 12 * args.iterations) * n_vox_rank
         sub_gbs = sub_bytes / (ms_per_step * 1e-3) / 1e9
@@ -306,7 +308,7 @@ def main():
                     + (" -- ALL RANKS SHARE ONE GPU (builder's check, not a scaling figure)" if args.share_one_gpu else "")),
             },
             "roofline": {
-                "kernel": "k_rbgs_pair (one launch = one full red+black SOR iteration over all leaves)" if world == 1 else
+                "kernel": sor_form if world == 1 else
                           "pressure loop of rank 0 INCLUDING its halo exchanges (comm-inclusive; the kernel alone is the N=1 figure)",
                 "bound": "hbm",
                 "achieved": achieved,
@@ -315,9 +317,12 @@ def main():
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
+                # per red+black ITERATION (SURVEY 8d's unit: 12 B/voxel); a launch of the blocked form holds `iterations_per_launch` of them
                 "algorithmic_bytes_per_launch": BYTES_PER_VOXEL_ITER * n_vox_rank,
                 "ms_per_launch": ms_launch,
                 "launches_timed": launches,
+                "iterations_per_kernel_launch": sor_k,
+                "kernel_launches_per_solve": sor_launches,
                 "kernels": kernels,
                 "substep": {"algorithmic_bytes": sub_bytes, "ms": ms_per_step, "achieved": sub_gbs, "frac": sub_gbs / HBM_PEAK_GBS},
             },

@@ -137,6 +137,7 @@ SIGNATURES = {
     "hns_dist_pressure_time": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_longlong)]),
     "hns_dist_synchronize": (_i, [_vp, _vp]),
     "hns_dev_time_rbgs": (_i, [_vp, _fp, _fp, _fp, _f, _f, _i, _i, C.POINTER(C.c_float), _vp]),
+    "hns_grid_rbgs_plan": (_i, [_vp, _i, C.c_char_p, C.c_uint64, _ip, _ip]),
 }
 
 _lib = None

@@ -1351,6 +1351,35 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 	return launch_status("hns_dev_rbgs_iterate");
 }
 
+int hns_grid_rbgs_plan(hns_grid* g, int iterations, char* description, uint64_t description_bytes, int* launches, int* iterations_per_launch) {
+	if (int rc = check_grid(g, "hns_grid_rbgs_plan")) return rc;
+	if (iterations < 0) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_rbgs_plan: negative iteration count");
+	const int opt = options().rbgs.load();
+	int k_max = 0;
+	const int lb = (iterations >= 2 && !options().graph.load() && (opt == kRbgsBlock || (opt == kRbgsAuto && rbgs_auto_block(g)))) ? hns_rbgs_block_shape(g, &k_max) : 0;
+	char buf[256];
+	int n = iterations, k = 1;
+	if (lb) {
+		n = 0;
+		int left = iterations;
+		while (left >= 2) left -= (k_max >= 4 && left >= 4) ? 4 : 2, ++n;
+		n += left;
+		k = k_max;
+		snprintf(buf, sizeof(buf), "k_rbgs_block<%d,%d>: %d red+black iterations per launch on %s blocks with a %d-voxel halo, p read and written once per launch", lb, k_max, k_max,
+		         lb == 1 ? "one-leaf (8^3-voxel)" : "16^3-voxel", 2 * k_max);
+	} else {
+		const int form = rbgs_form(g, opt == kRbgsBlock ? kRbgsAuto : opt);
+		const char* names[] = {"?", "k_rbgs_color: two launches per iteration, in place (the reference's decomposition)", "k_rbgs_wave: one launch = one red+black iteration, one wave per leaf",
+		                       "k_rbgs_pair: one launch = one red+black iteration, one wave per z-adjacent leaf pair", "k_rbgs_resident", "k_rbgs_tile: one launch = one red+black iteration, 2 x 2 wave records per workgroup"};
+		snprintf(buf, sizeof(buf), "%s", names[form >= 0 && form <= 5 ? form : 0]);
+		if (form == kRbgsColor) n = 2 * iterations;
+	}
+	if (description && description_bytes) snprintf(description, description_bytes, "%s", buf);
+	if (launches) *launches = n;
+	if (iterations_per_launch) *iterations_per_launch = k;
+	return HNS_OK;
+}
+
 // ---- the mirroring sweep of a multi-GPU rank (see k_rbgs_pair_mirror) ----
 int hns_rbgs_count_boundary_records(hns_grid* g, int n_boundary, unsigned* d_scratch, unsigned* out2, void* stream) {
 	if (int rc = check_grid(g, "hns_rbgs_count_boundary_records")) return rc;

@@ -73,6 +73,15 @@ def rbgs_iterate(grid: IndexGridHandle, div, p_a, p_b, dx: float, omega: float, 
     return p_b if in_b.value else p_a
 
 
+def rbgs_plan(grid: IndexGridHandle, iterations: int):
+    """(description of the SOR kernel form this grid is swept with, kernel launches for `iterations`, iterations per launch)"""
+    lib = load_library()
+    buf = C.create_string_buffer(256)
+    n, k = C.c_int(0), C.c_int(0)
+    _raise(lib.hns_grid_rbgs_plan(grid.ptr, iterations, buf, 256, C.byref(n), C.byref(k)))
+    return buf.value.decode(), n.value, k.value
+
+
 def time_rbgs(grid: IndexGridHandle, div, p_a, p_b, dx: float, omega: float, iterations: int, reps: int) -> float:
     """Mean milliseconds per fused-iteration launch, measured with hipEvents on the launch stream."""
     ms = C.c_float(0.0)

@@ -345,6 +345,11 @@ int hns_dist_synchronize(hns_dist*, void* stream); /* waits for `stream` and the
 int hns_dev_time_rbgs(hns_grid*, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int reps, float* ms_per_launch,
                       void* stream);
 
+/* Which kernel form hns_dev_rbgs_iterate / the operators' pressure loops use for `iterations` iterations on this grid under the
+ * current options, as text (e.g. "k_rbgs_block<2,2>: 2 iterations per launch on 16^3-voxel blocks"), and how many kernel launches
+ * that is. For bench / profile labels; `description` may be null. */
+int hns_grid_rbgs_plan(hns_grid*, int iterations, char* description, uint64_t description_bytes, int* launches, int* iterations_per_launch);
+
 #ifdef __cplusplus
 }
 #endif
