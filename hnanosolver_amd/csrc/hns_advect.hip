@@ -111,6 +111,7 @@ __device__ __forceinline__ Taps make_taps(const GridDev& g, const int* s_nbr, co
 			T.t[c] = b < 0 ? -1 : b + (lx[di] | ly[dj] | lz[dk]);
 		}
 	} else {
+		if (g.far_flag) *g.far_flag = 1;  // a multi-GPU rank: this back-trace left the ghost layer (hns_dist reports it)
 #pragma unroll
 		for (int c = 0; c < 8; ++c) T.t[c] = tap_index(g, s_nbr, org, i + (c >> 2), j + ((c >> 1) & 1), k + (c & 1));  // unrolled: see make_taps_b
 	}
@@ -139,6 +140,7 @@ __device__ __forceinline__ TapsB make_taps_b(const GridDev& g, const int* s_nbr,
 			T.o[c] = s_b4[sx[di] + sy[dj] + sz[dk]] + (lx[di] | ly[dj] | lz[dk]);
 		}
 	} else {
+		if (g.far_flag) *g.far_flag = 1;  // a multi-GPU rank: this back-trace left the ghost layer (hns_dist reports it)
 #pragma unroll
 		for (int c = 0; c < 8; ++c) {  // unrolled: a rolled loop would index T.o dynamically and push the whole array into LDS
 			const int t = tap_index(g, s_nbr, org, i + (c >> 2), j + ((c >> 1) & 1), k + (c & 1));

@@ -43,6 +43,7 @@ GridDev hns_grid::dev() const {
 	d.first = (int)first_active;
 	d.oob = (int)outside_element;
 	d.rev = 0;
+	d.far_flag = far_flag;
 	return d;
 }
 

@@ -405,6 +405,7 @@ struct hns_dist {
 	std::vector<IpcPeer> ipc_peers;  // parallel to `peers`
 	uint32_t* ipc_flags = nullptr;   // fine-grained device memory, written by the peers
 	int* ipc_status = nullptr;       // host-mapped: non-zero once a wait on a peer ran out
+	int* far_status = nullptr;       // host-mapped: raised by an advection kernel whose back-trace left the one-leaf ghost layer (GridDev::far_flag)
 	uint32_t ipc_seq = 0;
 	bool ipc = false;
 	size_t unit_bytes = 0;  // bytes per scalar field over the local leaves (fields sit at multiples of it in the arena)
@@ -429,6 +430,13 @@ struct hns_dist {
 	size_t tev_used = 0;
 	long long timed_sweeps = 0;
 };
+
+static int far_check(const hns_dist* d) {
+	if (d->far_status && *(volatile int*)d->far_status)
+		return fail(HNS_ERR_RUNTIME, "hns_dist: an advection back-trace reached beyond the one-leaf ghost layer of this rank (|u| dt / dx above ~8 voxels at a partition "
+		                             "boundary): the owned result can differ from the single-domain run. Use a smaller time step (or fewer ranks); upload the fields again to clear this.");
+	return HNS_OK;
+}
 
 namespace {
 
@@ -673,6 +681,7 @@ void hns_dist_destroy(hns_dist* d) {
 	if (d->mir_tables) (void)hipFree(d->mir_tables);
 	if (d->ipc_flags) (void)hipFree(d->ipc_flags);
 	if (d->ipc_status) (void)hipHostFree(d->ipc_status);
+	if (d->far_status) (void)hipHostFree(d->far_status);
 	for (hipEvent_t e : d->tev) (void)hipEventDestroy(e);
 	if (d->ev_ready) (void)hipEventDestroy(d->ev_ready);
 	for (int i = 0; i < 2; ++i) {
@@ -729,6 +738,14 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 		if ((rc = hns_grid_set_outside_element(*gs[i], outside)) != HNS_OK) return bail(rc);
 	}
 	d->device = d->gA->device;
+	// A rank holds ONE layer of ghost leaves: a tap inside the 27-leaf neighbourhood of an owned leaf is always answered as the
+	// single domain would; further away a leaf that is missing HERE may exist on another rank. The advection kernels raise this
+	// word on such a tap and the next hns_dist call fails (the single-GPU path follows any back-trace through its origin hash).
+	if (world > 1) {
+		if (hipHostMalloc((void**)&d->far_status, 64, hipHostMallocMapped) != hipSuccess) return bail(fail(HNS_ERR_HIP, "hns_dist_create: hipHostMalloc failed"));
+		*d->far_status = 0;
+		for (int i = 0; i < 4; ++i) (*gs[i])->far_flag = d->far_status;
+	}
 
 	// device state: u, adv (Vec3f) | div, p_a, p_b | phi, phi_next per scalar | upload/download staging (Vec3f over the owned leaves)
 	{
@@ -1085,6 +1102,7 @@ int hns_dist_upload(hns_dist* d, const float* vel3, const float* const* scalars,
 	if (!d->gA) return fail(HNS_ERR_NO_DEVICE, "hns_dist_upload: plan-only handle (there is no CPU fallback)");
 	hipStream_t st = (hipStream_t)stream;
 	HNS_TRY(drain(d, st));
+	if (d->far_status) *d->far_status = 0;  // new fields: whatever an earlier back-trace did is history
 	const int nO = d->nB + d->nI;
 	if (nO == 0) return HNS_OK;
 	for (int f = -1; f < d->n_scalars; ++f) {
@@ -1114,7 +1132,7 @@ int hns_dist_download(hns_dist* d, float* vel3, float* const* scalars, float* pr
 		HNS_HIP(hipMemcpyAsync(dst, d->stage, sizeof(float) * 512 * (size_t)nO * nc, hipMemcpyDeviceToHost, st));
 		HNS_HIP(hipStreamSynchronize(st));
 	}
-	return HNS_OK;
+	return far_check(d);
 }
 
 }  // extern "C"
@@ -1520,7 +1538,7 @@ int check_step(const hns_dist* d, int iterations, float dt) {
 	if (!d) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_core_substep: null handle");
 	if (dt < 0.0f) return fail(HNS_ERR_INVALID_ARGUMENT, "dt (time step) cannot be negative.");
 	if (iterations <= 0) return fail(HNS_ERR_INVALID_ARGUMENT, "Number of pressure iterations must be positive.");
-	return HNS_OK;
+	return far_check(d);  // (raised by an earlier substep: kernels are asynchronous; hns_dist_synchronize / hns_dist_download report it too)
 }
 
 }  // namespace
@@ -1594,7 +1612,7 @@ int hns_dist_synchronize(hns_dist* d, void* stream) {
 	HNS_HIP(hipStreamSynchronize((hipStream_t)stream));
 	if (d->cs) HNS_HIP(hipStreamSynchronize(d->cs));
 	if (d->ipc_status && *(volatile int*)d->ipc_status) return fail(HNS_ERR_RUNTIME, "hns_dist: a peer did not answer within 20 s (one-sided transport); results are invalid");
-	return HNS_OK;
+	return far_check(d);
 }
 
 }  // extern "C"

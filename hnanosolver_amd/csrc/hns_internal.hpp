@@ -84,6 +84,8 @@ struct GridDev {
 	int first;  // first active leaf: kernels update leaves [first, first + n_active)
 	int oob;  // element read by advect_scalars for out-of-domain taps (0 on an unpartitioned grid)
 	int rev;  // 1: walk the launch order backwards (rows of eight workgroups reversed, see k_rbgs_pair)
+	int* far_flag;  // null, or (the local grid of a multi-GPU rank) a word the advection kernels raise when a tap leaves the 27-leaf neighbourhood of its
+	                // leaf: the rank holds one layer of ghost leaves, further away it cannot tell "outside the domain" from "on another rank"
 };
 
 // workgroup -> position in the launch-order tables, honouring GridDev::rev
@@ -127,6 +129,7 @@ struct hns_grid {
 	uint64_t n_active = 0;      // kernels update leaves [first_active, first_active + n_active) and only read the others
 	uint64_t first_active = 0;
 	uint64_t outside_element = 0;
+	int* far_flag = nullptr;    // see GridDev::far_flag (set by hns_dist; not owned)
 	bool on_device = false;
 	int device = -1;
 	// device copies

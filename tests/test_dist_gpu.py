@@ -313,3 +313,45 @@ def test_bench_driver_single_rank(partition):
     _, want = single_grid(o, R, ["density"], 6, 2)
     got = b.rank_obj.download()
     assert np.array_equal(got["vel"], want["vel"]) and np.array_equal(got["scalars"][0], want["density"])
+
+
+def test_back_trace_beyond_the_ghost_layer_is_reported():
+    """A rank holds one layer of ghost leaves. With |u| dt / dx ~ 21 voxels (SURVEY 8d's long-backtrace case, A = 400 / R) taps leave
+    the 27-leaf neighbourhood of their leaf: the single grid follows them through its origin hash, a rank cannot tell a leaf on
+    another rank from no leaf at all -- so it says so instead of returning something else. Uploading tame fields clears it."""
+    import hnanosolver_amd as H
+    import torch
+
+    R, world, names, iters = 32, 2, ["density"], 5
+    origins = fields.dense_leaves(R)
+    ranks = [HD.DistRank(origins, world, r, 1.0 / R, n_scalars=1, sweeps_per_exchange=4) for r in range(world)]
+    HD.DistRank.connect_local(ranks)
+    b = HD.partition_bounds(len(origins), world)
+    stream = int(torch.cuda.current_stream().cuda_stream)
+
+    def upload(amplitude):
+        f = fields.synthetic_fields(origins, R, amplitude_voxels=amplitude)
+        for r, d in enumerate(ranks):
+            sl = slice(b[r] * 512, b[r + 1] * 512)
+            d.upload(f["vel"][sl], [f[n][sl] for n in names])
+
+    upload(400.0)
+    HD.DistRank.local_core_substep(ranks, iters, 1.0 / 24.0, stream)
+    raised = 0
+    for d in ranks:
+        try:
+            d.synchronize(stream)
+        except H.HNSError as e:
+            assert "ghost layer" in str(e)
+            raised += 1
+    assert raised == world
+    with pytest.raises(H.HNSError, match="ghost layer"):
+        HD.DistRank.local_core_substep(ranks, iters, 1.0 / 24.0, stream)
+    with pytest.raises(H.HNSError, match="ghost layer"):
+        ranks[0].download()
+    upload(96.0)  # the benchmark amplitude (~5 voxels): within the layer, and the earlier failure is forgotten
+    HD.DistRank.local_core_substep(ranks, iters, 1.0 / 24.0, stream)
+    for d in ranks:
+        d.synchronize(stream)
+    _, want = single_grid(origins, R, names, iters, 1)
+    check(ranks, b, want, names)
