@@ -133,6 +133,8 @@ SIGNATURES = {
     "hns_dist_download": (_i, [_vp, _vp, C.POINTER(C.c_void_p), _vp, _vp]),
     "hns_dist_core_substep": (_i, [_vp, _i, _f, _vp]),
     "hns_dist_local_core_substep": (_i, [C.POINTER(C.c_void_p), _i, _i, _f, _vp]),
+    "hns_dist_sim_substep": (_i, [_vp, _i, _f, _vp, _ip, _i, _vp]),
+    "hns_dist_local_sim_substep": (_i, [C.POINTER(C.c_void_p), _i, _i, _f, _vp, _ip, _i, _vp]),
     "hns_dist_timing": (_i, [_vp, _i]),
     "hns_dist_pressure_time": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_longlong)]),
     "hns_dist_synchronize": (_i, [_vp, _vp]),

@@ -367,7 +367,7 @@ struct hns_dist {
 	void* arena = nullptr;
 	size_t arena_bytes = 0;
 	int device = -1;
-	float *u = nullptr, *adv = nullptr, *div = nullptr, *p_a = nullptr, *p_b = nullptr, *p_result = nullptr, *stage = nullptr;
+	float *u = nullptr, *adv = nullptr, *tmp = nullptr, *div = nullptr, *p_a = nullptr, *p_b = nullptr, *p_result = nullptr, *stage = nullptr;
 	std::vector<float*> phi, phi_next;
 	void* tables = nullptr;  // region tables of every peer (one allocation)
 	// the same regions, all peers concatenated (one pack / unpack launch per field when a rank has several peers)
@@ -747,11 +747,11 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 		for (int i = 0; i < 4; ++i) (*gs[i])->far_flag = d->far_status;
 	}
 
-	// device state: u, adv (Vec3f) | div, p_a, p_b | phi, phi_next per scalar | upload/download staging (Vec3f over the owned leaves)
+	// device state: u, adv, tmp (Vec3f) | div, p_a, p_b | phi, phi_next per scalar | upload/download staging (Vec3f over the owned leaves)
 	{
 		const size_t unit = pad256(sizeof(float) * 512 * (size_t)std::max(n_local, 1));
 		d->unit_bytes = unit;
-		const size_t units = 3 + 3 + 3 + 2 * (size_t)n_scalars + 3;
+		const size_t units = 3 + 3 + 3 + 3 + 2 * (size_t)n_scalars + 3;
 		if ((rc = hns_arena_get(unit * units, d->device, &d->arena, &d->arena_bytes)) != HNS_OK) return bail(rc);
 		if (hipMemset(d->arena, 0, unit * units) != hipSuccess) return bail(fail(HNS_ERR_HIP, "hns_dist_create: clearing the field memory failed"));
 		char* q = (char*)d->arena;
@@ -760,7 +760,7 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 			q += k * unit;
 			return r;
 		};
-		d->u = take(3), d->adv = take(3), d->div = take(1), d->p_a = take(1), d->p_b = take(1);
+		d->u = take(3), d->adv = take(3), d->tmp = take(3), d->div = take(1), d->p_a = take(1), d->p_b = take(1);
 		for (int s = 0; s < n_scalars; ++s) d->phi.push_back(take(1)), d->phi_next.push_back(take(1));
 		d->stage = take(3);
 		d->p_result = d->p_a;
@@ -1370,11 +1370,19 @@ struct Step {
 	// pressure loop cursor
 	int it = 0;
 	float *src = nullptr, *dst = nullptr;
+	// the whole Compute_Sim substep (reference HNanoSolver.cu:150-356) instead of its core: combustion parameters, the positions of
+	// fuel / waste / temperature / flame / collision_sdf among the rank's scalars, collision on, vorticity confinement on
+	const hns_combustion_params* prm = nullptr;
+	int fi[5] = {-1, -1, -1, -1, -1};
+	bool coll = false, vort = false;
 
+	bool full() const { return prm != nullptr; }
 	int n_phases() const {
 		const int blocks = (iterations + d->k - 1) / d->k;
+		if (full()) return 1 + (coll ? 1 : 0) + 1 + (vort ? 1 : 0) + 1 + 1 + blocks + 1 + 1;  // open | [collision] | advect_vector | [vorticity] | divergence | combustion | blocks | gradient | advect_scalars
 		return 1 + 1 + 1 + blocks + 1 + 1;  // open | advect_vector | divergence | pressure blocks | gradient | advect_scalars
 	}
+	const float* sdf() const { return coll ? d->phi[(size_t)fi[4]] : nullptr; }
 
 	int sweep(hns_grid* g, bool from_zero, hipStream_t s) const {
 		return hns_rbgs_iterate(g, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), 1, nullptr, s, from_zero);
@@ -1409,7 +1417,134 @@ struct Step {
 		return launch_status("hns_dist: chained launch");
 	}
 
+	// one block of up to k sweeps with the halo of p exchanged behind it; all but the last sweep the ghost leaves too
+	int sor_block_exchanged(int b) {
+		hns_dist* D = d;
+		typedef std::vector<std::pair<float*, int>> Fields;
+		if (b == 0) {
+			it = 0, src = d->p_a, dst = d->p_b;  // never warm-started (reference HNanoSolver.cu:113): the first sweep reads no p
+			if (d->timing && d->tev_used + 2 <= d->tev.size()) HNS_HIP(hipEventRecord(d->tev[d->tev_used], st));
+		}
+		const int n = std::min(d->k, iterations - it);
+		for (int j = 0; j < n - 1; ++j, ++it) {
+			HNS_TRY(sweep(d->gA, it == 0, st));
+			std::swap(src, dst);
+		}
+		const bool last = it + 1 == iterations, zero = it == 0;
+		HNS_TRY(post(d, last ? X_D1 : X_P, Fields{{dst, 1}}, st, [=](hipStream_t s) { return sweep(D->gB, zero, s); }));
+		HNS_TRY(sweep(d->gI, zero, st));
+		std::swap(src, dst);
+		++it;
+		if (last) d->p_result = src;
+		return HNS_OK;
+	}
+
+	// The full substep. Every kernel boundary a stencil crosses is an exchange (post / complete), whatever the transport: the chained
+	// and mirroring forms of the core substep are not used here. Pointwise kernels run over the owned leaves, local [0, nB + nI).
+	int run_full(int ph) {
+		const float inv_dx = 1.0f / d->voxel_size;
+		const int blocks = (iterations + d->k - 1) / d->k;
+		typedef std::vector<std::pair<float*, int>> Fields;
+		hns_dist* D = d;
+		const float* sd = sdf();
+		const int cl = coll ? 1 : 0;
+		const uint64_t n_owned = (uint64_t)(d->nB + d->nI) * 512u;
+		auto nothing = [](hipStream_t) { return HNS_OK; };
+		const float dtv = dt;
+		if (ph == 0) {  // the advection inputs: phi unless the previous substep already posted it, and u -- which collision rewrites first
+			Fields f;
+			if (!coll && !d->u_ghosts_fresh) {
+				if (d->phi_in_flight) HNS_TRY(complete(d, st));
+				f.emplace_back(d->u, 3);
+			}
+			if (!d->phi_in_flight)
+				for (float* p : d->phi) f.emplace_back(p, 1);
+			d->phi_in_flight = false;
+			if (f.empty()) return HNS_OK;
+			return post(d, X_ADV, f, st, nothing);
+		}
+		HNS_TRY(complete(d, st));
+		if (coll && ph == 1) {  // enforceCollisionBoundaries (HNanoSolver.cu:153-157) reads the ghost voxels of the SDF (its normal): they have arrived now
+			HNS_TRY(hns_dev_enforce_collision_boundaries(d->gO, d->u, sd, d->voxel_size, st));
+			return post(d, X_ADV, Fields{{d->u, 3}}, st, nothing);
+		}
+		int q = ph - 1 - (coll ? 1 : 0);
+		if (q == 0) {  // advect_vector (:162-170); vorticity confinement reads it up to factor_scale + 1 voxels away: whole leaves travel then
+			HNS_TRY(post(d, vort ? X_ADV : X_D1, Fields{{d->adv, 3}}, st, [=](hipStream_t s) { return hns_dev_advect_vector(D->gB, D->u, D->adv, sd, cl, dtv, inv_dx, s); }));
+			return hns_dev_advect_vector(d->gI, d->u, d->adv, sd, cl, dt, inv_dx, st);
+		}
+		if (vort && q == 1) {  // :172-176, out of place (the reference's in-place launch races)
+			const float scale = prm->vorticityScale, fs = prm->factorScale;
+			HNS_TRY(post(d, X_D1, Fields{{d->tmp, 3}}, st, [=](hipStream_t s) { return hns_dev_vorticity_confinement(D->gB, D->adv, D->tmp, dtv, inv_dx, scale, fs, s); }));
+			HNS_TRY(hns_dev_vorticity_confinement(d->gI, d->adv, d->tmp, dt, inv_dx, scale, fs, st));
+			std::swap(d->adv, d->tmp);
+			return HNS_OK;
+		}
+		q -= vort ? 2 : 1;
+		if (q == 0) {  // divergence (:181-188) + what combustion adds to it (:211-221, k_combustion_div: fuel and waste only)
+			const float ex = prm->expansionRate;
+			const float *fuel = d->phi[(size_t)fi[0]], *waste = d->phi[(size_t)fi[1]];
+			const uint64_t nb = (uint64_t)d->nB * 512u, ni = (uint64_t)d->nI * 512u;
+			HNS_TRY(post(d, X_DIV, Fields{{d->div, 1}}, st, [=](hipStream_t s) {
+				HNS_TRY(hns_dev_divergence(D->gB, D->adv, D->div, inv_dx, s));
+				return nb ? hns_combustion_div(fuel, waste, D->div, ex, nb, s) : HNS_OK;
+			}));
+			HNS_TRY(hns_dev_divergence(d->gI, d->adv, d->div, inv_dx, st));
+			return ni ? hns_combustion_div(fuel + nb, waste + nb, d->div + nb, ex, ni, st) : HNS_OK;
+		}
+		if (q == 1) {  // the rest of combustion, buoyancy with the NEW temperature (:226-234), outputs become inputs (:239-246): pointwise, owned voxels
+			if (n_owned) {
+				HNS_TRY(hns_combustion_fields(d->phi[(size_t)fi[0]], d->phi[(size_t)fi[1]], d->phi[(size_t)fi[2]], d->phi[(size_t)fi[3]], d->phi_next[(size_t)fi[0]],
+				                              d->phi_next[(size_t)fi[1]], d->phi_next[(size_t)fi[2]], d->phi_next[(size_t)fi[3]], prm->temperatureRelease, n_owned, st));
+				HNS_TRY(hns_dev_temperature_buoyancy(d->adv, d->phi_next[(size_t)fi[2]], d->adv, dt, prm->ambientTemp, prm->buoyancyStrength, n_owned, st));
+			}
+			Fields f;
+			for (int c = 0; c < 4; ++c) {
+				std::swap(d->phi[(size_t)fi[c]], d->phi_next[(size_t)fi[c]]);
+				f.emplace_back(d->phi[(size_t)fi[c]], 1);
+			}
+			return post(d, X_ADV, f, st, nothing);  // advect_scalars reads their ghosts; hidden under the pressure solve
+		}
+		q -= 2;
+		if (q < blocks) return sor_block_exchanged(q);
+		q -= blocks;
+		if (q == 0) {  // gradient subtraction (:278-289) [and collision, :292-296] -> u, whose ghosts the scalar advection reads
+			if (d->timing && d->tev_used + 2 <= d->tev.size()) {
+				HNS_HIP(hipEventRecord(d->tev[d->tev_used + 1], st));
+				d->tev_used += 2;
+				d->timed_sweeps += iterations;
+			}
+			const float vs = d->voxel_size;
+			HNS_TRY(post(d, X_ADV, Fields{{d->u, 3}}, st, [=](hipStream_t s) {
+				HNS_TRY(hns_dev_subtract_pressure_gradient(D->gB, D->adv, D->p_result, D->u, sd, cl, inv_dx, s));
+				return cl ? hns_dev_enforce_collision_boundaries(D->gB, D->u, sd, vs, s) : HNS_OK;
+			}));
+			HNS_TRY(hns_dev_subtract_pressure_gradient(d->gI, d->adv, d->p_result, d->u, sd, cl, inv_dx, st));
+			return cl ? hns_dev_enforce_collision_boundaries(d->gI, d->u, sd, vs, st) : HNS_OK;
+		}
+		// advect every float field except collision_sdf with the projected velocity (:321-356), and post them for the next substep
+		d->u_ghosts_fresh = !coll;  // (with collision the next substep rewrites u before it advects)
+		std::vector<const float*> in;
+		std::vector<float*> out;
+		std::vector<int> which;
+		for (int sidx = 0; sidx < d->n_scalars; ++sidx)
+			if (sidx != fi[4]) in.push_back(d->phi[(size_t)sidx]), out.push_back(d->phi_next[(size_t)sidx]), which.push_back(sidx);
+		Fields f;
+		for (float* p : out) f.emplace_back(p, 1);
+		const int ns = (int)in.size();
+		if (ns) {
+			HNS_TRY(post(d, X_ADV, f, st, [=](hipStream_t s) {
+				return D->gB->n_active ? hns_dev_advect_scalars(D->gB, D->u, in.data(), const_cast<float* const*>(out.data()), ns, sd, cl, dtv, inv_dx, s) : HNS_OK;
+			}));
+			if (d->gI->n_active) HNS_TRY(hns_dev_advect_scalars(d->gI, d->u, in.data(), out.data(), ns, sd, cl, dt, inv_dx, st));
+		}
+		for (int sidx : which) std::swap(d->phi[(size_t)sidx], d->phi_next[(size_t)sidx]);
+		d->phi_in_flight = ns > 0 && d->world > 1;
+		return HNS_OK;
+	}
+
 	int run(int ph) {
+		if (full()) return run_full(ph);
 		const float inv_dx = 1.0f / d->voxel_size;
 		const int blocks = (iterations + d->k - 1) / d->k;
 		typedef std::vector<std::pair<float*, int>> Fields;
@@ -1575,6 +1710,67 @@ int hns_dist_local_core_substep(hns_dist* const* ranks, int world, int iteration
 	for (int ph = 0, n = steps[0].n_phases(); ph < n; ++ph) {
 		if (ph > 0)
 			for (Step& s : steps) HNS_TRY(complete(s.d, s.st));
+		for (Step& s : steps) HNS_TRY(s.run(ph));
+	}
+	return HNS_OK;
+}
+
+// ---- the whole Compute_Sim substep, partitioned (reference HNanoSolver.cu:150-356; single GPU: hns_sim_substep) ----
+// field_index: positions of fuel, waste, temperature, flame and collision_sdf (-1: none) among the rank's scalars (hns_dist_upload
+// order). Every float field except collision_sdf is advected. Owned results equal hns_sim_substep's on the whole domain bit for bit.
+static int sim_step_args(const hns_dist* d, const hns_combustion_params* params, const int* field_index, int has_collision, Step& s) {
+	if (!params || !field_index) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_sim_substep: null argument");
+	const char* required[4] = {"fuel", "waste", "temperature", "flame"};
+	for (int c = 0; c < 4; ++c) {
+		if (field_index[c] < 0 || field_index[c] >= d->n_scalars) {
+			set_error("Missing required input field for combustion: %s", required[c]);  // HNanoSolver.cu:193-201
+			return HNS_ERR_RUNTIME;
+		}
+		for (int e = 0; e < c; ++e)
+			if (field_index[e] == field_index[c]) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_sim_substep: two combustion fields share one scalar");
+	}
+	if (field_index[4] >= d->n_scalars) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_sim_substep: collision_sdf index out of range");
+	for (int c = 0; c < 4; ++c)
+		if (field_index[4] >= 0 && field_index[4] == field_index[c]) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_sim_substep: collision_sdf shares a scalar with a combustion field");
+	// vorticity confinement reads u* up to (int)factor_scale + 1 voxels from a voxel: it must stay inside the one-leaf ghost layer
+	if ((int)params->factorScale > 6 || (int)params->factorScale < 0) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_sim_substep: factor_scale must be within 0..6 on a partitioned domain");
+	s.prm = params;
+	for (int c = 0; c < 5; ++c) s.fi[c] = field_index[c];
+	s.coll = has_collision && field_index[4] >= 0;  // HNanoSolver.cu:66-75
+	if (!s.coll) s.fi[4] = has_collision ? field_index[4] : field_index[4];  // (collision_sdf is never advected, used or not: HNanoSolver.cu:327)
+	s.vort = (int)params->factorScale != 0;  // (int)factor_scale == 0: the kernel is a bit-exact copy (hns_api.hip: Substep::part_a)
+	return HNS_OK;
+}
+
+int hns_dist_sim_substep(hns_dist* d, int iterations, float dt, const hns_combustion_params* params, const int* field_index, int has_collision, void* stream) {
+	HNS_TRY(check_step(d, iterations, dt));
+	if (!d->gA) return fail(HNS_ERR_NO_DEVICE, "hns_dist_sim_substep: plan-only handle (there is no CPU fallback)");
+	if (!d->local_ranks.empty() && d->world > 1) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_sim_substep: locally connected ranks step together (hns_dist_local_sim_substep)");
+	if (d->ipc_status && *(volatile int*)d->ipc_status) return fail(HNS_ERR_RUNTIME, "hns_dist: a peer did not answer within 20 s (one-sided transport); results are invalid");
+	memset(d->bytes_sent, 0, sizeof(d->bytes_sent));
+	d->messages_sent = d->exchanges = 0;
+	Step s{d, iterations, dt, (hipStream_t)stream};
+	HNS_TRY(sim_step_args(d, params, field_index, has_collision, s));
+	for (int ph = 0, n = s.n_phases(); ph < n; ++ph) HNS_TRY(s.run(ph));
+	return HNS_OK;
+}
+
+int hns_dist_local_sim_substep(hns_dist* const* ranks, int world, int iterations, float dt, const hns_combustion_params* params, const int* field_index, int has_collision,
+                               void* stream) {
+	if (!ranks || world < 1) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_local_sim_substep: bad arguments");
+	std::vector<Step> steps;
+	for (int r = 0; r < world; ++r) {
+		HNS_TRY(check_step(ranks[r], iterations, dt));
+		if ((int)ranks[r]->local_ranks.size() != world) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_local_sim_substep: ranks are not locally connected");
+		memset(ranks[r]->bytes_sent, 0, sizeof(ranks[r]->bytes_sent));
+		ranks[r]->messages_sent = ranks[r]->exchanges = 0;
+		steps.push_back(Step{ranks[r], iterations, dt, (hipStream_t)stream});
+		HNS_TRY(sim_step_args(ranks[r], params, field_index, has_collision, steps.back()));
+	}
+	for (int ph = 0, n = steps[0].n_phases(); ph < n; ++ph) {
+		// (before phase 0 too: with collision the phase rewrites u and posts it again, and a rank must have taken delivery of the
+		// exchange the previous substep left in flight before a peer posts the next one)
+		for (Step& s : steps) HNS_TRY(complete(s.d, s.st));
 		for (Step& s : steps) HNS_TRY(s.run(ph));
 	}
 	return HNS_OK;

@@ -211,6 +211,22 @@ class DistRank:
         arr = (C.c_void_p * len(ranks))(*[r._ptr for r in ranks])
         _raise(lib.hns_dist_local_core_substep(arr, len(ranks), int(iterations), float(dt), stream))
 
+    @staticmethod
+    def _field_index(names: Sequence[str]):
+        """positions of fuel, waste, temperature, flame, collision_sdf (-1: absent) in a rank's scalar list"""
+        return (C.c_int * 5)(*[list(names).index(n) if n in names else -1 for n in ("fuel", "waste", "temperature", "flame", "collision_sdf")])
+
+    def sim_substep(self, names: Sequence[str], iterations: int, dt: float, params, has_collision: bool = False, stream: int = 0) -> None:
+        """The whole Compute_Sim substep on this rank (hns_dist_sim_substep); `names` = the scalars in upload order."""
+        p = params._c()
+        _raise(lib.hns_dist_sim_substep(self._ptr, int(iterations), float(dt), C.byref(p), self._field_index(names), int(has_collision), stream))
+
+    @staticmethod
+    def local_sim_substep(ranks: Sequence["DistRank"], names: Sequence[str], iterations: int, dt: float, params, has_collision: bool = False, stream: int = 0) -> None:
+        arr = (C.c_void_p * len(ranks))(*[r._ptr for r in ranks])
+        p = params._c()
+        _raise(lib.hns_dist_local_sim_substep(arr, len(ranks), int(iterations), float(dt), C.byref(p), DistRank._field_index(names), int(has_collision), stream))
+
     def timing(self, max_solves: int) -> None:
         _raise(lib.hns_dist_timing(self._ptr, int(max_solves)))
 

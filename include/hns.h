@@ -337,6 +337,15 @@ int hns_dist_core_substep(hns_dist*, int iterations, float dt, void* stream);
 int hns_dist_local_core_substep(hns_dist* const* ranks, int world, int iterations, float dt, void* stream);
 /* hipEvent bracketing of the pressure loops (halo exchanges included), as hns_sim_timing / hns_sim_pressure_time. */
 int hns_dist_timing(hns_dist*, int max_solves);
+/* The whole Compute_Sim substep on the partitioned domain (reference HNanoSolver.cu:150-356; single GPU: hns_sim_substep): collision,
+ * advect_vector, vorticity confinement, divergence, combustion, buoyancy, the pressure solve, gradient subtraction, collision, and the
+ * advection of every float field except collision_sdf. field_index[5]: the positions of fuel, waste, temperature, flame and
+ * collision_sdf (-1: none) among the rank's scalars in hns_dist_upload order. Every kernel boundary a stencil crosses is a halo
+ * exchange (vorticity confinement reads whole ghost leaves of u*); the pointwise kernels run on the owned leaves. Owned results are
+ * bit-identical to hns_sim_substep on the whole domain (tests/test_dist_gpu.py). factor_scale must stay within 0..6. */
+int hns_dist_sim_substep(hns_dist*, int iterations, float dt, const hns_combustion_params*, const int* field_index, int has_collision, void* stream);
+int hns_dist_local_sim_substep(hns_dist* const* ranks, int world, int iterations, float dt, const hns_combustion_params*, const int* field_index, int has_collision,
+                               void* stream);
 int hns_dist_pressure_time(hns_dist*, float* total_ms, long long* sweeps);
 int hns_dist_synchronize(hns_dist*, void* stream); /* waits for `stream` and the communication stream */
 
