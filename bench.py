@@ -66,9 +66,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--partition", action="store_true", help="N > 1: split ONE --config domain across the ranks (strong scaling) instead of one slab per rank")
     ap.add_argument("--sweeps-per-exchange", type=int, default=0, help="N > 1: fused SOR sweeps between two halo refreshes of p (1..4, 0 = library default)")
-    ap.add_argument("--transport", choices=["auto", "rccl", "ipc"], default="auto",
-                    help="N > 1 halo transport: rccl = RCCL send/recv groups; ipc = one-sided puts into hipIpc-mapped peer memory with the SOR sweep "
-                         "delivering its own halo; auto (default) = ipc if it connects and reproduces three RCCL substeps bit for bit on this machine, else rccl")
+    ap.add_argument("--transport", choices=["auto", "rccl", "ipc"], default="rccl",
+                    help="N > 1 halo transport: rccl (default) = RCCL send/recv groups on a communication stream under the interior kernels; ipc = one-sided "
+                         "stores into hipIpc-mapped peer memory, every kernel delivering its own halo (has only run between processes sharing ONE GPU so "
+                         "far: opt-in); auto = ipc if it connects and reproduces three RCCL substeps bit for bit on this machine, else rccl. Whatever "
+                         "runs is first checked against the single-GPU result of the whole domain (config.verified)")
+    ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the start-up comparison of the partitioned run with the single-GPU run of the whole domain")
     ap.add_argument("--share-one-gpu", action="store_true",
                     help="builder's check on a 1-GPU box: all N ranks on cuda:0, host rendezvous over gloo, --transport ipc (RCCL refuses two ranks on one device)")
     ap.add_argument("--cook", action="store_true", help="time the cook-equivalent hns_compute_sim call (upload + grid build + substep + download) instead")
@@ -228,6 +231,8 @@ def main():
                               transport=args.transport, reference_transport="ipc" if args.share_one_gpu else "rccl")
         n_vox_rank = runner.n_owned * 512
         step, pressure_time, stage_times = runner.step, runner.pressure_time, None
+        if not args.no_verify:
+            runner.verify_against_single_gpu()
 
         def timing_on():
             runner.timing_on(args.steps)
@@ -302,6 +307,7 @@ def main():
                 "algorithmic_bytes_per_voxel_substep": BYTES_PER_VOXEL_SUBSTEP - 600 + 12 * args.iterations,
                 "halo": None if world == 1 else {k: runner.info()[k] for k in ("boundary_leaves", "interior_leaves", "ghost_leaves", "peers", "sweeps_per_exchange",
                                                                                 "bytes_sent", "messages_sent", "exchanges")},
+                "verified": "single GPU path (tests/ tie it to the oracle)" if world == 1 else runner.verified_note,
                 "parallelism": "single GPU" if world == 1 else (
                     (f"one domain in {world} contiguous leaf ranges" if args.partition else f"x-slab leaf partition over {world} ranks")
                     + ", halo transport: " + runner.transport_note

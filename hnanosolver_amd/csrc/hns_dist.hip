@@ -60,14 +60,19 @@ struct Rccl {
 	decltype(&ncclRecv) Recv = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
 	bool ok = false;
+	std::string why;  // what went wrong, captured where it went wrong (dlerror() clears itself when read)
 };
 Rccl& rccl() {
 	static Rccl r = [] {
 		Rccl t;
 		void* h = nullptr;
-		for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"})
+		for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
 			if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+			const char* e = dlerror();
+			t.why += std::string(t.why.empty() ? "" : "; ") + (e ? e : name);
+		}
 		if (!h) return t;
+		t.why.clear();
 		t.GetUniqueId = (decltype(t.GetUniqueId))dlsym(h, "ncclGetUniqueId");
 		t.CommInitRank = (decltype(t.CommInitRank))dlsym(h, "ncclCommInitRank");
 		t.CommDestroy = (decltype(t.CommDestroy))dlsym(h, "ncclCommDestroy");
@@ -77,13 +82,14 @@ Rccl& rccl() {
 		t.Recv = (decltype(t.Recv))dlsym(h, "ncclRecv");
 		t.GetErrorString = (decltype(t.GetErrorString))dlsym(h, "ncclGetErrorString");
 		t.ok = t.GetUniqueId && t.CommInitRank && t.CommDestroy && t.GroupStart && t.GroupEnd && t.Send && t.Recv && t.GetErrorString;
+		if (!t.ok) t.why = "the library lacks one of ncclGetUniqueId / CommInitRank / CommDestroy / GroupStart / GroupEnd / Send / Recv / GetErrorString";
 		return t;
 	}();
 	return r;
 }
 int need_rccl(const char* who) {
 	if (rccl().ok) return HNS_OK;
-	hns::set_error("%s: librccl.so.1 could not be loaded: %s", who, dlerror() ? dlerror() : "symbols missing");
+	hns::set_error("%s: librccl.so.1 could not be loaded: %s", who, rccl().why.c_str());
 	return HNS_ERR_RUNTIME;
 }
 }  // namespace
@@ -584,7 +590,9 @@ int ensure_flags(hns_dist* d) {
 // peer_arena / peer_unit / peer_flags: that peer's field memory, its bytes per scalar field and its flag page as addressable here
 int setup_mirror(hns_dist* d, const std::vector<std::vector<int>> (&remote_leaf)[X_COUNT], const std::vector<char*>& peer_arena, const std::vector<uint64_t>& peer_unit,
                  const std::vector<uint32_t*>& peer_flags) {
-	if (d->peers.size() > (size_t)kMirrorMaxPeers || d->world > kFlagSlots) return HNS_OK;  // (stay on the exchanged substep)
+	// (stay on the exchanged substep) -- decided from what EVERY rank knows: the owner of global leaf 0 has all other ranks as peers
+	// (the element-0 mirror region), so some rank exceeds the peer table exactly when world - 1 does, and then no rank mirrors
+	if (d->world - 1 > kMirrorMaxPeers || d->world > kFlagSlots) return HNS_OK;
 	HNS_TRY(ensure_flags(d));
 	const int nB = d->nB;
 	std::vector<int> first[X_COUNT];

@@ -297,6 +297,54 @@ class SlabBench:
             if world > 1 and connect:
                 self.rank_obj.connect_ipc() if transport == "ipc" else self.rank_obj.connect_rccl()
         self.rank_obj.upload(*self._fields)
+        self._glob, self._R, self._partition, self._first, self._count, self._world = glob, R, partition, first, count, world
+        self.verified_note = "single GPU" if world == 1 else "not checked"
+
+    def verify_against_single_gpu(self, substeps: int = 2, max_voxels: int = 600_000_000) -> bool:
+        """Every rank computes `substeps` substeps of the WHOLE domain on its own GPU with the single-GPU path (the same on every rank, bit
+        for bit) and compares its owned leaves of the partitioned run with it: velocity and density must be identical. The
+        transport that is about to be timed is what runs the partitioned side, so a scaling figure comes with a statement about its
+        physics. Collective (the partitioned substeps are). Leaves the rank with freshly uploaded fields."""
+        from . import api, device as D, fields
+
+        if self._world == 1:
+            return True
+        n_vox = len(self._glob) * LEAF_VOXELS
+        if n_vox > max_voxels:
+            self.verified_note = f"not checked against the single-GPU result (whole domain of {n_vox} voxels kept off one GPU)"
+            return True
+        d = self.rank_obj
+        d.upload(*self._fields)
+        for _ in range(substeps):
+            d.core_substep(self.iterations, self.dt, self.stream)
+        d.synchronize(self.stream)
+        got = d.download()
+        if self._partition:
+            f = fields.synthetic_fields(self._glob, self._R)
+            vel, den = f["vel"], f["density"]
+        else:  # every slab carries the same fields (periodic in x)
+            o = self._glob[: len(self._glob) // self._world].copy()
+            f = fields.synthetic_fields(o, self._R)
+            vel, den = np.tile(f["vel"], (self._world, 1)), np.tile(f["density"], self._world)
+        grid = api.create_grid_from_leaves(self._glob, self.vs)
+        sim = D.Sim(grid, ["density"])
+        arrays = {"vel": np.ascontiguousarray(vel), "density": np.ascontiguousarray(den)}
+        sim.upload(arrays)
+        for _ in range(substeps):
+            sim.core_substep(self.iterations, self.dt, self.vs, self.stream)
+        sim.download(arrays)
+        sl = slice(self._first * LEAF_VOXELS, (self._first + self._count) * LEAF_VOXELS)
+        same = np.array_equal(got["vel"], arrays["vel"][sl]) and np.array_equal(got["scalars"][0], arrays["density"][sl])
+        sim.close()
+        import torch.distributed as dist
+
+        t = self.torch.tensor([1 if same else 0], dtype=self.torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(int(t.item()))
+        self.verified_note = (f"owned velocity and density after {substeps} substeps bit-identical to the single-GPU run of the whole domain on every rank" if ok else
+                              "MISMATCH against the single-GPU run of the whole domain: THIS RUN'S PHYSICS IS WRONG, its throughput means nothing")
+        d.upload(*self._fields)
+        return ok
 
     def _verified_one_sided(self, make, sweeps_per_exchange, reference_transport):
         """transport = auto: the one-sided transport with the chained substep (every kernel delivers its own halo) if -- on THIS machine, now -- it connects

@@ -40,6 +40,11 @@ def main():
 
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    import hnanosolver_amd as H
+
+    # every rank of this test sits on cuda:0: in-kernel waits of several processes can fill the device's wave slots and starve the
+    # process they wait for (hns_dist.hip: "guarded" puts ONE waiting wave in front of every chained launch instead)
+    H.set_option("dist_mirror", "guarded")
     try:
         origins, R = case_leaves(case)
         names = ["density", "temperature"]

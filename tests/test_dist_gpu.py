@@ -222,18 +222,26 @@ def _run_processes(world, case, k, iters, substeps, tmp_path, timeout=420):
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_process_worker.py")
+    # output to a file per rank: a rank that fills a pipe nobody is reading yet would block inside a collective its peers wait in
+    logs = [open(os.path.join(str(tmp_path), f"rank{r}.log"), "w+") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), case, str(k), str(iters), str(substeps), str(tmp_path)],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
-    outs = []
+                              stdout=logs[r], stderr=subprocess.STDOUT, text=True) for r in range(world)]
     try:
+        import time
+        deadline = time.monotonic() + timeout
         for p in procs:
-            outs.append(p.communicate(timeout=timeout)[0])
+            p.wait(timeout=max(1.0, deadline - time.monotonic()))
     finally:
         for p in procs:  # exactly the processes started here
             if p.poll() is None:
                 p.kill()
+    outs = []
+    for f in logs:
+        f.seek(0)
+        outs.append(f.read())
+        f.close()
     for r, p in enumerate(procs):
-        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:] if r < len(outs) else ''}"
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
     return [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
 
 
@@ -277,7 +285,7 @@ def test_bench_py_as_two_processes_sharing_the_gpu(extra, tmp_path):
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "bench.py"), "--gpus", "2", "--share-one-gpu", "--steps", "3", "--warmup", "1", "--iterations", "10"] + (extra or ["--config", "64"])
+           os.path.join(root, "bench.py"), "--gpus", "2", "--share-one-gpu", "--transport", "auto", "--steps", "3", "--warmup", "1", "--iterations", "10"] + (extra or ["--config", "64"])
     p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -286,6 +294,7 @@ def test_bench_py_as_two_processes_sharing_the_gpu(extra, tmp_path):
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["value"] > 0 and j["unit"] == "substeps/s"
     assert j["scaling"] == ("strong" if extra else "weak")
     assert "verified bit for bit" in j["config"]["parallelism"], j["config"]["parallelism"]
+    assert "bit-identical to the single-GPU run of the whole domain" in j["config"]["verified"], j["config"]["verified"]  # what was timed was checked against one GPU first
     assert j["config"]["halo"]["sweeps_per_exchange"] == 1 and j["config"]["halo"]["bytes_sent"]["p"] > 0
 
 
