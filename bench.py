@@ -153,7 +153,23 @@ def cpu_baseline(origins, R, iterations, budget_s=25.0):
     G.advect_scalars(u, [f["density"]], dt, inv_dx)
     t_post = time.perf_counter() - t2
     per_substep = t_pre + t_post + (t_it / it_s) * iterations
+    # ONE core on BASELINE.json's CPU-runnable configuration (64^3, the whole substep, nothing extrapolated): SURVEY 8d asks for it
+    one = None
+    try:
+        o64 = fields.dense_leaves(64)
+        G1, f1 = OracleGrid(o64), fields.synthetic_fields(o64, 64)
+        L.orc_set_threads(1)
+        t3 = time.perf_counter()
+        a1 = G1.advect_vector(f1["vel"], dt, 64.0)
+        d1 = G1.divergence(a1, 64.0)
+        p1 = G1.rbgs_iterations(d1, 1.0 / 64, float(L.orc_omega_compute(1.0 / 64)), iterations)
+        u1 = G1.subtract_pressure_gradient(a1, p1, 64.0)
+        G1.advect_scalars(u1, [f1["density"]], dt, 64.0)
+        one = {"value": 1.0 / (time.perf_counter() - t3), "unit": "substeps/s", "cores": 1, "workload": "64^3 dense-active grid, the whole core substep"}
+    finally:
+        L.orc_set_threads(cores)
     return {
+        "one_core_64": one,
         "value": 1.0 / per_substep,
         "unit": "substeps/s",
         "cores": cores,

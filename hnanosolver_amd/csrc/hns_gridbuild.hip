@@ -180,13 +180,10 @@ __global__ __launch_bounds__(256) void k_write_pairs(const int* __restrict__ nbr
 // window -- the head leaf at z = window start, or 8 above it when the z-runs pair up on odd leaf positions. Records whose
 // window has no such leader, and groups with a missing member, are swept by the one-wave kernel instead.
 
-__global__ __launch_bounds__(256) void k_head_index(const int* __restrict__ recs, int n_pairs, int* __restrict__ head_of_leaf, int* __restrict__ wave_of_leaf) {
+__global__ __launch_bounds__(256) void k_head_index(const int* __restrict__ recs, int n_pairs, int* __restrict__ head_of_leaf) {
 	const int p = blockIdx.x * 256 + threadIdx.x;
 	if (p >= n_pairs) return;
-	const int l0 = recs[(size_t)p * 56], l1 = recs[(size_t)p * 56 + 28];
-	head_of_leaf[l0] = p;
-	wave_of_leaf[l0] = p;  // which wave record sweeps a leaf (the resident SOR kernel's waves wait for their neighbours' records)
-	if (l1 >= 0) wave_of_leaf[l1] = p;
+	head_of_leaf[recs[(size_t)p * 56]] = p;
 }
 
 __global__ __launch_bounds__(256) void k_group_assign(GridDev g, const int* __restrict__ recs, int n_pairs, const int* __restrict__ head_of_leaf, int wy, int wz,
@@ -259,11 +256,6 @@ using namespace hns;
 // allocation (hns_grid_upload), sized for n_active = n_leaves, so nothing is allocated here.
 int hns_grid_upload_schedule(hns_grid* g) {
 	g->n_pairs = g->n_singles = 0;
-	{
-		std::lock_guard<std::mutex> lock(g->graph_mutex);
-		for (auto& e : g->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);  // captured launches hold the old lists
-		g->graphs.clear();
-	}
 	const int n = (int)g->n_active, first = (int)g->first_active;
 	if (n == 0) return HNS_OK;
 	// One chunk per XCD wins by a wide margin while the sweep arrays fit the Infinity Cache and its neighbourhood (256^3: 40 vs
@@ -291,7 +283,7 @@ int hns_grid_upload_schedule(hns_grid* g) {
 	g->n_singles = (uint64_t)h_totals[1];
 	k_write_pairs<<<n_blocks, 256, 0, 0>>>(nbr27, first, n, linear, pre, partner, block_heads, (int*)g->d_pairs);
 	HNS_HIP(hipDeviceSynchronize());
-	g->tiles_built = false;  // built when a solve first asks for the blocked or resident form (most grids never do)
+	g->tiles_built = false;  // built when a solve first asks for the blocked form (most grids never do)
 	g->sb_built = false;     // (likewise the block records of hns_sorblock.hip)
 	g->n_tile_groups = g->n_tile_rest = 0;
 	return HNS_OK;
@@ -300,7 +292,7 @@ int hns_grid_upload_schedule(hns_grid* g) {
 // Tile groups of the blocked SOR kernel for the current wave records (see k_group_assign). Tables live in the grid's arena:
 // d_tile_groups = n_tile_groups x kTileWaves record indices, d_tile_rest = the n_tile_rest records outside complete groups.
 int hns_grid_build_tiles(hns_grid* g) {
-	std::lock_guard<std::mutex> lock(g->graph_mutex);  // cooks from several host threads may share the grid
+	std::lock_guard<std::mutex> lock(g->build_mutex);  // cooks from several host threads may share the grid
 	if (g->tiles_built) return HNS_OK;
 	g->tiles_built = true;
 	g->n_tile_groups = g->n_tile_rest = 0;
@@ -319,8 +311,7 @@ int hns_grid_build_tiles(hns_grid* g) {
 	HNS_HIP(hipMemsetAsync(members, 0xFF, sizeof(int) * (size_t)np * w, 0));
 	HNS_HIP(hipMemsetAsync(totals, 0, 2 * sizeof(int), 0));
 	const int* recs = (const int*)g->d_pairs;
-	HNS_HIP(hipMemsetAsync(g->d_wave_of_leaf, 0xFF, sizeof(int) * (size_t)nl, 0));
-	k_head_index<<<nb, 256, 0, 0>>>(recs, np, head_of_leaf, (int*)g->d_wave_of_leaf);
+	k_head_index<<<nb, 256, 0, 0>>>(recs, np, head_of_leaf);
 	k_group_assign<<<nb, 256, 0, 0>>>(g->dev(), recs, np, head_of_leaf, kTileY, kTileZ, leader, members);
 	k_group_flags<<<nb, 256, 0, 0>>>(leader, members, np, w, lead_flag, rest_flag);
 	k_flag_counts<<<nb, 256, 0, 0>>>(lead_flag, np, counts);
@@ -353,7 +344,7 @@ int hns_grid_upload(hns_grid* g) {
 	const size_t n_blocks = (nl + 255) / 256;
 	auto pad = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
 	const size_t tw = (size_t)kTileY * kTileZ;
-	const size_t sz[12] = {pad(16 * nl),                        // origins (int4)
+	const size_t sz[10] = {pad(16 * nl),                        // origins (int4)
 	                       pad(4 * 27 * nl),                    // nbr27
 	                       pad(4 * (hash_size + 1)),            // hash + the duplicate-origin status word
 	                       pad(4 * nl),                         // sched
@@ -362,16 +353,13 @@ int hns_grid_upload(hns_grid* g) {
 	                       pad(4 * (nl + n_blocks + 2)),        // schedule-build scratch
 	                       pad(4 * nl),                         // tile groups: every record in at most one group
 	                       pad(4 * nl),                         // records outside complete groups
-	                       pad(4 * (nl * (5 + tw) + n_blocks + 2)),  // tile-build scratch (hns_grid_build_tiles)
-	                       pad(4 * nl),                         // wave record of every leaf
-	                       pad(4 * (nl + 1))};                  // resident SOR kernel: progress flag per wave record + one give-up word
+	                       pad(4 * (nl * (5 + tw) + n_blocks + 2))};  // scratch of the builds on first use (hns_grid_build_tiles, hns_grid_build_blocks)
 	size_t total = 0;
 	for (size_t s : sz) total += s;
 	HNS_TRY_RC(hns_arena_get(total, g->device, &g->d_arena, &g->arena_bytes));
 	char* q = (char*)g->d_arena;
-	void** slot[12] = {&g->d_origins, &g->d_nbr27, &g->d_hash, &g->d_sched_mem, &g->d_blk, &g->d_pairs, &g->d_scratch, &g->d_tile_groups, &g->d_tile_rest, &g->d_tile_mem,
-	                   &g->d_wave_of_leaf, &g->d_flags};
-	for (int i = 0; i < 12; ++i) {
+	void** slot[10] = {&g->d_origins, &g->d_nbr27, &g->d_hash, &g->d_sched_mem, &g->d_blk, &g->d_pairs, &g->d_scratch, &g->d_tile_groups, &g->d_tile_rest, &g->d_tile_mem};
+	for (int i = 0; i < 10; ++i) {
 		*slot[i] = q;
 		q += sz[i];
 	}
@@ -417,10 +405,6 @@ int hns_grid_host_tables(const hns_grid* cg) {
 void hns_grid_free_device(hns_grid* g) {
 	if (!g) return;
 	(void)hns_grid_release_cache(g);
-	for (auto& e : g->graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);
-	g->graphs.clear();
-	if (g->cap_stream) (void)hipStreamDestroy((hipStream_t)g->cap_stream);
-	g->cap_stream = nullptr;
 	if (g->d_sb_tab) hns_arena_put(g->d_sb_tab, g->sb_bytes, g->device);
 	g->d_sb_tab = nullptr;
 	g->sb_bytes = 0;
@@ -430,9 +414,7 @@ void hns_grid_free_device(hns_grid* g) {
 	g->d_arena = nullptr;
 	g->arena_bytes = 0;
 	g->d_origins = g->d_nbr27 = g->d_hash = g->d_sched = g->d_sched_mem = g->d_blk = g->d_pairs = g->d_scratch = nullptr;
-	g->d_tile_groups = g->d_tile_rest = g->d_tile_mem = g->d_wave_of_leaf = g->d_flags = nullptr;
-	if (g->h_status) (void)hipHostFree(g->h_status);
-	g->h_status = nullptr;
+	g->d_tile_groups = g->d_tile_rest = g->d_tile_mem = nullptr;
 	g->n_tile_groups = g->n_tile_rest = 0;
 	g->on_device = false;
 }

@@ -25,17 +25,16 @@ inline int fail(int code, const char* msg) {
 // ---- options (hns_set_option) -------------------------------------------------------------------------------------
 // Alternative kernel forms and data-movement strategies kept for A/B measurement and as cross-checks of the default one.
 // Every entry point reads the current value when it is called, so a test or benchmark can switch forms between calls.
-enum { kRbgsAuto = 0, kRbgsColor = 1, kRbgsWave = 2, kRbgsPair = 3, kRbgsResident = 4, kRbgsTile = 5, kRbgsBlock = 6 };
+enum { kRbgsAuto = 0, kRbgsColor = 1, kRbgsWave = 2, kRbgsPair = 3, kRbgsTile = 4, kRbgsBlock = 5 };
 enum { kScheduleAuto = 0, kScheduleLinear = 1, kScheduleChunk = 2 };
 struct Options {
-	std::atomic<int> rbgs{kRbgsAuto};          // "rbgs": auto | color | wave | pair | resident | tile | block
+	std::atomic<int> rbgs{kRbgsAuto};          // "rbgs": auto | color | wave | pair | tile | block
 	std::atomic<int> advect_generic{0};        // "advect": auto | generic (64-bit addressed kernels)
 	std::atomic<int> stencil_block{0};         // "stencil": auto | block (512-thread divergence / gradient)
 	std::atomic<int> schedule{kScheduleAuto};  // "schedule": auto | linear | chunk (read when launch tables are built)
 	std::atomic<int> schedule_segment{0};      // "schedule_segment": leaves per XCD segment of the launch order, 0 = by size
 	std::atomic<int> alternate{1};             // "alternate": odd SOR sweeps walk the records backwards
 	std::atomic<int> rev{1};                   // "rev": divergence / advect_scalars walk the leaves backwards
-	std::atomic<int> graph{0};                 // "graph": replay the pressure loop as a hipGraph
 	std::atomic<int> cook_cache{1};            // "cook_cache": operator calls keep their device buffers with the grid
 	std::atomic<int> cook_pipeline{1};         // "cook_pipeline": hns_compute_sim overlaps transfers with the substep
 	std::atomic<int> dist_wire_us{0};          // "dist_wire_us": loopback transport only, emulated time on the wire per exchange
@@ -101,16 +100,6 @@ __device__ __forceinline__ int launch_leaf(const GridDev& g, unsigned b) {
 	return g.sched ? g.sched[pos] : g.first + pos;
 }
 
-// a captured pressure loop (hipGraphExec_t) and the arguments it was captured for
-struct RbgsGraph {
-	const float* div;
-	float* p_a;
-	float* p_b;
-	float dx2, omega;
-	int iterations, mode;
-	void* exec;
-};
-
 }  // namespace hns
 
 struct hns_sim;
@@ -151,7 +140,7 @@ struct hns_grid {
 	void* d_tile_rest = nullptr;
 	void* d_tile_mem = nullptr;
 	uint64_t n_tile_groups = 0, n_tile_rest = 0;
-	bool tiles_built = false;  // d_tile_* / d_wave_of_leaf are filled on first use (hns_grid_build_tiles)
+	bool tiles_built = false;  // d_tile_* are filled on first use (hns_grid_build_tiles)
 	// temporally blocked SOR kernel (hns_sorblock.hip): records of the 16^3-voxel blocks in launch order (64 leaves under each tile),
 	// built on first use into an arena allocation of their own
 	void* d_sb_tab = nullptr;
@@ -159,15 +148,7 @@ struct hns_grid {
 	uint64_t n_sb = 0;
 	bool sb_built = false;
 	int sb_seg = 0;
-	// resident SOR kernel (whole pressure loop in one launch): wave record of every leaf, one progress flag per wave record, and
-	// a host-visible word a wave raises when it gives up waiting (hns_pressure.hip: k_rbgs_resident)
-	void* d_wave_of_leaf = nullptr;
-	void* d_flags = nullptr;
-	int* h_status = nullptr;
-	int resident_capacity = -1;  // wave records the chip can hold at once (-1: not asked yet)
-	std::vector<hns::RbgsGraph> graphs;  // cached hipGraph replays of the pressure loop (dropped when the schedule changes)
-	void* cap_stream = nullptr;          // private capture stream
-	std::mutex graph_mutex;              // guards graphs / cap_stream
+	std::mutex build_mutex;              // guards the tables built on first use (tile groups, block records): cooks from several host threads may share a grid
 	std::mutex host_mutex;               // guards the lazy host copy of the device-built tables and sim_cache
 	std::vector<hns_sim*> sim_cache;     // device-resident state kept between operator calls (hns_api.hip: make_sim)
 	hns::GridDev dev() const;

@@ -437,16 +437,10 @@ __device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __r
 	in.leaf1 = __builtin_amdgcn_readfirstlane(rec[28]);
 	const bool single = in.leaf1 < 0;
 	// below the lower leaf / above the top leaf (the top leaf is leaf0 itself when it travels alone)
-#if defined(HNS_EXP) && (HNS_EXP & 16)
-	const int n_zm = -1, n_zp = -1;
-#elif defined(HNS_EXP) && (HNS_EXP & 32)  // z halo read out of the wave's OWN leaves: same access pattern, no foreign lines
-	const int n_zm = in.leaf0, n_zp = single ? in.leaf0 : in.leaf1;
-#else
 	// (TILED: a face shared inside the workgroup counts as absent here -- the loads stay branch-free, hit the always-hot
 	// leaf 0 and are discarded; the real values arrive through LDS in pair_compute)
 	const int n_zm = (TILED && nb.zm >= 0) ? -1 : __builtin_amdgcn_readfirstlane(rec[1 + 12]);
 	const int n_zp = (TILED && nb.zp >= 0) ? -1 : __builtin_amdgcn_readfirstlane(single ? rec[1 + 14] : rec[28 + 1 + 14]);
-#endif
 	const int l = c.l;
 	const RowP zero_row = {{v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}}};
 	in.D0 = glb_rowp(div, in.leaf0, l), in.D1 = glb_rowp(div, in.leaf1, l);
@@ -455,10 +449,6 @@ __device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __r
 		in.zlo = in.zhi = make_float2(0.0f, 0.0f);
 	} else {
 		in.P0 = glb_rowp(p_in, in.leaf0, l), in.P1 = glb_rowp(p_in, in.leaf1, l);
-#if defined(HNS_EXP) && (HNS_EXP & 128)  // own rows first, halo only once they have landed (are the neighbours' lines in L2 by then?)
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		__builtin_amdgcn_sched_barrier(0);
-#endif
 		in.zlo = *reinterpret_cast<const float2*>(p_in + (size_t)(n_zm < 0 ? 0 : n_zm) * 512 + l * 8 + 6);
 		in.zhi = *reinterpret_cast<const float2*>(p_in + (size_t)(n_zp < 0 ? 0 : n_zp) * 512 + l * 8);
 		if (n_zm < 0) in.zlo = make_float2(0.0f, 0.0f);
@@ -485,13 +475,7 @@ __device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __r
 	// a y-face row of a neighbour inside the workgroup is that wave's own row: nothing to load or recompute (absent, as above)
 	const bool shared_duty = TILED && ((f == 2 && nb.ym >= 0) || (f == 3 && nb.yp >= 0));
 	const int n_f = shared_duty ? -1 : (c.w ? (single ? -1 : nf1) : nf0);
-#ifdef HNS_EXP  // timing experiments only (profiles/micro/exp): pretend some halo sources are absent; results are wrong
-	const int own_leaf = c.w ? (single ? in.leaf0 : in.leaf1) : in.leaf0;
-	const int n_f_p = ((HNS_EXP & 1) && f < 2) || ((HNS_EXP & 4) && f >= 2) ? -1 : (((HNS_EXP & 64) && f >= 2) ? own_leaf : n_f);
-	const int n_f_d = ((HNS_EXP & 2) && f < 2) || ((HNS_EXP & 8) && f >= 2) ? -1 : (((HNS_EXP & 64) && f >= 2) ? own_leaf : n_f);
-#else
 	const int n_f_p = n_f, n_f_d = n_f;
-#endif
 	const int srcA = f == 0 ? 56 + i : (f == 1 ? i : (f == 2 ? i * 8 + 7 : i * 8));
 	const int srcB = f == 0 ? 48 + i : (f == 1 ? 8 + i : (f == 2 ? i * 8 + 6 : i * 8 + 1));
 	in.f_ok = n_f >= 0;
@@ -504,11 +488,7 @@ __device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __r
 	in.HA = glb_rowp(p_in, n_f_p, srcA);
 	in.HB = glb_rowp(p_in, n_f_p, srcB);
 	// the halo row's own z-neighbour outside the pair: z=-1 for the lower leaf, z=8 for the upper leaf
-#ifdef HNS_EXP
-	const int n_e = (((HNS_EXP & 1) && f < 2) || ((HNS_EXP & 4) && f >= 2)) ? -1 : (c.w ? ne1 : ne0);
-#else
 	const int n_e = shared_duty ? -1 : (c.w ? ne1 : ne0);
-#endif
 	const float ev = p_in[(size_t)(n_e < 0 ? 0 : n_e) * 512 + srcA * 8 + (c.w ? 0 : 7)];
 	in.e_val = n_e < 0 ? 0.0f : ev;
 	// edge rows along z (lanes 0..7): tile rows (-1,-1), (-1,8), (8,-1), (8,8) of each leaf
@@ -521,8 +501,7 @@ __device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __r
 // TILED (k_rbgs_tile): `tiles` holds one tile per wave of the workgroup, S = tiles[own]. A face listed in `nb` is read out
 // of the neighbouring wave's tile -- its staged rows before the red sweep, its updated rows after it -- instead of being
 // loaded and recomputed here: the same values (a wave's recomputed halo reds ARE the neighbour's own reds), so the same bits.
-// Out: where the swept rows go -- StorePlain (16-byte stores to p_out) or, in the resident kernel, StoreResident (write-through
-// stores that other CUs can read inside the launch, and the rows kept for the next iteration).
+// Out: where the swept rows go -- StorePlain (16-byte stores to p_out), or StoreMirror for a multi-GPU rank (below).
 struct StorePlain {
 	float* __restrict__ p_out;
 	__device__ __forceinline__ void operator()(int leaf, int k, int l, const RowP& o) const {
@@ -754,156 +733,6 @@ __global__ __launch_bounds__(64 * kTileY * kTileZ) __attribute__((amdgpu_waves_p
 	nb.zm = __builtin_amdgcn_readfirstlane(nb.zm), nb.zp = __builtin_amdgcn_readfirstlane(nb.zp);
 	const PairIn in = pair_load<ZERO, true>(c, rec, div, p_in, nb);
 	pair_compute<true>(S, S[wv], c, in, nb, StorePlain{p_out}, dx2, omega);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// red-black SOR, resident form: the WHOLE pressure loop in one launch (grids of a few thousand leaves)
-// ---------------------------------------------------------------------------------------------------------------
-//
-// Below ~8k leaves a sweep is not bound by bandwidth but by the launch boundary and by one wave's load latency: 128^3 takes
-// 8.2 us per sweep, 64^3 4 us, for 1.5 / 0.2 us worth of HBM traffic. Here every wave record gets one wave for the whole
-// solve (all of them resident at once: at most 16 per CU by LDS, 4096 on the chip) and keeps its rows of p and div in
-// registers across iterations; what crosses between waves is the halo only, through the two p buffers in memory:
-//
-//   iteration k of a wave:  wait until every wave it reads from has published iteration k-1   (one flag per wave)
-//                           load the halo of p out of the k-1 buffer                         (loads that bypass L1: sc1)
-//                           sweep (pair_compute, the same arithmetic)                         -> bit-identical
-//                           store its rows to the k buffer with write-through stores (sc1), wait for them, publish k
-//
-// The same wait also covers the write-after-read hazard of the ping-pong: a wave overwrites the buffer its neighbours read
-// in iteration k-1 only after they have published k-1. There is no grid-wide barrier and no fence: payload stores are
-// write-through and payload loads skip L1 (MI355X_MICROARCH.md, inter-workgroup visibility: "sc1 stores and loads both
-// sides"), the flag is a relaxed agent-scope atomic polled by the lanes that own a neighbour. Every spin is bounded: a wave
-// that gives up raises *status and the host reports it (results are then undefined); it cannot hang the device.
-__device__ v4f hns_buffer_load_v4f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
-__device__ v2f hns_buffer_load_v2f32_p(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
-__device__ float hns_buffer_load_f32_p(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
-__device__ void hns_buffer_store_v4f32(v4f data, v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
-constexpr int kSc1 = 16;  // cache-policy bit of the raw buffer intrinsics on gfx942/gfx950: sc1 (bit 0: sc0, bit 1: nt)
-
-__device__ __forceinline__ v4i p_rsrc(const float* p, unsigned bytes) {
-	const unsigned long long a = (unsigned long long)p;
-	v4i r;
-	r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-	r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
-	r.z = __builtin_amdgcn_readfirstlane((int)bytes);
-	r.w = 0x00020000;
-	return r;
-}
-
-// row `row` of leaf `leaf` (< 0: zeros) through the descriptor, bypassing L1
-__device__ __forceinline__ RowP sc1_rowp(const v4i& r, int leaf, int row) {
-	const int off = ((leaf < 0 ? 0 : leaf) * 512 + row * 8) * 4;
-	const v4f a = hns_buffer_load_v4f32(r, off, 0, kSc1), b = hns_buffer_load_v4f32(r, off + 16, 0, kSc1);
-	const bool ok = leaf >= 0;
-	RowP o;
-	o.q[0] = v2f{ok ? a.x : 0.0f, ok ? a.y : 0.0f};
-	o.q[1] = v2f{ok ? a.z : 0.0f, ok ? a.w : 0.0f};
-	o.q[2] = v2f{ok ? b.x : 0.0f, ok ? b.y : 0.0f};
-	o.q[3] = v2f{ok ? b.z : 0.0f, ok ? b.w : 0.0f};
-	return o;
-}
-
-// the halo of p for one record out of the buffer behind `r` (what pair_load fetches besides the own rows and div)
-__device__ __forceinline__ void resident_halo(const PairLaneCtx& c, const int* __restrict__ rec, const v4i& r, PairIn& in) {
-	const bool single = in.leaf1 < 0;
-	const int l = c.l;
-	const int n_zm = __builtin_amdgcn_readfirstlane(rec[1 + 12]);
-	const int n_zp = __builtin_amdgcn_readfirstlane(single ? rec[1 + 14] : rec[28 + 1 + 14]);
-	const v2f lo = hns_buffer_load_v2f32_p(r, ((n_zm < 0 ? 0 : n_zm) * 512 + l * 8 + 6) * 4, 0, kSc1);
-	const v2f hi = hns_buffer_load_v2f32_p(r, ((n_zp < 0 ? 0 : n_zp) * 512 + l * 8) * 4, 0, kSc1);
-	in.zlo = n_zm < 0 ? make_float2(0.0f, 0.0f) : make_float2(lo.x, lo.y);
-	in.zhi = n_zp < 0 ? make_float2(0.0f, 0.0f) : make_float2(hi.x, hi.y);
-	const int f = (l >> 3) & 3, i = l & 7;
-	const int* __restrict__ r0 = rec + 1;
-	const int* __restrict__ r1 = rec + (single ? 1 : 29);
-	const int a0 = r0[4], a1 = r0[22], a2 = r0[10], a3 = r0[16];
-	const int b0 = r1[4], b1 = r1[22], b2 = r1[10], b3 = r1[16];
-	const int c0 = r0[3], c1 = r0[21], c2 = r0[9], c3 = r0[15];
-	const int d0 = r1[5], d1 = r1[23], d2 = r1[11], d3 = r1[17];
-	const int nf0 = f == 0 ? a0 : (f == 1 ? a1 : (f == 2 ? a2 : a3));
-	const int nf1 = f == 0 ? b0 : (f == 1 ? b1 : (f == 2 ? b2 : b3));
-	const int ne0 = f == 0 ? c0 : (f == 1 ? c1 : (f == 2 ? c2 : c3));
-	const int ne1 = f == 0 ? d0 : (f == 1 ? d1 : (f == 2 ? d2 : d3));
-	const int n_f = c.w ? (single ? -1 : nf1) : nf0;
-	const int srcA = f == 0 ? 56 + i : (f == 1 ? i : (f == 2 ? i * 8 + 7 : i * 8));
-	const int srcB = f == 0 ? 48 + i : (f == 1 ? 8 + i : (f == 2 ? i * 8 + 6 : i * 8 + 1));
-	in.HA = sc1_rowp(r, n_f, srcA);
-	in.HB = sc1_rowp(r, n_f, srcB);
-	const int n_e = c.w ? ne1 : ne0;
-	const float ev = hns_buffer_load_f32_p(r, ((n_e < 0 ? 0 : n_e) * 512 + srcA * 8 + (c.w ? 0 : 7)) * 4, 0, kSc1);
-	in.e_val = n_e < 0 ? 0.0f : ev;
-	const int n_er = (single && c.ew) ? -1 : rec[28 * c.ew + 1 + (c.ea ? 2 : 0) * 9 + (c.eb ? 2 : 0) * 3 + 1];
-	if (l < 8) in.ER = sc1_rowp(r, n_er, (c.ea ? 0 : 7) * 8 + (c.eb ? 0 : 7));
-}
-
-struct StoreResident {
-	v4i rsrc;
-	RowP* keep;  // [2]: the rows just swept, the next iteration's own rows
-	__device__ __forceinline__ void operator()(int leaf, int k, int l, const RowP& o) const {
-		keep[k] = o;
-		const int off = (leaf * 512 + l * 8) * 4;
-		hns_buffer_store_v4f32(v4f{o.q[0].x, o.q[0].y, o.q[1].x, o.q[1].y}, rsrc, off, 0, kSc1);
-		hns_buffer_store_v4f32(v4f{o.q[2].x, o.q[2].y, o.q[3].x, o.q[3].y}, rsrc, off + 16, 0, kSc1);
-	}
-};
-
-constexpr unsigned kResidentSpinLimit = 400000;  // polls (each >= ~0.5 us): a stuck solve gives up within a fraction of a second
-
-template <bool ZERO>
-__global__ __launch_bounds__(64) void k_rbgs_resident(const int* __restrict__ pairs, const int* __restrict__ wave_of_leaf, const float* __restrict__ div, float* p_a,
-                                                      float* p_b, const unsigned p_bytes, const float dx2, const float omega, const int iterations, unsigned* flags,
-                                                      unsigned* gave_up, int* status) {
-	__shared__ __attribute__((aligned(16))) PairTile S;
-	const PairLaneCtx c = pair_lane_ctx(threadIdx.x);
-	const int* __restrict__ rec = pairs + (size_t)blockIdx.x * 56;
-	const TileNbr nb = {-1, -1, -1, -1, false};
-	// the waves this one reads from: lane i < 54 looks after neighbour slot i % 27 of leaf i / 27 (a few waves appear twice)
-	const int l = c.l;
-	int watch = -1;
-	if (l < 54) {
-		const int leaf = rec[28 * (l / 27)];
-		const int nl = leaf < 0 ? -1 : rec[28 * (l / 27) + 1 + l % 27];
-		if (nl >= 0) watch = wave_of_leaf[nl];
-		if (watch == (int)blockIdx.x) watch = -1;
-	}
-	// iteration 0 reads what earlier launches wrote (or nothing: ZERO); from then on a wave's own rows stay in registers, its
-	// div rows are re-read (they never change and sit in L2: cheaper than 24 registers held across the loop)
-	RowP keep[2];
-	for (int k = 0; k < iterations; ++k) {
-		float* src = (k & 1) ? p_b : p_a;
-		float* dst = (k & 1) ? p_a : p_b;
-		PairIn in;
-		if (k == 0) {
-			in = pair_load<ZERO, false>(c, rec, div, p_a, nb);
-		} else {
-			unsigned spins = 0;
-			bool ready = false;
-			while (!ready) {
-				const unsigned seen = watch < 0 ? (unsigned)k : __hip_atomic_load(flags + watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				ready = __all(seen >= (unsigned)k);
-				if (!ready) {
-					__builtin_amdgcn_s_sleep(1);
-					// give up when this wave has waited far too long, or (looked at now and then) when another wave has
-					if (++spins > kResidentSpinLimit || ((spins & 255u) == 0 && __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-						if (l == 0) {
-							__hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-							__hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // host-visible
-						}
-						return;
-					}
-				}
-			}
-			asm volatile("" ::: "memory");  // the halo loads below stay below the poll
-			in = pair_load<true, false>(c, rec, div, src, nb);  // div rows and the record's flags; every p row zero so far
-			in.P0 = keep[0], in.P1 = keep[1];
-			resident_halo(c, rec, p_rsrc(src, p_bytes), in);
-		}
-		pair_compute<false>(&S, S, c, in, nb, StoreResident{p_rsrc(dst, p_bytes), keep}, dx2, omega);
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left this CU ...
-		__syncthreads();                                  // (one wave: orders the LDS tile against the next iteration's staging)
-		if (l == 0) __hip_atomic_store(flags + blockIdx.x, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ... then the flag
-	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1145,7 +974,6 @@ static int rbgs_form(hns_grid* g, int opt) {
 	if (!g->d_pairs) return kRbgsWave;
 	if (opt == kRbgsPair) return kRbgsPair;
 	if (opt == kRbgsTile) return (hns_grid_build_tiles(g) == HNS_OK && g->d_tile_groups) ? kRbgsTile : kRbgsPair;
-	if (opt == kRbgsResident) return kRbgsPair;  // (the resident form is a property of a whole solve: hns_rbgs_iterate decides)
 	// (<= 2048: also the boundary range of a multi-GPU rank, a few thousand leaves swept next to the interior launch)
 	if (g->n_active <= 2048 || (g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs)) return kRbgsWave;
 	// far beyond the Infinity Cache the halo of leaves swept elsewhere on the chip is what costs: blocked form where most
@@ -1217,48 +1045,12 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 	}
 	const float dx2 = dx * dx;  // Kernel.cu:608
 	const GridDev gd = g->dev();
-	// Small grids: the whole loop in one launch, every wave record resident for the length of the solve (k_rbgs_resident).
-	{
-		const int opt = options().rbgs.load();
-		// Opt-in only: measured on MI355X it LOSES to one launch per iteration (64^3: 5.7 us per iteration against 4.0-4.2; a wave
-		// pays three dependent memory round trips per iteration -- flag poll, halo loads that bypass L1, write-through drain --
-		// where a kernel boundary costs 1.7 us), as MI355X_MICROARCH.md's hand-off price list predicts. Kept as the measured answer
-		// to "one launch for the whole loop", bit-identical (tests/test_resident_gpu.py).
-		const bool wanted = opt == kRbgsResident;
-		if (wanted && iterations >= 2 && g->d_pairs && g->n_pairs > 0 && !options().graph.load() && hns_grid_build_tiles(g) == HNS_OK && g->d_wave_of_leaf) {
-			if (g->resident_capacity < 0) {
-				int per_cu = 0, cus = 0;
-				hipDeviceProp_t prop;
-				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rbgs_resident<false>, 64, 0) == hipSuccess && hipGetDeviceProperties(&prop, g->device) == hipSuccess)
-					cus = prop.multiProcessorCount;
-				g->resident_capacity = per_cu * cus;
-				if (!g->h_status && hipHostMalloc((void**)&g->h_status, sizeof(int), hipHostMallocMapped) == hipSuccess) *g->h_status = 0;
-			}
-			// (a margin: the occupancy query can be one block per CU optimistic, MI355X_MICROARCH.md "Residency")
-			if (g->h_status && (int64_t)g->n_pairs <= (int64_t)g->resident_capacity - g->resident_capacity / 8) {
-				if (*g->h_status != 0) {
-					*g->h_status = 0;
-					return fail(HNS_ERR_HIP, "hns_dev_rbgs_iterate: an earlier resident pressure solve on this grid gave up waiting for a neighbouring wave; its result was undefined");
-				}
-				hipStream_t st = (hipStream_t)stream;
-				HNS_HIP(hipMemsetAsync(g->d_flags, 0, sizeof(unsigned) * (g->n_pairs + 1), st));  // progress flags + the device-side give-up word
-				const unsigned p_bytes = (unsigned)(sizeof(float) * 512 * (size_t)g->topo.n_leaves);
-				if (from_zero)
-					hipLaunchKernelGGL(k_rbgs_resident<true>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, (const int*)g->d_wave_of_leaf, div, p_a, p_b, p_bytes,
-					                   dx2_of(dx), omega, iterations, (unsigned*)g->d_flags, (unsigned*)g->d_flags + g->n_pairs, g->h_status);
-				else
-					hipLaunchKernelGGL(k_rbgs_resident<false>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, (const int*)g->d_wave_of_leaf, div, p_a, p_b, p_bytes,
-					                   dx2_of(dx), omega, iterations, (unsigned*)g->d_flags, (unsigned*)g->d_flags + g->n_pairs, g->h_status);
-				return launch_status("hns_dev_rbgs_iterate");
-			}
-		}
-	}
 	// Temporally blocked form (hns_sorblock.hip): k iterations per launch, p read and written once per launch. An odd iteration
 	// left over goes through the one-iteration form below.
 	{
 		const int opt = options().rbgs.load();
 		int k_max = 0;
-		const int lb = (iterations >= 2 && !options().graph.load() && (opt == kRbgsBlock || (opt == kRbgsAuto && rbgs_auto_block(g)))) ? hns_rbgs_block_shape(g, &k_max) : 0;
+		const int lb = (iterations >= 2 && (opt == kRbgsBlock || (opt == kRbgsAuto && rbgs_auto_block(g)))) ? hns_rbgs_block_shape(g, &k_max) : 0;
 		if (lb) {
 			float* src = p_a;
 			float* dst = p_b;
@@ -1283,63 +1075,12 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 		HNS_HIP(hipMemsetAsync(p_a, 0, sizeof(float) * 512 * (size_t)g->topo.n_leaves, (hipStream_t)stream));
 		from_zero = false;
 	}
-	const int mode = form | (from_zero ? 256 : 0);  // graph-cache key: kernel form + whether the first sweep skips p_a
 	// Odd sweeps walk the record list backwards: a sweep ends with the tail of p / div in the Infinity Cache and the next one
 	// begins there. Nothing below the cache size, -11 % at 288^3 (287 MB of sweep arrays against 256 MB of cache), -6 % at
 	// 320^3, -1.4 % at 512^3 (profiles/micro/sor_schedule.py). The result does not depend on the order. Option "alternate" = 0: off.
+	// (Replaying the loop as a hipGraph was measured neutral at every size -- 64^3 4.11 vs 4.14 us per sweep, 256^3 39.2 vs 39.1: the
+	// eager loop is never launch-bound -- and removed in round 3.)
 	const bool alternate = options().alternate.load() != 0;
-	const bool use_graph = options().graph.load() != 0;
-
-	// Optional (option "graph" = 1): replay the loop as one hipGraph, captured once per (buffers, parameters) on a private stream
-	// and cached in the grid. Off by default: measured on MI355X the eager loop is never launch-bound (64^3: 4.11 vs
-	// 4.14 us per sweep, 128^3: 8.3 vs 8.2, 256^3: 39.2 vs 39.1 with / without the graph), and stream capture is
-	// fragile when several host threads cook at once (a legacy-stream call in another thread fails while a capture is open).
-	if (use_graph && iterations >= 4) {
-		std::lock_guard<std::mutex> lock(g->graph_mutex);  // cooks from several threads may share one grid
-		hns::RbgsGraph* hit = nullptr;
-		for (auto& e : g->graphs)
-			if (e.div == div && e.p_a == p_a && e.p_b == p_b && e.dx2 == dx2 && e.omega == omega && e.iterations == iterations && e.mode == mode) hit = &e;
-		if (!hit) {
-			// Capture can fail through no fault of this call: on this runtime a synchronising HIP call made by ANOTHER host
-			// thread (a cook on a different grid) invalidates a thread-local capture. Any failure here drops the capture
-			// stream and falls through to the eager loop below; the next call tries again.
-			hipGraphExec_t exec = nullptr;
-			bool ok = g->cap_stream || hipStreamCreateWithFlags((hipStream_t*)&g->cap_stream, hipStreamNonBlocking) == hipSuccess;
-			hipStream_t cs = (hipStream_t)g->cap_stream;
-			if (ok) ok = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess;
-			if (ok) {
-				float* src = p_a;
-				float* dst = p_b;
-				for (int it = 0; it < iterations; ++it) {
-					if (launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, form, cs, from_zero && it == 0, alternate && (it & 1)) != HNS_OK) ok = false;
-					float* tmp = src;
-					src = dst;
-					dst = tmp;
-				}
-				hipGraph_t graph = nullptr;
-				ok = hipStreamEndCapture(cs, &graph) == hipSuccess && graph;
-				if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
-				if (graph) (void)hipGraphDestroy(graph);
-			}
-			if (ok) {
-				if (g->graphs.size() >= 8) {  // small cache: drop the oldest
-					(void)hipGraphExecDestroy((hipGraphExec_t)g->graphs.front().exec);
-					g->graphs.erase(g->graphs.begin());
-				}
-				g->graphs.push_back(hns::RbgsGraph{div, p_a, p_b, dx2, omega, iterations, mode, (void*)exec});
-				hit = &g->graphs.back();
-			} else {
-				(void)hipGetLastError();
-				if (g->cap_stream) (void)hipStreamDestroy((hipStream_t)g->cap_stream);
-				g->cap_stream = nullptr;
-			}
-		}
-		if (hit) {
-			HNS_HIP(hipGraphLaunch((hipGraphExec_t)hit->exec, (hipStream_t)stream));
-			return HNS_OK;
-		}
-	}
-
 	float* src = p_a;
 	float* dst = p_b;
 	for (int it = 0; it < iterations; ++it) {
@@ -1356,7 +1097,7 @@ int hns_grid_rbgs_plan(hns_grid* g, int iterations, char* description, uint64_t 
 	if (iterations < 0) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_rbgs_plan: negative iteration count");
 	const int opt = options().rbgs.load();
 	int k_max = 0;
-	const int lb = (iterations >= 2 && !options().graph.load() && (opt == kRbgsBlock || (opt == kRbgsAuto && rbgs_auto_block(g)))) ? hns_rbgs_block_shape(g, &k_max) : 0;
+	const int lb = (iterations >= 2 && (opt == kRbgsBlock || (opt == kRbgsAuto && rbgs_auto_block(g)))) ? hns_rbgs_block_shape(g, &k_max) : 0;
 	char buf[256];
 	int n = iterations, k = 1;
 	if (lb) {
@@ -1370,8 +1111,8 @@ int hns_grid_rbgs_plan(hns_grid* g, int iterations, char* description, uint64_t 
 	} else {
 		const int form = rbgs_form(g, opt == kRbgsBlock ? kRbgsAuto : opt);
 		const char* names[] = {"?", "k_rbgs_color: two launches per iteration, in place (the reference's decomposition)", "k_rbgs_wave: one launch = one red+black iteration, one wave per leaf",
-		                       "k_rbgs_pair: one launch = one red+black iteration, one wave per z-adjacent leaf pair", "k_rbgs_resident", "k_rbgs_tile: one launch = one red+black iteration, 2 x 2 wave records per workgroup"};
-		snprintf(buf, sizeof(buf), "%s", names[form >= 0 && form <= 5 ? form : 0]);
+		                       "k_rbgs_pair: one launch = one red+black iteration, one wave per z-adjacent leaf pair", "k_rbgs_tile: one launch = one red+black iteration, 2 x 2 wave records per workgroup"};
+		snprintf(buf, sizeof(buf), "%s", names[form >= 0 && form <= 4 ? form : 0]);
 		if (form == kRbgsColor) n = 2 * iterations;
 	}
 	if (description && description_bytes) snprintf(description, description_bytes, "%s", buf);

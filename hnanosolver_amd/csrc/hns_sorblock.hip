@@ -64,17 +64,6 @@ struct SbGeo {
 
 constexpr float kInv6 = 0.166666667f;  // Kernel.cu:609
 
-#ifdef HNS_SB_TRACE  // timing experiments only (profiles/micro/sb_trace.py): s_memtime stamps of the first thread of workgroups HNS_SB_TRACE .. +63
-__device__ unsigned long long g_sb_trace[64 * 16];
-#define SB_STAMP(n)                                                                              \
-	do {                                                                                         \
-		if (blockIdx.x >= HNS_SB_TRACE && blockIdx.x < HNS_SB_TRACE + 64 && (threadIdx.x == 0)) g_sb_trace[(blockIdx.x - HNS_SB_TRACE) * 16 + (n)] = __builtin_readcyclecounter(); \
-	} while (0)
-#else
-#define SB_STAMP(n) \
-	do {            \
-	} while (0)
-#endif
 
 // a thread's z-row for the length of the launch, split by colour (static indexing only: the arrays live in registers)
 template <int HALF, int C>
@@ -151,7 +140,6 @@ __device__ __forceinline__ void sb_sweep(Row& r, SbLds<LB, K>& L, const int i, c
 		}
 	}
 	if (S < 2 * K) __syncthreads();
-	SB_STAMP(4 + S);
 }
 
 template <int LB, int K, int S, bool PAR, bool MASKED>
@@ -169,7 +157,6 @@ __device__ __forceinline__ void sb_body(SbLds<LB, K>& L, const int t, const int*
                                         float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega) {
 	using G = SbGeo<LB, K>;
 	constexpr int H = G::H, T = G::T, C = G::C, HALF = G::HALF, NQ = G::NQ, NCH = G::NCH, HS4 = G::HS4;
-	SB_STAMP(0);
 	// thread t of the section: the t-th row of this parity among the rows inside the rim, x = 1.., y = 1..
 	const bool valid = t < G::CROWS;  // (the last wave of a section has lanes without a row)
 	const int xq = valid ? t / G::HC : 0;
@@ -188,7 +175,6 @@ __device__ __forceinline__ void sb_body(SbLds<LB, K>& L, const int t, const int*
 		r.ok[cz] = id >= 0 ? 0xFFFFFFFFu : 0u;
 		base[cz] = (unsigned)id * 2048u + row_bytes;
 	}
-	SB_STAMP(1);
 	const sb4i rp = sb_rsrc(p_in, field_bytes), rd = sb_rsrc(div, field_bytes), ro = sb_rsrc(p_out, field_bytes);
 	sb4f pc[NCH], dc[NCH];
 #pragma unroll
@@ -228,7 +214,6 @@ __device__ __forceinline__ void sb_body(SbLds<LB, K>& L, const int t, const int*
 			LK[q] = make_float4(rb[4 * q], rb[4 * q + 1], 4 * q + 2 < HALF ? rb[4 * q + 2] : 0.0f, 4 * q + 3 < HALF ? rb[4 * q + 3] : 0.0f);
 		}
 	}
-	SB_STAMP(2);
 	// split by colour: even z of a row with even x+y are red (colour = (x + y + z) & 1, Kernel.cu:599-601)
 #pragma unroll
 	for (int j = 0; j < NCH; ++j) {
@@ -238,7 +223,6 @@ __device__ __forceinline__ void sb_body(SbLds<LB, K>& L, const int t, const int*
 		r.dR[2 * j] = PAR ? d1 : d0, r.dB[2 * j] = PAR ? d0 : d1;
 		r.dR[2 * j + 1] = PAR ? d3 : d2, r.dB[2 * j + 1] = PAR ? d2 : d3;
 	}
-	SB_STAMP(3);
 	if (valid) {
 		float4* LR = L.a[PAR ? 1 : 0][0] + i * HS4;
 		float4* LK = L.a[PAR ? 1 : 0][1] + i * HS4;
@@ -254,12 +238,10 @@ __device__ __forceinline__ void sb_body(SbLds<LB, K>& L, const int t, const int*
 #pragma unroll
 	for (int cz = 0; cz < C; ++cz) mine = mine && (r.ok[cz] != 0u || !valid);
 	const bool all_present = __syncthreads_and(mine) != 0;
-	SB_STAMP(4);
 	if (all_present)
 		SbSweeps<LB, K, 1, PAR, false>::run(r, L, i, b, dist, omega);
 	else
 		SbSweeps<LB, K, 1, PAR, true>::run(r, L, i, b, dist, omega);
-	SB_STAMP(5 + 2 * K);
 	if (dist >= H) {  // the rows of the block itself
 #pragma unroll
 		for (int j = H / 4; j < NCH - H / 4; ++j) {
@@ -270,10 +252,6 @@ __device__ __forceinline__ void sb_body(SbLds<LB, K>& L, const int t, const int*
 			sb_store4(v, ro, (int)(base[cz] + (unsigned)(zl * 4)), 0, 0);
 		}
 	}
-#ifdef HNS_SB_TRACE
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-	SB_STAMP(6 + 2 * K);
 }
 
 // recs: one record per workgroup, in launch order. LB = 1: {leaf, nbr27[27]} (the grid's d_blk); LB = 2: the 4 x 4 x 4 leaves
@@ -349,7 +327,7 @@ using namespace hns;
 // Block records of the 16^3 form for the whole grid, built on first use (most small grids never ask). The table comes
 // out of the arena pool and goes back with the grid.
 int hns_grid_build_blocks(hns_grid* g) {
-	std::lock_guard<std::mutex> lock(g->graph_mutex);
+	std::lock_guard<std::mutex> lock(g->build_mutex);
 	const int seg = options().sor_block_seg.load();
 	if (g->sb_built && g->sb_seg == seg) return HNS_OK;
 	if (g->d_sb_tab) hns_arena_put(g->d_sb_tab, g->sb_bytes, g->device);
@@ -413,17 +391,3 @@ int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const fl
 	return HNS_OK;
 }
 
-#ifdef HNS_SB_TRACE
-extern "C" int hns_sb_occupancy(int which) {
-	int n = -1;
-	if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rbgs_block<2, 2, false>, SbGeo<2, 2>::NT, 0);
-	if (which == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rbgs_block<1, 2, false>, SbGeo<1, 2>::NT, 0);
-	if (which == 2) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rbgs_block<1, 4, false>, SbGeo<1, 4>::NT, 0);
-	return n;
-}
-extern "C" int hns_sb_trace_read(unsigned long long* out) {
-	HNS_HIP(hipDeviceSynchronize());
-	HNS_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(hns::g_sb_trace), sizeof(unsigned long long) * 64 * 16));
-	return HNS_OK;
-}
-#endif

@@ -132,7 +132,7 @@ struct OptionDesc {
 	std::atomic<int> Options::*field;
 	const char* const* words;  // value words, index = stored value; nullptr: a non-negative integer
 };
-const char* const kWordsRbgs[] = {"auto", "color", "wave", "pair", "resident", "tile", "block", nullptr};
+const char* const kWordsRbgs[] = {"auto", "color", "wave", "pair", "tile", "block", nullptr};
 const char* const kWordsAdvect[] = {"auto", "generic", nullptr};
 const char* const kWordsStencil[] = {"auto", "block", nullptr};
 const char* const kWordsSchedule[] = {"auto", "linear", "chunk", nullptr};
@@ -145,7 +145,6 @@ const OptionDesc kOptions[] = {
     {"schedule", &Options::schedule, kWordsSchedule},
     {"alternate", &Options::alternate, kWordsBool},
     {"rev", &Options::rev, kWordsBool},
-    {"graph", &Options::graph, kWordsBool},
     {"cook_cache", &Options::cook_cache, kWordsBool},
     {"cook_pipeline", &Options::cook_pipeline, kWordsBool},
     {"sor_block_lb", &Options::sor_block_lb, nullptr},

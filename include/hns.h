@@ -24,9 +24,11 @@
  * synchronous: it returns after the stream has drained, like the reference's cudaStreamSynchronize at the end of
  * each driver (HNanoSolver.cu:371, PressureProjection.cu:72, Advection.cu:99-103,158).
  *
- * Threading: like the reference's entry points there is no global state; hns_last_error() is thread-local. One grid may
- * be used by several host threads at once (Houdini cooks verbs concurrently): each operator call works on its own
- * device buffers -- the set kept with the grid if it is free, a private one otherwise.
+ * Threading: hns_last_error() is thread-local, and one grid may be used by several host threads at once (Houdini cooks verbs
+ * concurrently): each operator call works on its own device buffers -- the set kept with the grid if it is free, a private one
+ * otherwise. Process-wide state, unlike the reference's entry points (which have none): the options of hns_set_option (atomics,
+ * read by every entry point when it is called -- switch them while no call is in flight) and the pool of idle device
+ * allocations (hns_trim_memory; internally locked).
  *
  * There is no CPU fallback: without a usable HIP device every compute entry point fails with HNS_ERR_NO_DEVICE.
  */
@@ -60,18 +62,19 @@ int hns_trim_memory(void);
  * (all of them produce the same bits; tests/test_kernel_variants_gpu.py). Process-wide, read by every entry point when it
  * is called. value = NULL restores the default. Names and values:
  *   "rbgs"          auto | color (two launches per iteration) | wave (one wave per leaf) | pair (one wave per z-adjacent leaf
- *                   pair) | tile (y / z neighbouring pairs share a workgroup and their faces) | resident (whole pressure
- *                   loop in one launch, small grids)
+ *                   pair) | tile (y / z neighbouring pairs share a workgroup and their faces) | block (temporally blocked: several
+ *                   iterations per launch on a block of leaves with a halo, hns_sorblock.hip). auto: by grid size
+ *   "sor_block_lb"  0 = by size | 1 | 2: block edge of the temporally blocked form, in leaves
+ *   "sor_block_k"   0 = by shape | 2 | 4: its iterations per launch (4: one-leaf blocks only)
+ *   "sor_block_seg" N: its blocks per XCD segment of the launch order (0: one chunk per XCD; read when the block table is built)
  *   "advect"        auto | generic (64-bit addressed advection kernels)
  *   "stencil"       auto | block (512-thread divergence and gradient kernels)
  *   "schedule"      auto | linear | chunk (workgroup -> leaf order; takes effect when a grid's launch tables are next built)
  *   "schedule_segment" N leaves per XCD segment of the launch order under "schedule" = auto (0 = by grid size)
  *   "alternate"     1 | 0 (odd SOR sweeps walk the wave records backwards)
  *   "rev"           1 | 0 (divergence and advect_scalars walk the leaves backwards)
- *   "graph"         0 | 1 (replay the pressure loop as a hipGraph)
  *   "cook_cache"    1 | 0 (operator calls keep their device buffers with the grid)
  *   "cook_pipeline" 1 | 0 (hns_compute_sim overlaps its transfers with the substep)
- *   "sor_block"     0 = auto | N leaf pairs per workgroup of the SOR kernel
  *   "sor_lds_pad"   N: extra LDS bytes per wave of the pair SOR kernel (fewer waves in flight; an experiment)
  *   "dist_wire_us"  N: the loopback transport of hns_dist holds every exchange N microseconds (emulated wire time)
  *   "dist_chain"    1 | 0: with dist_mirror, every kernel of the substep of such a rank delivers its own halo (no exchanges at all

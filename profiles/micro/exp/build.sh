@@ -1,12 +1,22 @@
 #!/bin/bash
-# builds libhns_exp<mask>.so next to this script: the product sources with -DHNS_EXP=<mask> (see hns_pressure.hip: pair_load)
-cd "$(dirname "$0")/../../../hnanosolver_amd/csrc"
-# an argument of the form name:-Dflag[,-Dflag...] builds libhns_<name>.so with those flags instead
-for m in "$@"; do
-  flags="-DHNS_EXP=$m"; name="exp$m"
-  case "$m" in *:*) name="${m%%:*}"; flags="$(echo "${m#*:}" | tr ',' ' ')";; esac
-  out=../../profiles/micro/exp/libhns_$name.so
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -I../../include $flags -x hip \
-     hns_topology.cpp hns_nanovdb.cpp hns_leafio.cpp hns_gridbuild.hip hns_advect.hip hns_pressure.hip hns_pointwise.hip hns_api.hip hns_dist.hip -shared -pthread -ldl -o $out &
+# Experiment builds of libhns: the product sources plus ONE of the patches in this directory (timing switches and instrumentation live
+# here, not in the product kernels), compiled with extra -D flags into profiles/micro/exp/libhns_<name>.so (load with HNS_LIBRARY=...).
+#   build.sh <name> <patch file or -> [-Dflag ...]
+#     build.sh halo4   sor_halo_exp.patch   -DHNS_EXP=4           # pair SOR kernel without its y-face halo (results wrong, timing only)
+#     build.sh trace   sorblock_trace.patch -DHNS_SB_TRACE=2048   # s_memtime stamps of workgroups 2048..2111 (profiles/micro/sb_trace.py)
+#     build.sh p4      advect_p4.patch      -DHNS_EXP_P4          # velocity gathered out of a float4-padded copy
+set -e
+here="$(cd "$(dirname "$0")" && pwd)"; src="$here/../../../hnanosolver_amd/csrc"
+name=$1; patch=$2; shift 2
+tmp=$(mktemp -d); cp "$src"/*.hip "$src"/*.hpp "$src"/*.cpp "$tmp"/
+[ "$patch" != "-" ] && (cd "$tmp" && patch -s -p0 < "$here/$patch")
+cd "$tmp"
+objs=""
+for f in hns_topology.cpp hns_nanovdb.cpp hns_leafio.cpp hns_gridbuild.hip hns_advect.hip hns_pressure.hip hns_sorblock.hip hns_pointwise.hip hns_api.hip hns_dist.hip; do
+  extra=""; [ "$f" = hns_sorblock.hip ] && extra="-fno-slp-vectorize"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -I"$src/../../include" $extra "$@" -x hip -c $f -o $f.o &
+  objs="$objs $f.o"
 done
 wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o "$here/libhns_$name.so" $objs -ldl
+rm -rf "$tmp"; echo "$here/libhns_$name.so"

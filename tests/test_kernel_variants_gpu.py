@@ -48,13 +48,11 @@ VARIANTS = {
     "sor_two_launches_per_iteration": {"rbgs": "color"},  # the reference's own decomposition
     "sor_wave_per_leaf": {"rbgs": "wave"},
     "sor_wave_per_leaf_pair": {"rbgs": "pair"},  # the production form at scale; small grids default to one wave per leaf
-    "sor_resident": {"rbgs": "resident"},  # whole pressure loop in one launch
     "sor_blocked": {"rbgs": "tile"},  # wave records that are y / z neighbours share a workgroup and their faces
     # temporally blocked (hns_sorblock.hip; small grids take it by default): K iterations per launch on blocks of 1 / 8 leaves
     "sor_two_iterations_per_launch_leaf_blocks": {"rbgs": "block", "sor_block_lb": "1", "sor_block_k": "2"},
     "sor_four_iterations_per_launch_leaf_blocks": {"rbgs": "block", "sor_block_lb": "1", "sor_block_k": "4"},
     "sor_two_iterations_per_launch_16cube_blocks": {"rbgs": "block", "sor_block_lb": "2", "sor_block_k": "2"},
-    "sor_graph_replay": {"graph": "1"},
     "schedule_linear": {"schedule": "linear"},
     "sor_one_direction": {"alternate": "0", "rbgs": "pair"},
     "all_kernels_forwards": {"rev": "0"},
