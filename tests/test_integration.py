@@ -157,3 +157,28 @@ def test_reference_side_shim_runs_and_matches_the_python_path(tmp_path):
 
     # (the program prints ten significant digits of position-weighted sums over 100k values: any differing value shows)
     assert np.isclose(nums[0][0], checksum(d.pValues("vel")), rtol=2e-9, atol=0) and np.isclose(nums[0][1], checksum(d.pValues("density")), rtol=2e-9, atol=0)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/SOP"), reason="needs the reference checkout")
+def test_port_script_matches_every_anchor_of_the_reference_checkout(tmp_path):
+    """integration/port_reference.py = the reference-side edits of integration/hns_shim.cpp as an executable list, anchored on file,
+    line and expected token. Applied to a temporary copy of the reference's src/SOP + src/Utils: every anchor matches, no CUDA
+    identifier is left in the code of the edited files, and the six entry-point declarations now carry the shim's types."""
+    import importlib.util
+    import shutil
+
+    spec = importlib.util.spec_from_file_location("port_reference", os.path.join(ROOT, "integration", "port_reference.py"))
+    port = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(port)
+    dst = tmp_path / "ref"
+    for sub in ("src/SOP", "src/Utils"):
+        shutil.copytree(os.path.join("/root/reference", sub), dst / sub)
+    n, problems = port.apply(str(dst), write=False)
+    assert not problems and n == len(port.EDITS), problems
+    n, problems = port.apply(str(dst), write=True)
+    assert not problems and n == len(port.EDITS)
+    assert port.leftovers(str(dst)) == []
+    hpp = (dst / "src/SOP/HNanoSolver/SOP_HNanoSolver.hpp").read_text()
+    assert "hns_shim::GridHandle& handle" in hpp and "const hipStream_t& stream" in hpp and "DeviceBuffer" not in hpp
+    n2, problems2 = port.apply(str(dst), write=False)  # a second run finds nothing to do and says so
+    assert n2 == 0 and len(problems2) == len(port.EDITS)
