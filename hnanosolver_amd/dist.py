@@ -319,30 +319,37 @@ class SlabBench:
             d.core_substep(self.iterations, self.dt, self.stream)
         d.synchronize(self.stream)
         got = d.download()
-        if self._partition:
-            f = fields.synthetic_fields(self._glob, self._R)
-            vel, den = f["vel"], f["density"]
-        else:  # every slab carries the same fields (periodic in x)
-            o = self._glob[: len(self._glob) // self._world].copy()
-            f = fields.synthetic_fields(o, self._R)
-            vel, den = np.tile(f["vel"], (self._world, 1)), np.tile(f["density"], self._world)
-        grid = api.create_grid_from_leaves(self._glob, self.vs)
-        sim = D.Sim(grid, ["density"])
-        arrays = {"vel": np.ascontiguousarray(vel), "density": np.ascontiguousarray(den)}
-        sim.upload(arrays)
-        for _ in range(substeps):
-            sim.core_substep(self.iterations, self.dt, self.vs, self.stream)
-        sim.download(arrays)
-        sl = slice(self._first * LEAF_VOXELS, (self._first + self._count) * LEAF_VOXELS)
-        same = np.array_equal(got["vel"], arrays["vel"][sl]) and np.array_equal(got["scalars"][0], arrays["density"][sl])
-        sim.close()
+        why = ""
+        try:  # (whatever goes wrong on one rank, every rank reaches the collective below)
+            if self._partition:
+                f = fields.synthetic_fields(self._glob, self._R)
+                vel, den = f["vel"], f["density"]
+            else:  # every slab carries the same fields (periodic in x)
+                o = self._glob[: len(self._glob) // self._world].copy()
+                f = fields.synthetic_fields(o, self._R)
+                vel, den = np.tile(f["vel"], (self._world, 1)), np.tile(f["density"], self._world)
+            grid = api.create_grid_from_leaves(self._glob, self.vs)
+            sim = D.Sim(grid, ["density"])
+            arrays = {"vel": np.ascontiguousarray(vel), "density": np.ascontiguousarray(den)}
+            sim.upload(arrays)
+            for _ in range(substeps):
+                sim.core_substep(self.iterations, self.dt, self.vs, self.stream)
+            sim.download(arrays)
+            sl = slice(self._first * LEAF_VOXELS, (self._first + self._count) * LEAF_VOXELS)
+            same = np.array_equal(got["vel"], arrays["vel"][sl]) and np.array_equal(got["scalars"][0], arrays["density"][sl])
+            sim.close()
+        except Exception as e:  # noqa: BLE001
+            same, why = False, f" [the single-GPU side failed on a rank: {type(e).__name__}: {e}]"[:200]
         import torch.distributed as dist
 
-        t = self.torch.tensor([1 if same else 0], dtype=self.torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        t = self.torch.tensor([1 if same else 0, 0 if why else 1], dtype=self.torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        ok = bool(int(t.item()))
-        self.verified_note = (f"owned velocity and density after {substeps} substeps bit-identical to the single-GPU run of the whole domain on every rank" if ok else
-                              "MISMATCH against the single-GPU run of the whole domain: THIS RUN'S PHYSICS IS WRONG, its throughput means nothing")
+        ok, ran = bool(int(t[0].item())), bool(int(t[1].item()))
+        if not ran:
+            self.verified_note = "NOT checked: the single-GPU run of the whole domain failed on a rank" + why
+        else:
+            self.verified_note = (f"owned velocity and density after {substeps} substeps bit-identical to the single-GPU run of the whole domain on every rank" if ok else
+                                  "MISMATCH against the single-GPU run of the whole domain: THIS RUN'S PHYSICS IS WRONG, its throughput means nothing")
         d.upload(*self._fields)
         return ok
 
