@@ -985,9 +985,12 @@ static int rbgs_form(hns_grid* g, int opt) {
 
 // Grids the temporally blocked form sweeps by default (option "rbgs" = auto)
 // (measured, profiles/r03_sor_forms.txt, us per iteration one-iteration form -> blocked: 64 leaves 3.7 -> 2.1, 512 4.0 -> 3.0, 4,096 7.9 -> 6.5,
-// 13,824 20.5 -> 19.3, 64,000 98 -> 88, 262,144 394 -> 349; between ~16k and ~40k leaves -- 256^3 -- both take the same time and the
-// established pair form stays)
-static bool rbgs_auto_block(const hns_grid* g) { return g->n_active <= 16000 || g->n_active >= 40000; }
+// 13,824 19.0 -> 17.8, 32,768 39.2 -> 37.1, 64,000 98 -> 88, 262,144 394 -> 349: every size; the one-iteration forms remain for
+// launch ranges -- the ranks of a multi-GPU run -- and for an odd iteration left over)
+static bool rbgs_auto_block(const hns_grid* g) {
+	(void)g;
+	return true;
+}
 
 // one full (red, black) iteration src -> dst. src_is_zero (pair form only): the caller vouches that src is 0 on every
 // leaf (first iteration of a solve) and the kernel skips reading it.

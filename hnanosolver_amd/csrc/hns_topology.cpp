@@ -150,6 +150,7 @@ const OptionDesc kOptions[] = {
     {"sor_block_lb", &Options::sor_block_lb, nullptr},
     {"sor_block_k", &Options::sor_block_k, nullptr},
     {"sor_block_seg", &Options::sor_block_seg, nullptr},
+    {"sor_block_stagger", &Options::sor_block_stagger, nullptr},
     {"sor_lds_pad", &Options::sor_lds_pad, nullptr},
     {"schedule_segment", &Options::schedule_segment, nullptr},
     {"dist_wire_us", &Options::dist_wire_us, nullptr},

@@ -75,7 +75,6 @@ def rbgs_iterate(grid: IndexGridHandle, div, p_a, p_b, dx: float, omega: float, 
 
 def rbgs_plan(grid: IndexGridHandle, iterations: int):
     """(description of the SOR kernel form this grid is swept with, kernel launches for `iterations`, iterations per launch)"""
-    lib = load_library()
     buf = C.create_string_buffer(256)
     n, k = C.c_int(0), C.c_int(0)
     _raise(lib.hns_grid_rbgs_plan(grid.ptr, iterations, buf, 256, C.byref(n), C.byref(k)))

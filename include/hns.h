@@ -67,6 +67,7 @@ int hns_trim_memory(void);
  *   "sor_block_lb"  0 = by size | 1 | 2: block edge of the temporally blocked form, in leaves
  *   "sor_block_k"   0 = by shape | 2 | 4: its iterations per launch (4: one-leaf blocks only)
  *   "sor_block_seg" N: its blocks per XCD segment of the launch order (0: one chunk per XCD; read when the block table is built)
+ *   "sor_block_stagger" N: its launch-start stagger between the two workgroups of a CU, x 1,024 cycles (default 8; 0 = off)
  *   "advect"        auto | generic (64-bit addressed advection kernels)
  *   "stencil"       auto | block (512-thread divergence and gradient kernels)
  *   "schedule"      auto | linear | chunk (workgroup -> leaf order; takes effect when a grid's launch tables are next built)

@@ -64,7 +64,7 @@ def timing(cfgs, opts):
         div = torch.randn(N, device="cuda")
         p_a = torch.zeros(N, device="cuda"); p_b = torch.zeros(N, device="cuda")
         for form in ({"rbgs": "pair"}, {"rbgs": "wave"}, {"rbgs": "block", "sor_block_lb": 1, "sor_block_k": 2}, {"rbgs": "block", "sor_block_lb": 1, "sor_block_k": 4},
-                     {"rbgs": "block", "sor_block_lb": 2, "sor_block_k": 2}):
+                     {"rbgs": "block", "sor_block_lb": 2, "sor_block_k": 2, "sor_block_stagger": 0}, {"rbgs": "block", "sor_block_lb": 2, "sor_block_k": 2}):
             if form.get("sor_block_lb") == 1 and len(origins) > 5000:
                 continue
             if form["rbgs"] == "wave" and len(origins) > 20000:
