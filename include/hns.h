@@ -279,7 +279,11 @@ int hns_dev_unpack_leaves(const float* packed, const int32_t* leaf_ids, uint64_t
 /* Leaf-partitioned multi-GPU core substep (new: the reference is single-GPU). One hns_dist per rank = per GPU.      */
 /* Rank r owns leaves [n*r/world, n*(r+1)/world) of the global leaf list (NanoVDB order: x-slabs for box domains), */
 /* keeps one layer of ghost leaves and refreshes exactly the ghost voxels the next kernel can read (hns_dist.hip). */
-/* Owned results are bit-identical to the single-domain hns_sim_core_substep.                                      */
+/* Owned results are bit-identical to the single-domain hns_sim_core_substep -- as long as no advection back-trace    */
+/* leaves the 27-leaf neighbourhood of its voxel's leaf (|u| dt / dx up to ~8 voxels): a rank holds ONE layer of      */
+/* ghost leaves. A longer back-trace is detected on the device and the next hns_dist_*_substep / hns_dist_synchronize */
+/* / hns_dist_download returns HNS_ERR_RUNTIME saying so; hns_dist_upload clears it (the single-GPU path follows any  */
+/* back-trace through its origin hash and has no such limit).                                                         */
 /* ------------------------------------------------------------------------------------------------------------ */
 
 typedef struct hns_dist hns_dist;
