@@ -1434,9 +1434,11 @@ struct Step {
 			if (d->timing && d->tev_used + 2 <= d->tev.size()) HNS_HIP(hipEventRecord(d->tev[d->tev_used], st));
 		}
 		const int n = std::min(d->k, iterations - it);
-		for (int j = 0; j < n - 1; ++j, ++it) {
-			HNS_TRY(sweep(d->gA, it == 0, st));
-			std::swap(src, dst);
+		if (n > 1) {  // the sweeps over owned + ghost leaves as ONE solve of n - 1 iterations: the library picks the form (two iterations per launch where that pays)
+			int in_b = 0;
+			HNS_TRY(hns_rbgs_iterate(d->gA, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), n - 1, &in_b, st, it == 0));
+			if (in_b) std::swap(src, dst);
+			it += n - 1;
 		}
 		const bool last = it + 1 == iterations, zero = it == 0;
 		HNS_TRY(post(d, last ? X_D1 : X_P, Fields{{dst, 1}}, st, [=](hipStream_t s) { return sweep(D->gB, zero, s); }));
@@ -1593,11 +1595,12 @@ struct Step {
 		}
 		if (ph < 3 + blocks) {  // one block of up to k sweeps; all but the last sweep the ghost leaves too
 			const int b = ph - 3;
+			if (!d->mirror) return sor_block_exchanged(b);
 			if (b == 0) {
 				it = 0, src = d->p_a, dst = d->p_b;  // never warm-started (reference HNanoSolver.cu:113): the first sweep reads no p
 				if (d->timing && d->tev_used + 2 <= d->tev.size()) HNS_HIP(hipEventRecord(d->tev[d->tev_used], st));
 			}
-			if (d->mirror) {  // the sweep delivers its boundary rows itself (k_rbgs_pair_mirror): no exchange, no second stream
+			{  // the sweep delivers its boundary rows itself (k_rbgs_pair_mirror): no exchange, no second stream
 				const PhaseMirror m = phase_args(d, X_P, Outs{{dst, 1}});
 				const bool zero = it == 0, backwards = options().alternate.load() != 0 && (it & 1);
 				if (d->n_boundary_records || d->gO->n_active == 0) {
@@ -1612,18 +1615,6 @@ struct Step {
 				if (last_sweep) d->p_result = src;
 				return launch_status("hns_dist: mirror sweep");
 			}
-			const int n = std::min(d->k, iterations - it);
-			for (int j = 0; j < n - 1; ++j, ++it) {
-				HNS_TRY(sweep(d->gA, it == 0, st));
-				std::swap(src, dst);
-			}
-			const bool last = it + 1 == iterations, zero = it == 0;
-			HNS_TRY(post(d, last ? X_D1 : X_P, Fields{{dst, 1}}, st, [=](hipStream_t s) { return sweep(D->gB, zero, s); }));
-			HNS_TRY(sweep(d->gI, zero, st));
-			std::swap(src, dst);
-			++it;
-			if (last) d->p_result = src;
-			return HNS_OK;
 		}
 		if (ph == 3 + blocks) {
 			if (d->mirror && !d->chain && d->mir.n_peers) {  // the gradient reads what the peers' last sweep wrote into the ghost voxels
