@@ -883,11 +883,19 @@ int hns_dist_connect_rccl(hns_dist* d, const void* unique_id128) {
 
 // Timing only: this rank alone on the device, every message answered with this rank's own payload (wrong data, right
 // sizes, same streams / events / kernels). What one rank costs next to the plain single-GPU substep, before any wire time.
+// The loopback transports answer every message out of the rank's own send buffer: timing only, the ghost values (and with them
+// the back-traces) mean nothing -- no point in reporting that they leave the ghost layer.
+static void no_far_check(hns_dist* d) {
+	for (hns_grid* g : {d->gB, d->gI, d->gO, d->gA})
+		if (g) g->far_flag = nullptr;
+}
+
 int hns_dist_connect_loopback(hns_dist* d) {
 	if (!d || !d->gA) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_loopback: bad handle");
 	if (d->comm || !d->local_ranks.empty()) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_connect_loopback: already connected");
 	HNS_TRY(ensure_comm_stream(d));
 	d->loopback = true;
+	no_far_check(d);
 	if (mirror_wanted(d)) {  // the chained substep, looped back: boundary values go into this rank's own ghost leaves, flags to itself
 		HNS_TRY(ensure_flags(d));
 		std::vector<std::vector<int>> remote[X_COUNT];
@@ -920,6 +928,7 @@ int hns_dist_connect_loopback_rccl(hns_dist* d) {
 	HNS_NCCL(rccl().GetUniqueId(&id));
 	HNS_NCCL(rccl().CommInitRank(&d->comm, 1, id, 0));
 	d->loopback = true;
+	no_far_check(d);
 	return HNS_OK;
 }
 
