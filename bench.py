@@ -14,10 +14,11 @@ e.g. plume1024 = BASELINE.json's 1024^3-extent sparse grid, split across the ran
 voxels of u / div / p / phi over RCCL where the single-GPU code has a kernel boundary that a stencil crosses, under the
 interior kernels (csrc/hns_dist.hip; hnanosolver_amd/dist.py is the host mirror). `value` = slab-substeps/s summed over ranks = N x (global substeps/s).
 
-Rank 0 prints ONE JSON line. `roofline`: the SOR kernel (`kernel` names the form the library picked for this grid size),
-algorithmic 12 B/voxel per red+black iteration (read p, read div, write p once each; a launch of the temporally blocked form
-holds several iterations and is priced per iteration all the same), time per iteration from hipEvents recorded on the launch
-stream around the pressure loop of every timed step. `roofline.kernels` carries the same figures for all five kernels of the substep (each bracketed by hipEvents
+Rank 0 prints ONE JSON line. `roofline`: the SOR kernel (`kernel` names the form the library picked for this grid size).
+Algorithmic bytes are 12 B/voxel per red+black iteration (read p, read div, write p once each); a launch of the temporally
+blocked form holds `iterations_per_launch` iterations, so per KERNEL LAUNCH -- the unit of `algorithmic_bytes_per_launch`,
+`ms_per_launch` and `traffic`, and what rocprofv3 --stats lists -- they are 12 B/voxel x iterations per launch; `achieved` is
+their ratio either way. Times come from hipEvents recorded on the launch stream around the pressure loop of every timed step. `roofline.kernels` carries the same figures for all five kernels of the substep (each bracketed by hipEvents
 on the launch stream, in a short pass of its own after the timed region) and `roofline.substep` the whole substep
 against 688 B/voxel. `traffic` is NOT measured by this
 run (bench.py cannot run rocprofv3 on itself): it is the PMC-derived HBM bytes per launch from the builder's committed
@@ -283,25 +284,29 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = (1 if args.partition and world > 1 else world) * args.steps / elapsed  # slab-substeps/s over all ranks (partitioned: substeps/s of the one domain)
-        ms_launch = p_ms / max(1, launches)
-        achieved = BYTES_PER_VOXEL_ITER * n_vox_rank / (ms_launch * 1e-3) / 1e9 if launches else None
+        ms_iter = p_ms / max(1, launches)  # per red+black iteration
+        # per KERNEL LAUNCH (what rocprofv3 --stats lists): a solve of `iterations` iterations is sor_launches launches
+        iters_per_launch = args.iterations / max(1, sor_launches)
+        ms_launch = ms_iter * iters_per_launch
+        achieved = BYTES_PER_VOXEL_ITER * n_vox_rank / (ms_iter * 1e-3) / 1e9 if launches else None
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc) and world == 1:
             try:
                 j = json.load(open(pmc))
                 if j.get("config") == args.config and j.get("kernel") == sor_form.split(":")[0].split("<")[0] and j.get("kernel_source_sha16") == kernel_source_sha16():
-                    traffic = j.get("hbm_bytes_per_launch")
+                    traffic = j.get("hbm_bytes_per_launch") * iters_per_launch  # (the profile stores bytes per iteration)
                     traffic_source = "profiles/pmc_latest.json: builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on this kernel source; not measured by this run"
             except Exception:
                 traffic = None
         kernels = {}
         if n_sub:
             for st, ms in stages.items():
-                per = ms / n_sub / (args.iterations if st == "pressure" else 1)  # ms per launch
-                alg = STAGE_BYTES[st] * n_vox_rank
+                n_l = sor_launches if st == "pressure" else 1
+                per = ms / n_sub / n_l  # ms per kernel launch
+                alg = STAGE_BYTES[st] * n_vox_rank * (args.iterations / n_l if st == "pressure" else 1)
                 gbs = alg / (per * 1e-3) / 1e9 if per > 0 else None
-                kernels[STAGE_KERNEL[st] if st != "pressure" else sor_form.split(":")[0]] = {"stage": st, "ms_per_launch": per, "launches_per_substep": args.iterations if st == "pressure" else 1,  # (pressure: per red+black iteration)
+                kernels[STAGE_KERNEL[st] if st != "pressure" else sor_form.split(":")[0]] = {"stage": st, "ms_per_launch": per, "launches_per_substep": n_l,
                                              "algorithmic_bytes_per_launch": alg, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS if gbs else None}
         sub_bytes = (BYTES_PER_VOXEL_SUBSTEP - 600 + 12 * args.iterations) * n_vox_rank
         sub_gbs = sub_bytes / (ms_per_step * 1e-3) / 1e9
@@ -343,12 +348,15 @@ def main():
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
-                # per red+black ITERATION (SURVEY 8d's unit: 12 B/voxel); a launch of the blocked form holds `iterations_per_launch` of them
-                "algorithmic_bytes_per_launch": BYTES_PER_VOXEL_ITER * n_vox_rank,
+                # per KERNEL LAUNCH, as rocprofv3 --stats lists the kernel: a launch of the temporally blocked form holds several red+black
+                # iterations (SURVEY 8d's unit of 12 B/voxel is the iteration), so its algorithmic bytes are 12 B/voxel x iterations per launch
+                "algorithmic_bytes_per_launch": BYTES_PER_VOXEL_ITER * n_vox_rank * iters_per_launch,
                 "ms_per_launch": ms_launch,
-                "launches_timed": launches,
-                "iterations_per_kernel_launch": sor_k,
+                "iterations_per_launch": iters_per_launch,
                 "kernel_launches_per_solve": sor_launches,
+                "ms_per_iteration": ms_iter,
+                "algorithmic_bytes_per_iteration": BYTES_PER_VOXEL_ITER * n_vox_rank,
+                "iterations_timed": launches,
                 "kernels": kernels,
                 "substep": {"algorithmic_bytes": sub_bytes, "ms": ms_per_step, "achieved": sub_gbs, "frac": sub_gbs / HBM_PEAK_GBS},
             },
