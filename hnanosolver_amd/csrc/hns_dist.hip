@@ -1744,8 +1744,7 @@ static int sim_step_args(const hns_dist* d, const hns_combustion_params* params,
 	if ((int)params->factorScale > 6 || (int)params->factorScale < 0) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_sim_substep: factor_scale must be within 0..6 on a partitioned domain");
 	s.prm = params;
 	for (int c = 0; c < 5; ++c) s.fi[c] = field_index[c];
-	s.coll = has_collision && field_index[4] >= 0;  // HNanoSolver.cu:66-75
-	if (!s.coll) s.fi[4] = has_collision ? field_index[4] : field_index[4];  // (collision_sdf is never advected, used or not: HNanoSolver.cu:327)
+	s.coll = has_collision && field_index[4] >= 0;  // HNanoSolver.cu:66-75 (collision_sdf itself is never advected, used or not: :327)
 	s.vort = (int)params->factorScale != 0;  // (int)factor_scale == 0: the kernel is a bit-exact copy (hns_api.hip: Substep::part_a)
 	return HNS_OK;
 }
