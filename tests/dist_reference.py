@@ -157,3 +157,92 @@ class ReferenceRank:
                 self._put(d, o, "I")
             self.phi, self.phi_next = self.phi_next, self.phi
             self.phi_in_flight = self.world > 1
+
+    # ---- the whole Compute_Sim substep (hns_dist.hip: Step::run_full; reference HNanoSolver.cu:150-356) ----
+    def sim_substep(self, names, iterations, dt, params, has_collision):
+        """`names`: the scalars in load order. Same phases, exchange types and launch ranges as hns_dist_sim_substep."""
+        G, k = self.G, self.k
+        ci = [names.index(n) for n in ("fuel", "waste", "temperature", "flame")]
+        i_sdf = names.index("collision_sdf") if "collision_sdf" in names else -1
+        coll = bool(has_collision) and i_sdf >= 0
+        sdf = self.phi[i_sdf] if coll else None
+        vort = int(params.factorScale) != 0
+        nO = self.nB + self.nI
+        self.ranges["O"] = (0, nO)
+        # open: phi (collision_sdf among it) unless already posted, u unless collision is about to rewrite it
+        f = []
+        if not coll and not self.u_fresh:
+            self.complete()
+            f.append(self.u)
+        if not self.phi_in_flight:
+            f += self.phi
+        self.phi_in_flight = False
+        if f:
+            self.post(X_ADV, f)
+        self.complete()
+        if coll:  # the SDF's ghost voxels are there now (the collision normal reads them)
+            self._put(self.u, G.enforce_collision_boundaries(self.u, sdf, self.vs), "O")
+            self.post(X_ADV, [self.u])
+            self.complete()
+        adv = G.advect_vector(self.u, dt, self.inv_dx, sdf, coll)
+        self._put(self.adv, adv, "B")
+        self.post(X_ADV if vort else X_D1, [self.adv])
+        self._put(self.adv, adv, "I")
+        self.complete()
+        if vort:
+            tmp = G.vorticity_confinement(self.adv, dt, self.inv_dx, params.vorticityScale, params.factorScale)
+            new = self.adv.copy()
+            self._put(new, tmp, "B")
+            self._put(new, tmp, "I")
+            self.adv = new
+            self.post(X_D1, [self.adv])
+            self.complete()
+        div = G.divergence(self.adv, self.inv_dx)
+        fu, wa, te, fl, div2 = G.combustion_oxygen(self.phi[ci[0]], self.phi[ci[1]], self.phi[ci[2]], div, self.phi[ci[3]], params.temperatureRelease, params.expansionRate)
+        self._put(self.div, div2, "B")
+        self.post(X_DIV, [self.div])
+        self._put(self.div, div2, "I")
+        self.complete()
+        self._put(self.adv, G.temperature_buoyancy(self.adv, te, dt, params.ambientTemp, params.buoyancyStrength), "O")
+        for c, new in zip(ci, (fu, wa, te, fl)):
+            self._put(self.phi_next[c], new, "O")
+            self.phi[c], self.phi_next[c] = self.phi_next[c], self.phi[c]
+        self.post(X_ADV, [self.phi[c] for c in ci])
+        self.complete()
+        self.p_a[:] = 0.0
+        src, dst, it = self.p_a, self.p_b, 0
+        while it < iterations:
+            n = min(k, iterations - it)
+            for _ in range(n - 1):
+                self.sweep(src, dst, "A")
+                src, dst = dst, src
+                it += 1
+            last = it + 1 == iterations
+            p = src.copy()
+            G.rbgs(self.div, p, self.vs, 0, self.omega)
+            G.rbgs(self.div, p, self.vs, 1, self.omega)
+            self._put(dst, p, "B")
+            self.post(X_D1 if last else X_P, [dst])
+            self._put(dst, p, "I")
+            src, dst = dst, src
+            it += 1
+            self.complete()
+        self.p = src
+        u = G.subtract_pressure_gradient(self.adv, self.p, self.inv_dx, sdf, coll)
+        if coll:
+            u = G.enforce_collision_boundaries(u, sdf, self.vs)  # (pointwise in u: enforcing the full array and keeping the owned part = enforcing the owned part)
+        self._put(self.u, u, "B")
+        self.post(X_ADV, [self.u])
+        self._put(self.u, u, "I")
+        self.complete()
+        self.u_fresh = not coll
+        which = [i for i in range(len(self.phi)) if i != i_sdf]
+        out = G.advect_scalars(self.u, [self.phi[i] for i in which], dt, self.inv_dx, sdf, coll)
+        for i, o in zip(which, out):
+            self._put(self.phi_next[i], o, "B")
+        self.post(X_ADV, [self.phi_next[i] for i in which])
+        for i, o in zip(which, out):
+            self._put(self.phi_next[i], o, "I")
+        for i in which:
+            self.phi[i], self.phi_next[i] = self.phi_next[i], self.phi[i]
+        self.phi_in_flight = self.world > 1

@@ -167,3 +167,76 @@ def test_partitioned_substep_is_bit_identical_to_single_domain(tmp_path, name, w
         assert np.array_equal(z["p"], p[sl]), f"rank {r} pressure"
         assert np.array_equal(z["phi0"], phi[0][sl]) and np.array_equal(z["phi1"], phi[1][sl]), f"rank {r} scalars"
         assert z["bytes_sent"] > 0
+
+
+SIM_NAMES = ["density", "temperature", "fuel", "waste", "flame", "collision_sdf"]
+
+
+def _sim_inputs(name):
+    origins, R = _case(name)
+    f = fields.synthetic_fields(origins, R)
+    f["collision_sdf"] = fields.sphere_sdf(origins, R)
+    f["waste"] = (0.05 * f["density"]).astype(np.float32)
+    f["flame"] = (0.3 * f["fuel"]).astype(np.float32)
+    return origins, R, f
+
+
+def _sim_params(fs):
+    from hnanosolver_amd import api
+
+    return api.CombustionParams(factorScale=fs, vorticityScale=0.01, buoyancyStrength=0.05)  # gentle: back-traces stay inside the one-leaf ghost layer
+
+
+def _sim_worker(rank, world, port, name, iters, k, coll, fs, out_dir):
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from dist_reference import ReferenceRank
+    from oracle_lib import oracle
+
+    oracle().orc_set_threads(max(1, (os.cpu_count() or 8) // world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        origins, R, f = _sim_inputs(name)
+        rr = ReferenceRank(origins, world, rank, 1.0 / R, len(SIM_NAMES), k, poison=7.0)
+        b = HD.partition_bounds(len(origins), world)
+        sl = slice(b[rank] * 512, b[rank + 1] * 512)
+        rr.load_owned(f["vel"][sl], [f[n][sl] for n in SIM_NAMES])
+        for _ in range(2):
+            rr.sim_substep(SIM_NAMES, iters, 1.0 / 24.0, _sim_params(fs), coll)
+        rr.complete()
+        dist.barrier()
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), u=rr.owned(rr.u), **{n: rr.owned(rr.phi[i]) for i, n in enumerate(SIM_NAMES)})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world,k,coll,fs", [("plume", 2, 4, True, 1.0), ("dense", 3, 2, False, 0.5)])
+def test_partitioned_compute_sim_walk_is_bit_identical_to_single_domain(tmp_path, name, world, k, coll, fs):
+    """The WHOLE Compute_Sim substep walked through the library's plan on CPU (oracle as engine, gloo as wire; the phases of
+    hns_dist.hip: Step::run_full): owned results of two chained substeps equal the oracle's own Compute driver on the single domain.
+    tests/test_dist_gpu.py ties the HIP path to the same answer."""
+    import torch.multiprocessing as mp
+
+    from oracle_lib import OracleGrid
+
+    iters = 5
+    mp.spawn(_sim_worker, args=(world, _free_port(), name, iters, k, coll, fs, str(tmp_path)), nprocs=world, join=True)
+    origins, R, f = _sim_inputs(name)
+    G = OracleGrid(origins)
+    u = f["vel"].copy()
+    phi = {n: f[n].copy() for n in SIM_NAMES}
+    sdf0 = phi["collision_sdf"].copy()
+    for _ in range(2):
+        assert G.compute_sim(u, phi, iters, 1.0 / 24.0, 1.0 / R, _sim_params(fs), coll) == 0
+        phi["collision_sdf"][:] = sdf0  # the reference's driver hands the SDF back zeroed (HNanoSolver.cu:364-369); the device-resident state keeps it
+    b = HD.partition_bounds(len(origins), world)
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        sl = slice(b[r] * 512, b[r + 1] * 512)
+        assert np.array_equal(z["u"], u[sl]), f"rank {r} velocity"
+        for n in SIM_NAMES:
+            assert np.array_equal(z[n], phi[n][sl]), f"rank {r} {n}"
