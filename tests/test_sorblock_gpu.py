@@ -23,8 +23,13 @@ def leaf_sets():
     shifted = fields.dense_leaves(24).astype(np.int64) + np.array([-4104, -16, 120])
     shifted = shifted.astype(np.int32)
     shifted = np.ascontiguousarray(shifted[fields.nanovdb_order(shifted)])
+    # 2 x 2 x 2 leaves in each corner region of the int32 coordinate range: a 16^3 block's neighbours lie outside it there
+    lo, hi = -2**31, 2**31 - 16
+    corner = np.array([[i, j, k] for i in (0, 8) for j in (0, 8) for k in (0, 8)], dtype=np.int64)
+    edge = np.concatenate([corner + np.array(c) for c in ((lo, lo, lo), (hi, hi, hi), (lo, 0, hi), (hi, lo, 0))]).astype(np.int32)
+    edge = np.ascontiguousarray(edge[fields.nanovdb_order(edge)])
     return {"dense32": fields.dense_leaves(32), "dense40": fields.dense_leaves(40), "plume": fields.plume_leaves(16, 1.5, 0.3), "scatter": scatter,
-            "node_borders": shifted, "one_leaf": np.array([[8, -8, 0]], dtype=np.int32)}
+            "node_borders": shifted, "one_leaf": np.array([[8, -8, 0]], dtype=np.int32), "int32_edge": edge}
 
 
 @pytest.fixture(autouse=True)
