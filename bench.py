@@ -278,6 +278,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    ghosts_note = None
+    if world > 1:  # after the timed region: do the ghost voxels the timed transport wrote hold their owners' bits? (collective; any failure is reported, not raised)
+        try:
+            group = None
+            n_pairs, bad = runner.rank_obj.ghost_check(group)
+            ghosts_note = (f"after the timed substeps the velocity and p ghost voxels of all {n_pairs} (owner, holder, field) pairs are bit-equal to their owners' values"
+                           if not bad else f"GHOST VOXELS DIFFER FROM THEIR OWNERS' VALUES after the timed substeps in {len(bad)} of {n_pairs} pairs, first {bad[0]}")
+        except Exception as e:  # noqa: BLE001
+            ghosts_note = f"ghost check did not complete: {type(e).__name__}: {e}"[:300]
     p_ms, launches = pressure_time()  # (launches: red+black iterations inside the bracketed pressure loops)
     sor_form, sor_launches, sor_k = D.rbgs_plan(grid, args.iterations) if world == 1 else ("", args.iterations, 1)
     stages, n_sub = stage_times() if stage_times else ({}, 0)
@@ -333,6 +342,7 @@ def main():
                 "halo": None if world == 1 else {k: runner.info()[k] for k in ("boundary_leaves", "interior_leaves", "ghost_leaves", "peers", "sweeps_per_exchange",
                                                                                 "bytes_sent", "messages_sent", "exchanges")},
                 "verified": "single GPU path (tests/ tie it to the oracle)" if world == 1 else runner.verified_note,
+                "ghosts": ghosts_note,
                 "parallelism": "single GPU" if world == 1 else (
                     (f"one domain in {world} contiguous leaf ranges" if args.partition else f"x-slab leaf partition over {world} ranks")
                     + ", halo transport: " + runner.transport_note

@@ -131,6 +131,7 @@ SIGNATURES = {
     "hns_dist_peer_region": (_i, [_vp, _i, _i, _i, _vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "hns_dist_upload": (_i, [_vp, _vp, C.POINTER(C.c_void_p), _vp]),
     "hns_dist_download": (_i, [_vp, _vp, C.POINTER(C.c_void_p), _vp, _vp]),
+    "hns_dist_download_local": (_i, [_vp, _i, _vp, _vp]),
     "hns_dist_core_substep": (_i, [_vp, _i, _f, _vp]),
     "hns_dist_local_core_substep": (_i, [C.POINTER(C.c_void_p), _i, _i, _f, _vp]),
     "hns_dist_sim_substep": (_i, [_vp, _i, _f, _vp, _ip, _i, _vp]),

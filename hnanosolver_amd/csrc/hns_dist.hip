@@ -1152,6 +1152,23 @@ int hns_dist_download(hns_dist* d, float* vel3, float* const* scalars, float* pr
 	return far_check(d);
 }
 
+// Diagnostics: one field of ALL local leaves, ghosts included, in local order [boundary | interior | ghosts], as the device holds
+// it now. which: -2 = the last solve's p, -1 = velocity (3 floats per voxel), s >= 0 = scalar s.
+int hns_dist_download_local(hns_dist* d, int which, float* out, void* stream) {
+	if (!d || !out) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_download_local: null argument");
+	if (!d->gA) return fail(HNS_ERR_NO_DEVICE, "hns_dist_download_local: plan-only handle");
+	if (which < -2 || which >= d->n_scalars) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_download_local: no such field");
+	hipStream_t st = (hipStream_t)stream;
+	HNS_HIP(hipStreamSynchronize(st));
+	if (d->cs) HNS_HIP(hipStreamSynchronize(d->cs));
+	const float* src = which == -2 ? d->p_result : (which == -1 ? d->u : d->phi[(size_t)which]);
+	const size_t n = d->local_global.size();
+	if (n == 0) return HNS_OK;
+	if (!src) return fail(HNS_ERR_RUNTIME, "hns_dist_download_local: the field does not exist yet");
+	HNS_HIP(hipMemcpy(out, src, sizeof(float) * 512 * n * (which == -1 ? 3 : 1), hipMemcpyDeviceToHost));
+	return HNS_OK;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------------------

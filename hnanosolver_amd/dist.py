@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -121,19 +121,11 @@ class DistRank:
 
     def connect_ipc(self, group=None) -> None:
         """Collective over torch.distributed (any backend): every rank exports the handles of its field memory, message
-        buffers and flag page, all ranks gather them and map their peers' (hns_dist_connect_ipc). One process per rank."""
-        import torch
-        import torch.distributed as dist
-
-        n = _lib.HNS_DIST_IPC_BLOB_BYTES
-        mine = (C.c_ubyte * n)()
-        _raise(lib.hns_dist_ipc_export(self._ptr, mine))
-        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
-        t = torch.frombuffer(bytearray(bytes(mine)), dtype=torch.uint8).to(dev)
-        out = [torch.empty_like(t) for _ in range(self.world)]
-        dist.all_gather(out, t, group=group)
-        blobs = b"".join(bytes(o.cpu().numpy().tobytes()) for o in out)
-        _raise(lib.hns_dist_connect_ipc(self._ptr, C.create_string_buffer(blobs, n * self.world)))
+        buffers and flag page, all ranks gather them and map their peers' (hns_dist_connect_ipc). One process per rank.
+        A failure on ANY rank raises on EVERY rank (the ranks agree after each step: none is left waiting in a collective)."""
+        ok, reason = self.try_connect_ipc(group)
+        if not ok:
+            raise RuntimeError(f"hns_dist: the ipc transport could not be set up on every rank ({reason})")
 
     def try_connect_ipc(self, group=None):
         """connect_ipc for callers that can fall back to another transport: every step that can fail on one rank alone is
@@ -201,6 +193,64 @@ class DistRank:
         if pressure:
             out["pressure"] = p
         return out
+
+    def download_local(self, which: int, stream: int = 0) -> np.ndarray:
+        """Field `which` (-2: the last solve's p, -1: velocity, s >= 0: scalar s) over ALL local leaves, ghosts included, in
+        local order (hns_dist_download_local): diagnostics."""
+        n = len(self.local_leaves()) * LEAF_VOXELS
+        out = np.empty((n, 3) if which == -1 else (n,), dtype=np.float32)
+        _raise(lib.hns_dist_download_local(self._ptr, int(which), out.ctypes.data, stream))
+        return out
+
+    # region type a field's ghost voxels are refreshed with by the END of a substep: the velocity travels as whole leaves
+    # ("advection inputs") behind the gradient subtraction, p within reach 1 of the owned voxels behind the last sweep
+    GHOST_REGION = {-1: 0, -2: 1}
+
+    def ghost_digests(self, fields: Sequence[int] = (-1, -2), stream: int = 0) -> Dict:
+        """{(owner rank, ghost-holder rank, field): SHA-1 of the values in message order} for every region this rank sends (its
+        own boundary voxels) and receives (its ghost voxels). Owner and ghost holder enumerate a region in the same order, so the
+        two digests of a pair are equal exactly when the ghost copy holds the owner's bits. Valid between substeps without
+        collision (with collision the next substep rewrites u before it exchanges it)."""
+        import hashlib
+
+        out = {}
+        peers = self.peers()
+        for f in fields:
+            a = self.download_local(f, stream)
+            t = self.GHOST_REGION[f]
+            for pp in peers:
+                for is_send, reg in ((True, pp.send[t]), (False, pp.recv[t])):
+                    if reg.voxels == 0:
+                        continue
+                    key = (self.rank, pp.rank, f) if is_send else (pp.rank, self.rank, f)
+                    out[key + ("owner" if is_send else "ghost",)] = hashlib.sha1(np.ascontiguousarray(a[reg.voxel_index()]).tobytes()).hexdigest()
+        return out
+
+    @staticmethod
+    def compare_ghost_digests(all_digests: Sequence[Dict]) -> Tuple[int, List]:
+        """(pairs compared, [(owner, holder, field), ...] whose ghost copy differs from the owner's values or is missing)"""
+        merged = {}
+        for d in all_digests:
+            merged.update(d)
+        pairs = sorted({k[:3] for k in merged})
+        bad = [k for k in pairs if merged.get(k + ("owner",)) is None or merged.get(k + ("owner",)) != merged.get(k + ("ghost",))]
+        return len(pairs), bad
+
+    def ghost_check(self, group=None, fields: Sequence[int] = (-1, -2), stream: int = 0) -> Tuple[int, List]:
+        """Collective over torch.distributed: after a substep, is every ghost voxel of the velocity and of p (the regions the next
+        kernels read) bit-equal to its owner's value? -> (pairs compared, mismatching pairs). A data-path check of the transport
+        that was actually used, on the memory it actually wrote -- independent of any reference run."""
+        import torch.distributed as dist
+
+        mine = self.ghost_digests(fields, stream)
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, mine, group=group)
+        return self.compare_ghost_digests(gathered)
+
+    @staticmethod
+    def ghost_check_local(ranks: Sequence["DistRank"], fields: Sequence[int] = (-1, -2), stream: int = 0) -> Tuple[int, List]:
+        """ghost_check for locally connected ranks (one process)"""
+        return DistRank.compare_ghost_digests([r.ghost_digests(fields, stream) for r in ranks])
 
     # ---- stepping ----
     def core_substep(self, iterations: int, dt: float, stream: int = 0) -> None:

@@ -339,6 +339,10 @@ int hns_dist_peer_region(const hns_dist*, int peer, int type, int is_send, int32
  * Synchronous. download: any pointer may be NULL; `pressure` receives the last solve's p. */
 int hns_dist_upload(hns_dist*, const float* vel3, const float* const* scalars, void* stream);
 int hns_dist_download(hns_dist*, float* vel3, float* const* scalars, float* pressure, void* stream);
+/* Diagnostics: one field over ALL local leaves, ghosts included, in local order (hns_dist_local_leaves), as the device holds it
+ * now; which = -2: the last solve's p, -1: velocity (3 floats per voxel), s >= 0: scalar s. Synchronous. With
+ * hns_dist_peer_region it lets a driver check that a rank's ghost voxels equal their owners' values (DistRank.ghost_check). */
+int hns_dist_download_local(hns_dist*, int which, float* out, void* stream);
 /* One core substep of this rank, asynchronous on `stream` and on the rank's communication stream (RCCL transport, or world 1). */
 int hns_dist_core_substep(hns_dist*, int iterations, float dt, void* stream);
 /* The same for locally connected ranks: all of them advance together, phase by phase, on `stream`. */

@@ -59,6 +59,8 @@ def main():
         for _ in range(substeps):
             d.core_substep(iters, 1.0 / 24.0, stream)
         d.synchronize(stream)
+        n_pairs, bad = d.ghost_check()  # collective: every ghost voxel of u and p against its owner's value, through the mapped peer memory
+        assert not bad and n_pairs > 0, (n_pairs, bad[:3])
         got = d.download(pressure=True)
         info = d.info()
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), vel=got["vel"], pressure=got["pressure"], exchanges=info["exchanges"], messages=info["messages_sent"],

@@ -240,3 +240,14 @@ def test_partitioned_compute_sim_walk_is_bit_identical_to_single_domain(tmp_path
         assert np.array_equal(z["u"], u[sl]), f"rank {r} velocity"
         for n in SIM_NAMES:
             assert np.array_equal(z[n], phi[n][sl]), f"rank {r} {n}"
+
+
+def test_ghost_digest_comparison_names_the_pair_that_differs():
+    """DistRank.compare_ghost_digests (the host half of ghost_check): a pair is good only if owner and holder both reported and agree"""
+    a = {(0, 1, -1, "owner"): "aa", (1, 0, -1, "ghost"): "bb", (0, 1, -2, "owner"): "cc"}
+    b = {(0, 1, -1, "ghost"): "aa", (1, 0, -1, "owner"): "bb", (0, 1, -2, "ghost"): "cc"}
+    assert HD.DistRank.compare_ghost_digests([a, b]) == (3, [])
+    b[(0, 1, -2, "ghost")] = "xx"  # a stale ghost copy of p on rank 1
+    assert HD.DistRank.compare_ghost_digests([a, b]) == (3, [(0, 1, -2)])
+    del b[(1, 0, -1, "owner")]  # a region only one side knows of
+    assert HD.DistRank.compare_ghost_digests([a, b]) == (3, [(0, 1, -2), (1, 0, -1)])

@@ -45,6 +45,9 @@ def run_local(origins, R, world, k, names, iters, substeps, dt=1.0 / 24.0):
 
 
 def check(ranks, b, want, names):
+    # the ghost voxels the next kernels read hold their owners' bits (velocity: whole leaves; p: reach 1), whatever the transport wrote them with
+    n_pairs, bad = HD.DistRank.ghost_check_local(ranks)
+    assert not bad and (n_pairs > 0 or len(ranks) == 1), (n_pairs, bad[:3])
     for r, d in enumerate(ranks):
         got = d.download()
         sl = slice(b[r] * 512, b[r + 1] * 512)
@@ -295,6 +298,7 @@ def test_bench_py_as_two_processes_sharing_the_gpu(extra, tmp_path):
     assert j["scaling"] == ("strong" if extra else "weak")
     assert "verified bit for bit" in j["config"]["parallelism"], j["config"]["parallelism"]
     assert "bit-identical to the single-GPU run of the whole domain" in j["config"]["verified"], j["config"]["verified"]  # what was timed was checked against one GPU first
+    assert "bit-equal to their owners' values" in j["config"]["ghosts"], j["config"]["ghosts"]  # and after the timed loop its ghost voxels were compared with their owners
     assert j["config"]["halo"]["sweeps_per_exchange"] == 1 and j["config"]["halo"]["bytes_sent"]["p"] > 0
 
 
