@@ -96,3 +96,24 @@ def test_blocked_sor_known_answer_harmonic_fixed_point():
     for lb, k in SHAPES:
         got = solve(grid, div, p0, 4, rbgs="block", sor_block_lb=lb, sor_block_k=k)
         assert torch.equal(got[inner], p0[inner]), (lb, k)
+
+
+def test_every_occupancy_pattern_of_a_block():
+    """a 16^3 block exists as soon as one of its 2 x 2 x 2 leaves does: all 255 occupancy patterns of one block, each inside a random half-filled
+    neighbourhood of leaves (so that the 4 x 4 x 4 leaves under the tile are present and absent in every combination a mask can meet)"""
+    rng = np.random.default_rng(11)
+    cells = np.array([[i, j, k] for i in range(2) for j in range(2) for k in range(2)], dtype=np.int32)
+    around = np.array([[i, j, k] for i in range(-2, 4) for j in range(-2, 4) for k in range(-2, 4) if not (0 <= i < 2 and 0 <= j < 2 and 0 <= k < 2)], dtype=np.int32)
+    for pattern in range(1, 256):
+        own = cells[[(pattern >> c) & 1 == 1 for c in range(8)]]
+        o = np.concatenate([own, around[rng.random(len(around)) < 0.5]]) * 8 + np.array([-16, 32, -48], dtype=np.int32)
+        o = np.ascontiguousarray(o[fields.nanovdb_order(o)].astype(np.int32))
+        grid = api.create_grid_from_leaves(o, 0.02)
+        n = len(o) * 512
+        g = torch.Generator(device="cpu").manual_seed(pattern)
+        div = torch.randn(n, generator=g).cuda()
+        p0 = (torch.rand(n, generator=g) * 2 - 1).cuda()
+        want = solve(grid, div, p0, 4, rbgs="color")
+        for lb, k in SHAPES:
+            got = solve(grid, div, p0, 4, rbgs="block", sor_block_lb=lb, sor_block_k=k)
+            assert torch.equal(want, got), (pattern, lb, k, float((want - got).abs().max()))
