@@ -45,6 +45,8 @@ struct Options {
 	std::atomic<int> sor_block_lb{0};          // "sor_block_lb": temporally blocked SOR (hns_sorblock.hip), block edge in leaves: 0 = by size, 1, 2
 	std::atomic<int> sor_block_k{0};           // "sor_block_k": ... iterations per launch: 0 = by shape, 2, 4 (4: one-leaf blocks only)
 	std::atomic<int> sor_block_stagger{8};     // "sor_block_stagger": ... launch-start stagger of the two workgroups of a CU, x 1,024 cycles (0 = off; hns_sorblock.hip)
+	std::atomic<int> sor_block_lean{0};        // "sor_block_lean" = auto | 0 | 1 (stored 0 / 1 / 2): ... its lean form (row state in LDS, three workgroups per CU); auto = by size
+	std::atomic<int> sor_block_lean_stagger{0};  // "sor_block_lean_stagger": ... launch-start stagger of the lean form's three workgroups per CU, x 1,024 cycles
 	std::atomic<int> sor_block_seg{0};         // "sor_block_seg": ... blocks per XCD segment of its launch order (0: one chunk per XCD; read when the block table is built)
 };
 Options& options();
@@ -188,5 +190,6 @@ int hns_grid_build_tiles(hns_grid* g);      // tile groups of the blocked SOR ke
 // implemented in hns_sorblock.hip: the temporally blocked SOR form (k iterations per launch)
 int hns_grid_build_blocks(hns_grid* g);     // records of the 16^3-voxel blocks
 int hns_rbgs_block_shape(hns_grid* g, int* k_max);  // block edge in leaves this grid is swept with (0: not by this form) and the iterations per launch
+bool hns_rbgs_block_lean(hns_grid* g, int lb, int k);  // is that launch the lean form of the kernel (row state in LDS, three workgroups per CU)?
 int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const float* div, const float* src, float* dst, float dx2, float omega, void* stream);
 int hns_grid_host_tables(const hns_grid* g);  // make topo.nbr27 / topo.hash valid on the host

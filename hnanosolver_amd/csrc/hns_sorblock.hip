@@ -58,6 +58,10 @@ struct SbGeo {
 	static constexpr int HS4 = 3;                // LDS stride of a colour array in float4 (48 bytes)
 	static constexpr int NCH = T / 4;            // 16-byte pieces of a row in memory
 	static constexpr int REC = LB == 1 ? 28 : 64;  // ints per block record
+	// 24-voxel tiles: the row state (p of both colours) stays in LDS, where the neighbours need it anyway, and only div * dx^2 is kept
+	// in registers -- 24 instead of 48 registers of state, <= 80 in all, which with the overlapped LDS arrays below lets THREE workgroups
+	// onto a CU instead of two (16-voxel tiles are small-grid, latency-bound launches: they keep the rows in registers)
+	static constexpr bool CAN_LEAN = T == 24;
 	static_assert(H % 4 == 0 && H <= 8, "rows must start on a 16-byte piece and stay within the neighbouring leaf");
 	static_assert(NQ <= HS4 && NT <= 1024 && RIM <= CROWS, "tile too large");
 };
@@ -83,9 +87,16 @@ struct SbRow {
 // LDS: [parity of x+y][colour][row][HS4 float4]. Rows of one parity are numbered x * HALF + (y >> 1): the lanes of a wave hold
 // consecutive rows of ONE parity, so which z are red is the same for the whole wave (PAR is a template parameter: no
 // per-lane selects anywhere) and ds_read_b128 at the 48-byte row stride is conflict-free.
+// The red values of the rows x = 0 and x = T-1 are never read (a black update happens at distance >= 2 from the rim, its lateral
+// neighbours at >= 1), so a red array is kept without its first and last HALF rows and the arrays overlap there: [black 0][red 0]
+// [black 1][red 1], a red array's row 0 lying HALF rows inside the end of the black array in front of it. Nobody may WRITE red values
+// of x = 0 / x = T-1 (the rim duty skips them). 52,992 instead of 55,296 bytes for 24-voxel tiles: three workgroups fit 160 KB.
 template <int LB, int K>
 struct SbLds {
-	float4 a[2][2][SbGeo<LB, K>::ROWS * SbGeo<LB, K>::HS4];
+	using G = SbGeo<LB, K>;
+	static constexpr int NB = G::ROWS * G::HS4, NR = (G::ROWS - 2 * G::HALF) * G::HS4;
+	float4 a[2 * (NB + NR)];
+	__device__ __forceinline__ float4* arr(int par, int colour) { return a + par * (NB + NR) + (colour ? 0 : NB - G::HALF * G::HS4); }
 };
 
 // One colour sweep S (1-based; odd = red = colour 0, Kernel.cu:601) of the whole tile, for the rows with parity PAR of x+y.
@@ -98,8 +109,8 @@ __device__ __forceinline__ void sb_sweep(Row& r, SbLds<LB, K>& L, const int i, c
 	float(&X)[HALF] = red ? r.R : r.B;          // the colour being updated
 	const float(&Y)[HALF] = red ? r.B : r.R;    // its neighbours' colour
 	const float(&dX)[HALF] = red ? r.dR : r.dB;
-	const float4* LY = L.a[PAR ? 0 : 1][red ? 1 : 0];  // the lateral neighbours are rows of the other parity
-	float4* LX = L.a[PAR ? 1 : 0][red ? 0 : 1];
+	const float4* LY = L.arr(PAR ? 0 : 1, red ? 1 : 0);  // the lateral neighbours are rows of the other parity
+	float4* LX = L.arr(PAR ? 1 : 0, red ? 0 : 1);
 	// z neighbours of X[j] in the own row: red voxel j of a row with even x+y sits at z = 2j (between black j-1 and j), with odd
 	// x+y at z = 2j+1 (between black j and j+1); black voxels the other way round
 	constexpr bool up = red ? PAR : !PAR;
@@ -207,8 +218,8 @@ __device__ __forceinline__ void sb_body(SbLds<LB, K>& L, const int t, const int*
 		sb4f rc[NCH];
 #pragma unroll
 		for (int j = 0; j < NCH; ++j) rc[j] = ZERO ? sb4f{0.0f, 0.0f, 0.0f, 0.0f} : sb_load4(rp, (int)(rbase[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
-		float4* LR = L.a[PAR ? 1 : 0][0] + (rx * HALF + (ry >> 1)) * HS4;
-		float4* LK = L.a[PAR ? 1 : 0][1] + (rx * HALF + (ry >> 1)) * HS4;
+		float4* LR = L.arr(PAR ? 1 : 0, 0) + (rx * HALF + (ry >> 1)) * HS4;
+		float4* LK = L.arr(PAR ? 1 : 0, 1) + (rx * HALF + (ry >> 1)) * HS4;
 		float rr[HALF + 4], rb[HALF + 4];
 #pragma unroll
 		for (int j = 0; j < NCH; ++j) {
@@ -217,7 +228,7 @@ __device__ __forceinline__ void sb_body(SbLds<LB, K>& L, const int t, const int*
 		}
 #pragma unroll
 		for (int q = 0; q < NQ; ++q) {
-			LR[q] = make_float4(rr[4 * q], rr[4 * q + 1], 4 * q + 2 < HALF ? rr[4 * q + 2] : 0.0f, 4 * q + 3 < HALF ? rr[4 * q + 3] : 0.0f);
+			if (side >= 2) LR[q] = make_float4(rr[4 * q], rr[4 * q + 1], 4 * q + 2 < HALF ? rr[4 * q + 2] : 0.0f, 4 * q + 3 < HALF ? rr[4 * q + 3] : 0.0f);
 			LK[q] = make_float4(rb[4 * q], rb[4 * q + 1], 4 * q + 2 < HALF ? rb[4 * q + 2] : 0.0f, 4 * q + 3 < HALF ? rb[4 * q + 3] : 0.0f);
 		}
 	}
@@ -231,8 +242,8 @@ __device__ __forceinline__ void sb_body(SbLds<LB, K>& L, const int t, const int*
 		r.dR[2 * j + 1] = PAR ? d3 : d2, r.dB[2 * j + 1] = PAR ? d2 : d3;
 	}
 	if (valid) {
-		float4* LR = L.a[PAR ? 1 : 0][0] + i * HS4;
-		float4* LK = L.a[PAR ? 1 : 0][1] + i * HS4;
+		float4* LR = L.arr(PAR ? 1 : 0, 0) + i * HS4;
+		float4* LK = L.arr(PAR ? 1 : 0, 1) + i * HS4;
 #pragma unroll
 		for (int q = 0; q < NQ; ++q) {
 			const int j = 4 * q;
@@ -261,17 +272,179 @@ __device__ __forceinline__ void sb_body(SbLds<LB, K>& L, const int t, const int*
 	}
 }
 
+// ---- the lean form (SbGeo::LEAN): the same sweeps with the thread's own row read from and written to its LDS entry ----
+
+template <int C, int HALF>
+struct SbLeanRow {
+	float dR[HALF], dB[HALF];  // div * dx^2 of the row's red / black voxels
+	unsigned ok[C];            // per leaf cell along z: all ones if the leaf exists, else 0
+};
+
+template <int LB, int K, int S, bool PAR, bool MASKED, class Row>
+__device__ __forceinline__ void sb_sweep_lean(Row& r, SbLds<LB, K>& L, const int i, const int b, const int dist, const float omega) {
+	using G = SbGeo<LB, K>;
+	constexpr int H = G::H, HALF = G::HALF, HS4 = G::HS4, NQ = G::NQ;
+	static_assert(NQ * 4 == HALF, "colour arrays are whole 16-byte pieces");
+	constexpr bool red = (S & 1) != 0;
+	const float(&dX)[HALF] = red ? r.dR : r.dB;
+	const float4* LY = L.arr(PAR ? 0 : 1, red ? 1 : 0);           // lateral neighbours: rows of the other parity, the other colour
+	float4* LXo = L.arr(PAR ? 1 : 0, red ? 0 : 1) + i * HS4;        // this row, the colour being updated (nobody else touches it in this sweep)
+	const float4* LYo = L.arr(PAR ? 1 : 0, red ? 1 : 0) + i * HS4;  // this row, the other colour: the z neighbours
+	constexpr bool up = red ? PAR : !PAR;  // as sb_sweep
+	constexpr int qlo = (S / 2) / 4, qhi = (HALF - S / 2 + 3) / 4;
+	constexpr int jlo = 4 * qlo, jhi = 4 * qhi < HALF ? 4 * qhi : HALF;
+	if (dist >= S) {
+		float Y[HALF];
+#pragma unroll
+		for (int q = 0; q < NQ; ++q) {
+			const float4 y4 = LYo[q];
+			Y[4 * q] = y4.x, Y[4 * q + 1] = y4.y, Y[4 * q + 2] = y4.z, Y[4 * q + 3] = y4.w;
+		}
+		const float4* pxp = LY + (i + HALF) * HS4;
+		const float4* pxm = LY + (i - HALF) * HS4;
+		const float4* pyp = LY + (i + b) * HS4;
+		const float4* pym = LY + (i + b - 1) * HS4;
+#pragma unroll
+		for (int q = qlo; q < qhi; ++q) {
+			const float4 x4 = LXo[q];
+			const float4 xp4 = pxp[q], xm4 = pxm[q], yp4 = pyp[q], ym4 = pym[q];
+			float X[4] = {x4.x, x4.y, x4.z, x4.w};
+			const float lat[4] = {xp4.x + xm4.x + yp4.x + ym4.x, xp4.y + xm4.y + yp4.y + ym4.y, xp4.z + xm4.z + yp4.z + ym4.z, xp4.w + xm4.w + yp4.w + ym4.w};
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				const int j = 4 * q + e;
+				if (j < jlo || j >= jhi) continue;
+				const float below = j > 0 ? Y[j > 0 ? j - 1 : 0] : 0.0f, above = j + 1 < HALF ? Y[j + 1 < HALF ? j + 1 : 0] : 0.0f;
+				const float zm = up ? Y[j] : below, zp = up ? above : Y[j];
+				const float pGS = ((lat[e] + zp + zm) - dX[j]) * kInv6;  // Kernel.cu:621 (dX = div * dx^2)
+				const float cand = X[e] + omega * (pGS - X[e]);          // Kernel.cu:622
+				const int cz = (2 * j - H + 8) >> 3;
+				X[e] = MASKED ? __uint_as_float(__float_as_uint(cand) & r.ok[cz]) : cand;
+			}
+			LXo[q] = make_float4(X[0], X[1], X[2], X[3]);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+	if (S < 2 * K) __syncthreads();
+}
+
+template <int LB, int K, int S, bool PAR, bool MASKED>
+struct SbSweepsLean {
+	template <class Row>
+	static __device__ __forceinline__ void run(Row& r, SbLds<LB, K>& L, const int i, const int b, const int dist, const float omega) {
+		sb_sweep_lean<LB, K, S, PAR, MASKED>(r, L, i, b, dist, omega);
+		if constexpr (S < 2 * K) SbSweepsLean<LB, K, S + 1, PAR, MASKED>::run(r, L, i, b, dist, omega);
+	}
+};
+
+template <int LB, int K, bool ZERO, bool PAR>
+__device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, const int t, const int* __restrict__ recs, const float* __restrict__ div, const float* __restrict__ p_in,
+                                             float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega) {
+	using G = SbGeo<LB, K>;
+	constexpr int H = G::H, T = G::T, C = G::C, HALF = G::HALF, NQ = G::NQ, NCH = G::NCH, HS4 = G::HS4;
+	static_assert(NCH == 2 * NQ, "two 16-byte pieces of a row in memory make one piece of each colour array");
+	const bool valid = t < G::CROWS;
+	const int xq = valid ? t / G::HC : 0;
+	const int x = 1 + xq, y = valid ? 1 + 2 * (t - xq * G::HC) + ((x + 1 + (PAR ? 1 : 0)) & 1) : 1;
+	const int b = y & 1;
+	const int i = x * HALF + (y >> 1);
+	const int dist = valid ? min(min(x, T - 1 - x), min(y, T - 1 - y)) : -1;
+	const int cx = (x - H + 8) >> 3, cy = (y - H + 8) >> 3;
+	const unsigned row_bytes = (unsigned)(((((x - H) & 7) << 3) | ((y - H) & 7)) * 32);
+	const int* __restrict__ rec = recs + (size_t)blockIdx.x * G::REC + (LB == 1 ? 1 : 0) + (cx * C + cy) * C;
+	unsigned base[C];
+	SbLeanRow<C, HALF> r;
+#pragma unroll
+	for (int cz = 0; cz < C; ++cz) {
+		const int id = valid ? rec[cz] : -1;
+		r.ok[cz] = id >= 0 ? 0xFFFFFFFFu : 0u;
+		base[cz] = (unsigned)id * 2048u + row_bytes;
+	}
+	const sb4i rp = sb_rsrc(p_in, field_bytes), rd = sb_rsrc(div, field_bytes), ro = sb_rsrc(p_out, field_bytes);
+	sb4f pc[NCH], dc[NCH];
+#pragma unroll
+	for (int j = 0; j < NCH; ++j) pc[j] = ZERO ? sb4f{0.0f, 0.0f, 0.0f, 0.0f} : sb_load4(rp, (int)(base[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
+#pragma unroll
+	for (int j = 0; j < NCH; ++j) dc[j] = sb_load4(rd, (int)(base[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
+	// Rim duty: the RIM rim rows of this parity (nobody updates them: p only, straight into LDS) as RIM * NCH 16-byte pieces dealt over
+	// the section's threads -- six lanes per 96-byte row. Side 0: x = 0, 1: x = T-1, 2: y = 0, 3: y = T-1; the m-th row of the right
+	// parity along the side. (Red values of sides 0 and 1 have no place in LDS and no reader: SbLds.)
+#pragma unroll
+	for (int q0 = 0; q0 < G::RIM * NCH; q0 += G::SEC) {
+		const int q = q0 + t;
+		if (q < G::RIM * NCH) {
+			const int mr = q / NCH, j = q - mr * NCH;
+			const int side = mr / G::HC, m = mr - side * G::HC;
+			const int along = 2 * m + (((side & 1) != 0) == PAR ? 2 : 1);  // sides 0, 2: along + 0 has parity PAR; sides 1, 3: along + T-1 (odd)
+			const int rx = side == 0 ? 0 : (side == 1 ? T - 1 : along), ry = side == 2 ? 0 : (side == 3 ? T - 1 : along);
+			const int rcx = (rx - H + 8) >> 3, rcy = (ry - H + 8) >> 3, rcz = (4 * j - H + 8) >> 3;
+			const unsigned rrow = (unsigned)(((((rx - H) & 7) << 3) | ((ry - H) & 7)) * 32 + ((4 * j - H) & 7) * 4);
+			sb4f v = sb4f{0.0f, 0.0f, 0.0f, 0.0f};
+			if (!ZERO) v = sb_load4(rp, (int)((unsigned)recs[(size_t)blockIdx.x * G::REC + (LB == 1 ? 1 : 0) + (rcx * C + rcy) * C + rcz] * 2048u + rrow), 0, 0);
+			float2* LR = reinterpret_cast<float2*>(L.arr(PAR ? 1 : 0, 0) + (rx * HALF + (ry >> 1)) * HS4) + j;
+			float2* LK = reinterpret_cast<float2*>(L.arr(PAR ? 1 : 0, 1) + (rx * HALF + (ry >> 1)) * HS4) + j;
+			if (side >= 2) *LR = PAR ? make_float2(v.y, v.w) : make_float2(v.x, v.z);
+			*LK = PAR ? make_float2(v.x, v.z) : make_float2(v.y, v.w);
+		}
+	}
+	// the row's p, split by colour (even z of a row with even x+y are red: colour = (x + y + z) & 1, Kernel.cu:599-601), into its LDS entry
+	if (valid) {
+		float4* LR = L.arr(PAR ? 1 : 0, 0) + i * HS4;
+		float4* LK = L.arr(PAR ? 1 : 0, 1) + i * HS4;
+#pragma unroll
+		for (int q = 0; q < NQ; ++q) {
+			const sb4f u = pc[2 * q], v = pc[2 * q + 1];
+			LR[q] = PAR ? make_float4(u.y, u.w, v.y, v.w) : make_float4(u.x, u.z, v.x, v.z);
+			LK[q] = PAR ? make_float4(u.x, u.z, v.x, v.z) : make_float4(u.y, u.w, v.y, v.w);
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < NCH; ++j) {
+		const float d0 = dc[j].x * dx2, d1 = dc[j].y * dx2, d2 = dc[j].z * dx2, d3 = dc[j].w * dx2;  // Kernel.cu:621: divVal * dx2
+		r.dR[2 * j] = PAR ? d1 : d0, r.dB[2 * j] = PAR ? d0 : d1;
+		r.dR[2 * j + 1] = PAR ? d3 : d2, r.dB[2 * j + 1] = PAR ? d2 : d3;
+	}
+	bool mine = true;
+#pragma unroll
+	for (int cz = 0; cz < C; ++cz) mine = mine && (r.ok[cz] != 0u || !valid);
+	const bool all_present = __syncthreads_and(mine) != 0;
+	if (all_present)
+		SbSweepsLean<LB, K, 1, PAR, false>::run(r, L, i, b, dist, omega);
+	else
+		SbSweepsLean<LB, K, 1, PAR, true>::run(r, L, i, b, dist, omega);
+	if (dist >= H) {  // the rows of the block itself, out of their own LDS entries (written by this thread: no barrier)
+		const float4* LR = L.arr(PAR ? 1 : 0, 0) + i * HS4;
+		const float4* LK = L.arr(PAR ? 1 : 0, 1) + i * HS4;
+		float R[HALF], B[HALF];
+#pragma unroll
+		for (int q = 0; q < NQ; ++q) {
+			const float4 a = LR[q], c = LK[q];
+			R[4 * q] = a.x, R[4 * q + 1] = a.y, R[4 * q + 2] = a.z, R[4 * q + 3] = a.w;
+			B[4 * q] = c.x, B[4 * q + 1] = c.y, B[4 * q + 2] = c.z, B[4 * q + 3] = c.w;
+		}
+#pragma unroll
+		for (int j = H / 4; j < NCH - H / 4; ++j) {
+			const int cz = (4 * j - H + 8) >> 3, zl = (4 * j - H) & 7;
+			sb4f v;
+			v.x = PAR ? B[2 * j] : R[2 * j], v.y = PAR ? R[2 * j] : B[2 * j];
+			v.z = PAR ? B[2 * j + 1] : R[2 * j + 1], v.w = PAR ? R[2 * j + 1] : B[2 * j + 1];
+			sb_store4(v, ro, (int)(base[cz] + (unsigned)(zl * 4)), 0, 0);
+		}
+	}
+}
+
 // recs: one record per workgroup, in launch order. LB = 1: {leaf, nbr27[27]} (the grid's d_blk); LB = 2: the 4 x 4 x 4 leaves
 // under the tile, cell (cx, cy, cz) at (cx*4 + cy)*4 + cz, -1 = absent. ZERO: p_in is known to be 0 (first launch of a solve,
 // HNanoSolver.cu:113) and is not read. The first half of the workgroup's waves takes the rows with even x+y, the second half
 // those with odd x+y; both halves meet at the same number of barriers.
-template <int LB, int K, bool ZERO>
-__global__ __launch_bounds__((SbGeo<LB, K>::NT), (SbGeo<LB, K>::NT >= 512 ? 4 : 1)) void k_rbgs_block(const int* __restrict__ recs, const float* __restrict__ div, const float* __restrict__ p_in,
+template <int LB, int K, bool ZERO, bool LEAN = false>
+__global__ __attribute__((amdgpu_waves_per_eu(LEAN ? 6 : 1, 8))) __launch_bounds__((SbGeo<LB, K>::NT)) void k_rbgs_block(const int* __restrict__ recs, const float* __restrict__ div, const float* __restrict__ p_in,
                                                                 float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega, const int stagger) {
 	using G = SbGeo<LB, K>;
 	__shared__ SbLds<LB, K> L;
 	const int t = threadIdx.x;
-	if (stagger > 0 && blockIdx.x < 512) {  // (the first round: 2 workgroups on each of 256 CUs)
+	constexpr unsigned PER_CU = LEAN ? 3u : 2u;  // workgroups of this kernel a CU holds
+	if (stagger > 0 && blockIdx.x < 256 * PER_CU) {  // (the first round: PER_CU workgroups on each of 256 CUs)
 		__shared__ unsigned s_slot;
 		if (t == 0) {
 			unsigned hw, xcc;
@@ -280,13 +453,21 @@ __global__ __launch_bounds__((SbGeo<LB, K>::NT), (SbGeo<LB, K>::NT >= 512 ? 4 : 
 			s_slot = atomicAdd(g_sb_slots + (((xcc & 15u) << 8) | ((hw >> 8) & 255u)), 1u);
 		}
 		__syncthreads();
-		if (s_slot & 1u)
-			for (int n = 0; n < stagger; ++n) __builtin_amdgcn_s_sleep(16);
+		const int wait = (int)(s_slot % PER_CU) * stagger;
+		for (int n = 0; n < wait; ++n) __builtin_amdgcn_s_sleep(16);
 	}
-	if (__builtin_amdgcn_readfirstlane(t >= G::SEC))
-		sb_body<LB, K, ZERO, true>(L, t - G::SEC, recs, div, p_in, p_out, field_bytes, dx2, omega);
-	else
-		sb_body<LB, K, ZERO, false>(L, t, recs, div, p_in, p_out, field_bytes, dx2, omega);
+	if constexpr (LEAN) {
+		static_assert(G::CAN_LEAN, "the lean form is written for 24-voxel tiles");
+		if (__builtin_amdgcn_readfirstlane(t >= G::SEC))
+			sb_body_lean<LB, K, ZERO, true>(L, t - G::SEC, recs, div, p_in, p_out, field_bytes, dx2, omega);
+		else
+			sb_body_lean<LB, K, ZERO, false>(L, t, recs, div, p_in, p_out, field_bytes, dx2, omega);
+	} else {
+		if (__builtin_amdgcn_readfirstlane(t >= G::SEC))
+			sb_body<LB, K, ZERO, true>(L, t - G::SEC, recs, div, p_in, p_out, field_bytes, dx2, omega);
+		else
+			sb_body<LB, K, ZERO, false>(L, t, recs, div, p_in, p_out, field_bytes, dx2, omega);
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -391,6 +572,16 @@ int hns_rbgs_block_shape(hns_grid* g, int* k_max) {
 	return lb;
 }
 
+// The lean form (row state in LDS, three workgroups per CU) where a launch runs to several rounds of workgroups and the grid still sits
+// in the Infinity Cache: one workgroup's latency is longer in it (128^3: 7.3 against 6.6 us per iteration), its throughput higher (1,000
+// blocks 11.2 against 11.6, 256^3 33.8-35.2 against 35.3-35.6, 66k-leaf plume 83.4 against 84.0), and beyond ~100k leaves the fabric
+// bounds both (512^3: 314 against 307-310) -- profiles/r03_sorblock_notes.txt 11. Option "sor_block_lean" = auto | 0 | 1.
+bool hns_rbgs_block_lean(hns_grid* g, int lb, int k) {
+	if (lb != 2 || k != 2) return false;
+	const int lo = options().sor_block_lean.load();
+	return lo == 0 ? (g->n_sb >= 768 && g->n_sb < 16384) : lo == 2;
+}
+
 // one launch: k iterations src -> dst
 int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const float* div, const float* src, float* dst, float dx2, float omega, void* stream) {
 	hipStream_t st = (hipStream_t)stream;
@@ -400,6 +591,7 @@ int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const fl
 	// "sor_block_stagger" = 0 switches it off, N sets the wait)
 	const int so = options().sor_block_stagger.load();
 	const int stag = (lb == 2 && g->n_sb >= 576) ? so : 0;
+	const bool lean = hns_rbgs_block_lean(g, lb, k);
 #define SB_LAUNCH(LB_, K_, recs, nblk)                                                                                                            \
 	do {                                                                                                                                           \
 		if (src_is_zero)                                                                                                                           \
@@ -409,7 +601,13 @@ int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const fl
 	} while (0)
 	if (lb == 1 && k == 2) SB_LAUNCH(1, 2, g->d_blk, g->n_active);
 	else if (lb == 1 && k == 4) SB_LAUNCH(1, 4, g->d_blk, g->n_active);
-	else if (lb == 2 && k == 2) SB_LAUNCH(2, 2, g->d_sb_tab, g->n_sb);
+	else if (lb == 2 && k == 2 && lean) {
+		const int sl = options().sor_block_lean_stagger.load();
+		if (src_is_zero)
+			hipLaunchKernelGGL((k_rbgs_block<2, 2, true, true>), dim3((unsigned)g->n_sb), dim3(SbGeo<2, 2>::NT), 0, st, (const int*)g->d_sb_tab, div, src, dst, bytes, dx2, omega, sl);
+		else
+			hipLaunchKernelGGL((k_rbgs_block<2, 2, false, true>), dim3((unsigned)g->n_sb), dim3(SbGeo<2, 2>::NT), 0, st, (const int*)g->d_sb_tab, div, src, dst, bytes, dx2, omega, sl);
+	} else if (lb == 2 && k == 2) SB_LAUNCH(2, 2, g->d_sb_tab, g->n_sb);
 	else return fail(HNS_ERR_INVALID_ARGUMENT, "hns_rbgs_block_launch: unsupported block shape");
 #undef SB_LAUNCH
 	return HNS_OK;

@@ -138,6 +138,7 @@ const char* const kWordsStencil[] = {"auto", "block", nullptr};
 const char* const kWordsSchedule[] = {"auto", "linear", "chunk", nullptr};
 const char* const kWordsBool[] = {"0", "1", nullptr};
 const char* const kWordsMirror[] = {"0", "1", "guarded", nullptr};
+const char* const kWordsAuto01[] = {"auto", "0", "1", nullptr};
 const OptionDesc kOptions[] = {
     {"rbgs", &Options::rbgs, kWordsRbgs},
     {"advect", &Options::advect_generic, kWordsAdvect},
@@ -150,6 +151,8 @@ const OptionDesc kOptions[] = {
     {"sor_block_lb", &Options::sor_block_lb, nullptr},
     {"sor_block_k", &Options::sor_block_k, nullptr},
     {"sor_block_seg", &Options::sor_block_seg, nullptr},
+    {"sor_block_lean", &Options::sor_block_lean, kWordsAuto01},
+    {"sor_block_lean_stagger", &Options::sor_block_lean_stagger, nullptr},
     {"sor_block_stagger", &Options::sor_block_stagger, nullptr},
     {"sor_lds_pad", &Options::sor_lds_pad, nullptr},
     {"schedule_segment", &Options::schedule_segment, nullptr},

@@ -52,7 +52,8 @@ VARIANTS = {
     # temporally blocked (hns_sorblock.hip; small grids take it by default): K iterations per launch on blocks of 1 / 8 leaves
     "sor_two_iterations_per_launch_leaf_blocks": {"rbgs": "block", "sor_block_lb": "1", "sor_block_k": "2"},
     "sor_four_iterations_per_launch_leaf_blocks": {"rbgs": "block", "sor_block_lb": "1", "sor_block_k": "4"},
-    "sor_two_iterations_per_launch_16cube_blocks": {"rbgs": "block", "sor_block_lb": "2", "sor_block_k": "2"},
+    "sor_two_iterations_per_launch_16cube_blocks": {"rbgs": "block", "sor_block_lb": "2", "sor_block_k": "2", "sor_block_lean": "0"},
+    "sor_two_iterations_per_launch_16cube_blocks_rows_in_lds": {"rbgs": "block", "sor_block_lb": "2", "sor_block_k": "2", "sor_block_lean": "1"},
     "schedule_linear": {"schedule": "linear"},
     "sor_one_direction": {"alternate": "0", "rbgs": "pair"},
     "all_kernels_forwards": {"rev": "0"},

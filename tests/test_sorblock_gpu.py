@@ -12,7 +12,7 @@ from oracle_lib import OracleGrid
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(1, 2), (1, 4), (2, 2)]  # (block edge in leaves, iterations per launch)
+SHAPES = [(1, 2), (1, 4), (2, 2), (2, -2)]  # (block edge in leaves, iterations per launch; negative: the lean form of the 16^3 blocks)
 
 
 def leaf_sets():
@@ -35,11 +35,14 @@ def leaf_sets():
 @pytest.fixture(autouse=True)
 def restore_options():
     yield
-    for k in ("rbgs", "sor_block_lb", "sor_block_k"):
+    for k in ("rbgs", "sor_block_lb", "sor_block_k", "sor_block_lean"):
         H.set_option(k, None)
 
 
 def solve(grid, div, p0, iters, **opts):
+    if "sor_block_k" in opts:  # rows in registers (two workgroups per CU) or in LDS (three): forced either way, whatever the size
+        opts["sor_block_lean"] = "1" if int(opts["sor_block_k"]) < 0 else "0"
+        opts["sor_block_k"] = abs(int(opts["sor_block_k"]))
     for k, v in opts.items():
         H.set_option(k, str(v))
     p_a = p0.clone()
