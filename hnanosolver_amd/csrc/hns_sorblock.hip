@@ -352,6 +352,29 @@ __device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, const int t, const
 	const int cx = (x - H + 8) >> 3, cy = (y - H + 8) >> 3;
 	const unsigned row_bytes = (unsigned)(((((x - H) & 7) << 3) | ((y - H) & 7)) * 32);
 	const int* __restrict__ rec = recs + (size_t)blockIdx.x * G::REC + (LB == 1 ? 1 : 0) + (cx * C + cy) * C;
+	// Rim duty: the RIM rim rows of this parity (nobody updates them: p only, straight into LDS) as RIM * NCH 16-byte pieces dealt over
+	// the section's threads -- six lanes per 96-byte row. Side 0: x = 0, 1: x = T-1, 2: y = 0, 3: y = T-1; the m-th row of the right
+	// parity along the side. (Red values of sides 0 and 1 have no place in LDS and no reader: SbLds.) Its leaf id is fetched together
+	// with the row's own, its load issued in front of the row's: one memory round trip for ids, one for data.
+	constexpr int NJ = (G::RIM * NCH + G::SEC - 1) / G::SEC;
+	bool rim_on[NJ], rim_red[NJ];
+	int rim_lds[NJ];       // float2 index of the piece in a colour array
+	unsigned rim_off[NJ];  // byte offset of the piece inside its leaf
+	int rim_id[NJ];
+#pragma unroll
+	for (int n = 0; n < NJ; ++n) {
+		const int q = n * G::SEC + t;
+		rim_on[n] = q < G::RIM * NCH;
+		const int mr = rim_on[n] ? q / NCH : 0, j = rim_on[n] ? q - mr * NCH : 0;
+		const int side = mr / G::HC, m = mr - side * G::HC;
+		const int along = 2 * m + (((side & 1) != 0) == PAR ? 2 : 1);  // sides 0, 2: along + 0 has parity PAR; sides 1, 3: along + T-1 (odd)
+		const int rx = side == 0 ? 0 : (side == 1 ? T - 1 : along), ry = side == 2 ? 0 : (side == 3 ? T - 1 : along);
+		const int rcx = (rx - H + 8) >> 3, rcy = (ry - H + 8) >> 3, rcz = (4 * j - H + 8) >> 3;
+		rim_off[n] = (unsigned)(((((rx - H) & 7) << 3) | ((ry - H) & 7)) * 32 + ((4 * j - H) & 7) * 4);
+		rim_red[n] = side >= 2;
+		rim_lds[n] = (rx * HALF + (ry >> 1)) * HS4 * 2 + j;
+		rim_id[n] = (!ZERO && rim_on[n]) ? recs[(size_t)blockIdx.x * G::REC + (LB == 1 ? 1 : 0) + (rcx * C + rcy) * C + rcz] : -1;
+	}
 	unsigned base[C];
 	SbLeanRow<C, HALF> r;
 #pragma unroll
@@ -361,29 +384,20 @@ __device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, const int t, const
 		base[cz] = (unsigned)id * 2048u + row_bytes;
 	}
 	const sb4i rp = sb_rsrc(p_in, field_bytes), rd = sb_rsrc(div, field_bytes), ro = sb_rsrc(p_out, field_bytes);
-	sb4f pc[NCH], dc[NCH];
+	sb4f rimv[NJ], pc[NCH], dc[NCH];
+#pragma unroll
+	for (int n = 0; n < NJ; ++n) rimv[n] = ZERO ? sb4f{0.0f, 0.0f, 0.0f, 0.0f} : sb_load4(rp, (int)((unsigned)rim_id[n] * 2048u + rim_off[n]), 0, 0);  // (id -1: beyond the field, reads 0)
 #pragma unroll
 	for (int j = 0; j < NCH; ++j) pc[j] = ZERO ? sb4f{0.0f, 0.0f, 0.0f, 0.0f} : sb_load4(rp, (int)(base[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
 #pragma unroll
 	for (int j = 0; j < NCH; ++j) dc[j] = sb_load4(rd, (int)(base[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
-	// Rim duty: the RIM rim rows of this parity (nobody updates them: p only, straight into LDS) as RIM * NCH 16-byte pieces dealt over
-	// the section's threads -- six lanes per 96-byte row. Side 0: x = 0, 1: x = T-1, 2: y = 0, 3: y = T-1; the m-th row of the right
-	// parity along the side. (Red values of sides 0 and 1 have no place in LDS and no reader: SbLds.)
 #pragma unroll
-	for (int q0 = 0; q0 < G::RIM * NCH; q0 += G::SEC) {
-		const int q = q0 + t;
-		if (q < G::RIM * NCH) {
-			const int mr = q / NCH, j = q - mr * NCH;
-			const int side = mr / G::HC, m = mr - side * G::HC;
-			const int along = 2 * m + (((side & 1) != 0) == PAR ? 2 : 1);  // sides 0, 2: along + 0 has parity PAR; sides 1, 3: along + T-1 (odd)
-			const int rx = side == 0 ? 0 : (side == 1 ? T - 1 : along), ry = side == 2 ? 0 : (side == 3 ? T - 1 : along);
-			const int rcx = (rx - H + 8) >> 3, rcy = (ry - H + 8) >> 3, rcz = (4 * j - H + 8) >> 3;
-			const unsigned rrow = (unsigned)(((((rx - H) & 7) << 3) | ((ry - H) & 7)) * 32 + ((4 * j - H) & 7) * 4);
-			sb4f v = sb4f{0.0f, 0.0f, 0.0f, 0.0f};
-			if (!ZERO) v = sb_load4(rp, (int)((unsigned)recs[(size_t)blockIdx.x * G::REC + (LB == 1 ? 1 : 0) + (rcx * C + rcy) * C + rcz] * 2048u + rrow), 0, 0);
-			float2* LR = reinterpret_cast<float2*>(L.arr(PAR ? 1 : 0, 0) + (rx * HALF + (ry >> 1)) * HS4) + j;
-			float2* LK = reinterpret_cast<float2*>(L.arr(PAR ? 1 : 0, 1) + (rx * HALF + (ry >> 1)) * HS4) + j;
-			if (side >= 2) *LR = PAR ? make_float2(v.y, v.w) : make_float2(v.x, v.z);
+	for (int n = 0; n < NJ; ++n) {
+		if (rim_on[n]) {
+			const sb4f v = rimv[n];
+			float2* LR = reinterpret_cast<float2*>(L.arr(PAR ? 1 : 0, 0)) + rim_lds[n];
+			float2* LK = reinterpret_cast<float2*>(L.arr(PAR ? 1 : 0, 1)) + rim_lds[n];
+			if (rim_red[n]) *LR = PAR ? make_float2(v.y, v.w) : make_float2(v.x, v.z);
 			*LK = PAR ? make_float2(v.x, v.z) : make_float2(v.y, v.w);
 		}
 	}
