@@ -586,14 +586,14 @@ int hns_rbgs_block_shape(hns_grid* g, int* k_max) {
 	return lb;
 }
 
-// The lean form (row state in LDS, three workgroups per CU) where a launch runs to several rounds of workgroups and the grid still sits
-// in the Infinity Cache: one workgroup's latency is longer in it (128^3: 7.3 against 6.6 us per iteration), its throughput higher (1,000
-// blocks 11.2 against 11.6, 256^3 33.8-35.2 against 35.3-35.6, 66k-leaf plume 83.4 against 84.0), and beyond ~100k leaves the fabric
-// bounds both (512^3: 314 against 307-310) -- profiles/r03_sorblock_notes.txt 11. Option "sor_block_lean" = auto | 0 | 1.
+// The lean form (row state in LDS, three workgroups per CU) wherever a launch does not fit the chip in one round of two workgroups per
+// CU (more than 512 blocks). One workgroup's latency is longer in it (128^3, 512 blocks: 6.8 against 6.6 us per iteration), its throughput
+// higher: 600-block plume 7.96 against 8.36, 1,000 blocks 10.3 against 11.5, 256^3 32.3 against 35.3, 66k-leaf plume 80.1 against 84.8,
+// 512^3 293 against 304 (profiles/r03_sorblock_notes.txt 11). Option "sor_block_lean" = auto | 0 | 1.
 bool hns_rbgs_block_lean(hns_grid* g, int lb, int k) {
 	if (lb != 2 || k != 2) return false;
 	const int lo = options().sor_block_lean.load();
-	return lo == 0 ? (g->n_sb >= 768 && g->n_sb < 16384) : lo == 2;
+	return lo == 0 ? g->n_sb > 512 : lo == 2;
 }
 
 // one launch: k iterations src -> dst
