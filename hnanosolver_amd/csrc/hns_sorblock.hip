@@ -377,11 +377,18 @@ __device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, const int t, const
 	}
 	unsigned base[C];
 	SbLeanRow<C, HALF> r;
+	int ids[C];
+	if (C == 4 && LB == 2) {  // (the four ids along z are one aligned 16-byte piece of the record)
+		const int4 q4 = valid ? *reinterpret_cast<const int4*>(rec) : make_int4(-1, -1, -1, -1);
+		ids[0] = q4.x, ids[1] = q4.y, ids[2] = q4.z, ids[C - 1] = q4.w;
+	} else {
+#pragma unroll
+		for (int cz = 0; cz < C; ++cz) ids[cz] = valid ? rec[cz] : -1;
+	}
 #pragma unroll
 	for (int cz = 0; cz < C; ++cz) {
-		const int id = valid ? rec[cz] : -1;
-		r.ok[cz] = id >= 0 ? 0xFFFFFFFFu : 0u;
-		base[cz] = (unsigned)id * 2048u + row_bytes;
+		r.ok[cz] = ids[cz] >= 0 ? 0xFFFFFFFFu : 0u;
+		base[cz] = (unsigned)ids[cz] * 2048u + row_bytes;
 	}
 	const sb4i rp = sb_rsrc(p_in, field_bytes), rd = sb_rsrc(div, field_bytes), ro = sb_rsrc(p_out, field_bytes);
 	sb4f rimv[NJ], pc[NCH], dc[NCH];
