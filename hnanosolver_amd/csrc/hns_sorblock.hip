@@ -338,8 +338,8 @@ struct SbSweepsLean {
 };
 
 template <int LB, int K, bool ZERO, bool PAR>
-__device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, const int t, const int* __restrict__ recs, const float* __restrict__ div, const float* __restrict__ p_in,
-                                             float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega) {
+__device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, const int t, const int* __restrict__ recs, const int* __restrict__ any_absent, const float* __restrict__ div,
+                                             const float* __restrict__ p_in, float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega) {
 	using G = SbGeo<LB, K>;
 	constexpr int H = G::H, T = G::T, C = G::C, HALF = G::HALF, NQ = G::NQ, NCH = G::NCH, HS4 = G::HS4;
 	static_assert(NCH == 2 * NQ, "two 16-byte pieces of a row in memory make one piece of each colour array");
@@ -425,10 +425,17 @@ __device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, const int t, const
 		r.dR[2 * j] = PAR ? d1 : d0, r.dB[2 * j] = PAR ? d0 : d1;
 		r.dR[2 * j + 1] = PAR ? d3 : d2, r.dB[2 * j + 1] = PAR ? d2 : d3;
 	}
-	bool mine = true;
+	// (the barrier behind the staging; whether a leaf under the tile is absent -- voxels need masking then -- is in the block table)
+	bool all_present;
+	if (any_absent) {
+		all_present = __builtin_amdgcn_readfirstlane(any_absent[blockIdx.x]) == 0;
+		__syncthreads();
+	} else {
+		bool mine = true;
 #pragma unroll
-	for (int cz = 0; cz < C; ++cz) mine = mine && (r.ok[cz] != 0u || !valid);
-	const bool all_present = __syncthreads_and(mine) != 0;
+		for (int cz = 0; cz < C; ++cz) mine = mine && (r.ok[cz] != 0u || !valid);
+		all_present = __syncthreads_and(mine) != 0;
+	}
 	if (all_present)
 		SbSweepsLean<LB, K, 1, PAR, false>::run(r, L, i, b, dist, omega);
 	else
@@ -459,7 +466,7 @@ __device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, const int t, const
 // HNanoSolver.cu:113) and is not read. The first half of the workgroup's waves takes the rows with even x+y, the second half
 // those with odd x+y; both halves meet at the same number of barriers.
 template <int LB, int K, bool ZERO, bool LEAN = false>
-__global__ __attribute__((amdgpu_waves_per_eu(LEAN ? 6 : 1, 8))) __launch_bounds__((SbGeo<LB, K>::NT)) void k_rbgs_block(const int* __restrict__ recs, const float* __restrict__ div, const float* __restrict__ p_in,
+__global__ __attribute__((amdgpu_waves_per_eu(LEAN ? 6 : 1, 8))) __launch_bounds__((SbGeo<LB, K>::NT)) void k_rbgs_block(const int* __restrict__ recs, const int* __restrict__ any_absent, const float* __restrict__ div, const float* __restrict__ p_in,
                                                                 float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega, const int stagger) {
 	using G = SbGeo<LB, K>;
 	__shared__ SbLds<LB, K> L;
@@ -480,9 +487,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(LEAN ? 6 : 1, 8))) __launch_bounds
 	if constexpr (LEAN) {
 		static_assert(G::CAN_LEAN, "the lean form is written for 24-voxel tiles");
 		if (__builtin_amdgcn_readfirstlane(t >= G::SEC))
-			sb_body_lean<LB, K, ZERO, true>(L, t - G::SEC, recs, div, p_in, p_out, field_bytes, dx2, omega);
+			sb_body_lean<LB, K, ZERO, true>(L, t - G::SEC, recs, any_absent, div, p_in, p_out, field_bytes, dx2, omega);
 		else
-			sb_body_lean<LB, K, ZERO, false>(L, t, recs, div, p_in, p_out, field_bytes, dx2, omega);
+			sb_body_lean<LB, K, ZERO, false>(L, t, recs, any_absent, div, p_in, p_out, field_bytes, dx2, omega);
 	} else {
 		if (__builtin_amdgcn_readfirstlane(t >= G::SEC))
 			sb_body<LB, K, ZERO, true>(L, t - G::SEC, recs, div, p_in, p_out, field_bytes, dx2, omega);
@@ -539,6 +546,7 @@ __global__ __launch_bounds__(256) void k_sb_table(GridDev g, const int* __restri
 	int leaf = -1;
 	if (x >= INT32_MIN && x <= INT32_MAX && y >= INT32_MIN && y <= INT32_MAX && z >= INT32_MIN && z <= INT32_MAX) leaf = d_find_leaf(g, (int)x, (int)y, (int)z);
 	tab[i] = leaf;
+	if (leaf < 0) tab[(int64_t)n_blocks * 64 + b] = 1;  // behind the records: "a leaf under this block's tile is absent" (zeroed by the host)
 }
 
 }  // namespace hns
@@ -568,7 +576,8 @@ int hns_grid_build_blocks(hns_grid* g) {
 	int nb = 0;
 	HNS_HIP(hipMemcpy(&nb, total, sizeof(int), hipMemcpyDeviceToHost));
 	if (nb <= 0) return fail(HNS_ERR_RUNTIME, "hns_grid_build_blocks: no block leader found");
-	if (int rc = hns_arena_get(sizeof(int) * 64 * (size_t)nb, g->device, &g->d_sb_tab, &g->sb_bytes)) return rc;
+	if (int rc = hns_arena_get(sizeof(int) * 65 * (size_t)nb, g->device, &g->d_sb_tab, &g->sb_bytes)) return rc;
+	HNS_HIP(hipMemsetAsync((int*)g->d_sb_tab + (size_t)nb * 64, 0, sizeof(int) * (size_t)nb, 0));
 	k_sb_table<<<(unsigned)(((int64_t)nb * 64 + 255) / 256), 256, 0, 0>>>(gd, leaders, nb, seg, (int*)g->d_sb_tab);
 	HNS_HIP(hipDeviceSynchronize());
 	g->n_sb = (uint64_t)nb;
@@ -616,18 +625,18 @@ int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const fl
 #define SB_LAUNCH(LB_, K_, recs, nblk)                                                                                                            \
 	do {                                                                                                                                           \
 		if (src_is_zero)                                                                                                                           \
-			hipLaunchKernelGGL((k_rbgs_block<LB_, K_, true>), dim3((unsigned)(nblk)), dim3(SbGeo<LB_, K_>::NT), 0, st, (const int*)(recs), div, src, dst, bytes, dx2, omega, stag); \
+			hipLaunchKernelGGL((k_rbgs_block<LB_, K_, true>), dim3((unsigned)(nblk)), dim3(SbGeo<LB_, K_>::NT), 0, st, (const int*)(recs), (const int*)nullptr, div, src, dst, bytes, dx2, omega, stag); \
 		else                                                                                                                                       \
-			hipLaunchKernelGGL((k_rbgs_block<LB_, K_, false>), dim3((unsigned)(nblk)), dim3(SbGeo<LB_, K_>::NT), 0, st, (const int*)(recs), div, src, dst, bytes, dx2, omega, stag); \
+			hipLaunchKernelGGL((k_rbgs_block<LB_, K_, false>), dim3((unsigned)(nblk)), dim3(SbGeo<LB_, K_>::NT), 0, st, (const int*)(recs), (const int*)nullptr, div, src, dst, bytes, dx2, omega, stag); \
 	} while (0)
 	if (lb == 1 && k == 2) SB_LAUNCH(1, 2, g->d_blk, g->n_active);
 	else if (lb == 1 && k == 4) SB_LAUNCH(1, 4, g->d_blk, g->n_active);
 	else if (lb == 2 && k == 2 && lean) {
 		const int sl = options().sor_block_lean_stagger.load();
 		if (src_is_zero)
-			hipLaunchKernelGGL((k_rbgs_block<2, 2, true, true>), dim3((unsigned)g->n_sb), dim3(SbGeo<2, 2>::NT), 0, st, (const int*)g->d_sb_tab, div, src, dst, bytes, dx2, omega, sl);
+			hipLaunchKernelGGL((k_rbgs_block<2, 2, true, true>), dim3((unsigned)g->n_sb), dim3(SbGeo<2, 2>::NT), 0, st, (const int*)g->d_sb_tab, (const int*)g->d_sb_tab + (size_t)g->n_sb * 64, div, src, dst, bytes, dx2, omega, sl);
 		else
-			hipLaunchKernelGGL((k_rbgs_block<2, 2, false, true>), dim3((unsigned)g->n_sb), dim3(SbGeo<2, 2>::NT), 0, st, (const int*)g->d_sb_tab, div, src, dst, bytes, dx2, omega, sl);
+			hipLaunchKernelGGL((k_rbgs_block<2, 2, false, true>), dim3((unsigned)g->n_sb), dim3(SbGeo<2, 2>::NT), 0, st, (const int*)g->d_sb_tab, (const int*)g->d_sb_tab + (size_t)g->n_sb * 64, div, src, dst, bytes, dx2, omega, sl);
 	} else if (lb == 2 && k == 2) SB_LAUNCH(2, 2, g->d_sb_tab, g->n_sb);
 	else return fail(HNS_ERR_INVALID_ARGUMENT, "hns_rbgs_block_launch: unsupported block shape");
 #undef SB_LAUNCH
