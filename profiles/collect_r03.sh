@@ -35,7 +35,7 @@ out = sys.argv[1]
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 from bench import kernel_source_sha16
 p = json.load(open(out + "/pmc_256.json"))
-name = [k for k in p if k.startswith("hns::k_rbgs_block<2, 2, false>")] or [k for k in p if k.startswith("hns::k_rbgs_pair<false>")]
+name = [k for k in p if k.startswith("hns::k_rbgs_block<2, 2, false")] or [k for k in p if k.startswith("hns::k_rbgs_pair<false>")]
 k = p[name[0]]
 fetch_kb, write_kb = k["FETCH_SIZE"]["mean"], k["WRITE_SIZE"]["mean"]
 per_launch = 1024.0 * (2.0 * fetch_kb + write_kb)
