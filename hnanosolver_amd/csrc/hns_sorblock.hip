@@ -338,7 +338,7 @@ struct SbSweepsLean {
 };
 
 template <int LB, int K, bool ZERO, bool PAR>
-__device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, const int t, const int* __restrict__ recs, const int* __restrict__ any_absent, const float* __restrict__ div,
+__device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, int* s_rec, const int t, const int* __restrict__ recs, const int* __restrict__ any_absent, const float* __restrict__ div,
                                              const float* __restrict__ p_in, float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega) {
 	using G = SbGeo<LB, K>;
 	constexpr int H = G::H, T = G::T, C = G::C, HALF = G::HALF, NQ = G::NQ, NCH = G::NCH, HS4 = G::HS4;
@@ -351,6 +351,8 @@ __device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, const int t, const
 	const int dist = valid ? min(min(x, T - 1 - x), min(y, T - 1 - y)) : -1;
 	const int cx = (x - H + 8) >> 3, cy = (y - H + 8) >> 3;
 	const unsigned row_bytes = (unsigned)(((((x - H) & 7) << 3) | ((y - H) & 7)) * 32);
+	static_assert(LB == 2 && K == 2, "the store phase below is written for 16^3 blocks with a 4-voxel halo");
+	if (!PAR && t < 64) s_rec[t] = recs[(size_t)blockIdx.x * G::REC + t];  // the block record for the store phase (visible behind the staging barrier)
 	const int* __restrict__ rec = recs + (size_t)blockIdx.x * G::REC + (LB == 1 ? 1 : 0) + (cx * C + cy) * C;
 	// Rim duty: the RIM rim rows of this parity (nobody updates them: p only, straight into LDS) as RIM * NCH 16-byte pieces dealt over
 	// the section's threads -- six lanes per 96-byte row. Side 0: x = 0, 1: x = T-1, 2: y = 0, 3: y = T-1; the m-th row of the right
@@ -440,23 +442,27 @@ __device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, const int t, const
 		SbSweepsLean<LB, K, 1, PAR, false>::run(r, L, i, b, dist, omega);
 	else
 		SbSweepsLean<LB, K, 1, PAR, true>::run(r, L, i, b, dist, omega);
-	if (dist >= H) {  // the rows of the block itself, out of their own LDS entries (written by this thread: no barrier)
-		const float4* LR = L.arr(PAR ? 1 : 0, 0) + i * HS4;
-		const float4* LK = L.arr(PAR ? 1 : 0, 1) + i * HS4;
-		float R[HALF], B[HALF];
+	// Store phase: the block's 16 x 16 rows x four 16-byte pieces, dealt over ALL threads in memory order (piece = ((x * 2 + z half) * 16 + y)
+	// * 2 + piece of the leaf row): a wave writes eight whole 128-byte lines. Written by the row owners instead -- lanes 64 bytes apart,
+	// half of them idle -- the stores cost as much as all the div loads (a fifth of the launch at 256^3). The values come out of the rows'
+	// LDS entries (every thread wrote its last sweep there), the leaf ids out of the record's LDS copy.
+	__syncthreads();
+	{
+		const int tid = t + (PAR ? G::SEC : 0);
+		const float2* A = reinterpret_cast<const float2*>(L.a);
+		constexpr int PSTR = (SbLds<LB, K>::NB + SbLds<LB, K>::NR) * 2, ROFF = (SbLds<LB, K>::NB - HALF * HS4) * 2;  // in float2: parity stride, offset of a red array
 #pragma unroll
-		for (int q = 0; q < NQ; ++q) {
-			const float4 a = LR[q], c = LK[q];
-			R[4 * q] = a.x, R[4 * q + 1] = a.y, R[4 * q + 2] = a.z, R[4 * q + 3] = a.w;
-			B[4 * q] = c.x, B[4 * q + 1] = c.y, B[4 * q + 2] = c.z, B[4 * q + 3] = c.w;
-		}
-#pragma unroll
-		for (int j = H / 4; j < NCH - H / 4; ++j) {
-			const int cz = (4 * j - H + 8) >> 3, zl = (4 * j - H) & 7;
+		for (int n = 0; n < 2; ++n) {
+			const int pq = tid + n * G::NT;
+			const int jz = pq & 1, yy = (pq >> 1) & 15, czb = (pq >> 5) & 1, xx = pq >> 6;
+			const int x = xx + H, y = yy + H, j = H / 4 + 2 * czb + jz;
+			const int par = (x + y) & 1;
+			const int e = par * PSTR + (x * HALF + (y >> 1)) * HS4 * 2 + j;
+			const float2 rr = A[e + ROFF], bb = A[e];
+			const int id = s_rec[((1 + (xx >> 3)) * C + 1 + (yy >> 3)) * C + 1 + czb];
 			sb4f v;
-			v.x = PAR ? B[2 * j] : R[2 * j], v.y = PAR ? R[2 * j] : B[2 * j];
-			v.z = PAR ? B[2 * j + 1] : R[2 * j + 1], v.w = PAR ? R[2 * j + 1] : B[2 * j + 1];
-			sb_store4(v, ro, (int)(base[cz] + (unsigned)(zl * 4)), 0, 0);
+			v.x = par ? bb.x : rr.x, v.y = par ? rr.x : bb.x, v.z = par ? bb.y : rr.y, v.w = par ? rr.y : bb.y;
+			sb_store4(v, ro, (int)((unsigned)id * 2048u + (unsigned)((((xx & 7) << 3) | (yy & 7)) * 32 + jz * 16)), 0, 0);
 		}
 	}
 }
@@ -470,6 +476,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(LEAN ? 6 : 1, 8))) __launch_bounds
                                                                 float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega, const int stagger) {
 	using G = SbGeo<LB, K>;
 	__shared__ SbLds<LB, K> L;
+	__shared__ int s_rec[LEAN ? 64 : 1];
 	const int t = threadIdx.x;
 	constexpr unsigned PER_CU = LEAN ? 3u : 2u;  // workgroups of this kernel a CU holds
 	if (stagger > 0 && blockIdx.x < 256 * PER_CU) {  // (the first round: PER_CU workgroups on each of 256 CUs)
@@ -487,9 +494,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(LEAN ? 6 : 1, 8))) __launch_bounds
 	if constexpr (LEAN) {
 		static_assert(G::CAN_LEAN, "the lean form is written for 24-voxel tiles");
 		if (__builtin_amdgcn_readfirstlane(t >= G::SEC))
-			sb_body_lean<LB, K, ZERO, true>(L, t - G::SEC, recs, any_absent, div, p_in, p_out, field_bytes, dx2, omega);
+			sb_body_lean<LB, K, ZERO, true>(L, s_rec, t - G::SEC, recs, any_absent, div, p_in, p_out, field_bytes, dx2, omega);
 		else
-			sb_body_lean<LB, K, ZERO, false>(L, t, recs, any_absent, div, p_in, p_out, field_bytes, dx2, omega);
+			sb_body_lean<LB, K, ZERO, false>(L, s_rec, t, recs, any_absent, div, p_in, p_out, field_bytes, dx2, omega);
 	} else {
 		if (__builtin_amdgcn_readfirstlane(t >= G::SEC))
 			sb_body<LB, K, ZERO, true>(L, t - G::SEC, recs, div, p_in, p_out, field_bytes, dx2, omega);
