@@ -272,6 +272,24 @@ __device__ __forceinline__ void sb_body(SbLds<LB, K>& L, const int t, const int*
 	}
 }
 
+// LDS of the lean form. Rows are numbered DENSELY in the order of the threads that sweep them: row (x, y) of parity P, y = 1 + d + 2k with
+// d = (x + 1 + P) & 1 = (y + 1) & 1 and k = 0..HC-1, has number x * HC + k -- a wave's 64 rows are 64 consecutive numbers and a 16-byte
+// access at the 48-byte row stride is free of bank conflicts (SbLds numbers them x * HALF + (y >> 1): one unused number per plane, which
+// puts two lanes of every 16 onto the same banks -- a third of the LDS cycles of the sweeps were conflicts). The rim rows y = 0 / y = T-1,
+// one per plane and parity, follow the T * HC dense rows of a BLACK array (only the black values of a rim row are ever read: a black
+// update happens at distance >= 2 from the rim). A RED array has the planes 1 .. T-2 only and starts HC rows before its first row would
+// lie: [black 0: T*HC + T rows][red 0: (T-2)*HC rows][black 1][red 1] -- nobody may write a red value of plane 0 or T-1 or of a rim row.
+template <int LB, int K>
+struct SbLdsDense {
+	using G = SbGeo<LB, K>;
+	static constexpr int HC = G::HC, T = G::T, HS4 = G::HS4;
+	static constexpr int NB = (T * HC + T) * HS4, NR = (T - 2) * HC * HS4, ROFF = NB - HC * HS4, PSTR = NB + NR;
+	float4 a[2 * PSTR];
+	__device__ __forceinline__ float4* arr(int par, int colour) { return a + par * PSTR + (colour ? 0 : ROFF); }
+	static __device__ __forceinline__ int row(int x, int y) { return x * HC + ((y - 1 - ((y + 1) & 1)) >> 1); }  // dense number of an interior-y row
+	static __device__ __forceinline__ int rim_row(int x) { return T * HC + x; }                                // the y-rim row of plane x
+};
+
 // ---- the lean form (SbGeo::LEAN): the same sweeps with the thread's own row read from and written to its LDS entry ----
 
 template <int C, int HALF>
@@ -281,7 +299,7 @@ struct SbLeanRow {
 };
 
 template <int LB, int K, int S, bool PAR, bool MASKED, class Row>
-__device__ __forceinline__ void sb_sweep_lean(Row& r, SbLds<LB, K>& L, const int i, const int b, const int dist, const float omega) {
+__device__ __forceinline__ void sb_sweep_lean(Row& r, SbLdsDense<LB, K>& L, const int i, const int ep, const int em, const int dist, const float omega) {
 	using G = SbGeo<LB, K>;
 	constexpr int H = G::H, HALF = G::HALF, HS4 = G::HS4, NQ = G::NQ;
 	static_assert(NQ * 4 == HALF, "colour arrays are whole 16-byte pieces");
@@ -300,10 +318,10 @@ __device__ __forceinline__ void sb_sweep_lean(Row& r, SbLds<LB, K>& L, const int
 			const float4 y4 = LYo[q];
 			Y[4 * q] = y4.x, Y[4 * q + 1] = y4.y, Y[4 * q + 2] = y4.z, Y[4 * q + 3] = y4.w;
 		}
-		const float4* pxp = LY + (i + HALF) * HS4;
-		const float4* pxm = LY + (i - HALF) * HS4;
-		const float4* pyp = LY + (i + b) * HS4;
-		const float4* pym = LY + (i + b - 1) * HS4;
+		const float4* pxp = LY + (i + G::HC) * HS4;  // rows (x+1, y), (x-1, y): same k, the planes next door
+		const float4* pxm = LY + (i - G::HC) * HS4;
+		const float4* pyp = LY + ep * HS4;           // rows (x, y+1), (x, y-1): numbers from the body (a rim row at the ends of a plane)
+		const float4* pym = LY + em * HS4;
 #pragma unroll
 		for (int q = qlo; q < qhi; ++q) {
 			const float4 x4 = LXo[q];
@@ -331,23 +349,26 @@ __device__ __forceinline__ void sb_sweep_lean(Row& r, SbLds<LB, K>& L, const int
 template <int LB, int K, int S, bool PAR, bool MASKED>
 struct SbSweepsLean {
 	template <class Row>
-	static __device__ __forceinline__ void run(Row& r, SbLds<LB, K>& L, const int i, const int b, const int dist, const float omega) {
-		sb_sweep_lean<LB, K, S, PAR, MASKED>(r, L, i, b, dist, omega);
-		if constexpr (S < 2 * K) SbSweepsLean<LB, K, S + 1, PAR, MASKED>::run(r, L, i, b, dist, omega);
+	static __device__ __forceinline__ void run(Row& r, SbLdsDense<LB, K>& L, const int i, const int ep, const int em, const int dist, const float omega) {
+		sb_sweep_lean<LB, K, S, PAR, MASKED>(r, L, i, ep, em, dist, omega);
+		if constexpr (S < 2 * K) SbSweepsLean<LB, K, S + 1, PAR, MASKED>::run(r, L, i, ep, em, dist, omega);
 	}
 };
 
 template <int LB, int K, bool ZERO, bool PAR>
-__device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, int* s_rec, const int t, const int* __restrict__ recs, const int* __restrict__ any_absent, const float* __restrict__ div,
+__device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, const int t, const int* __restrict__ recs, const int* __restrict__ any_absent, const float* __restrict__ div,
                                              const float* __restrict__ p_in, float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega) {
 	using G = SbGeo<LB, K>;
 	constexpr int H = G::H, T = G::T, C = G::C, HALF = G::HALF, NQ = G::NQ, NCH = G::NCH, HS4 = G::HS4;
 	static_assert(NCH == 2 * NQ, "two 16-byte pieces of a row in memory make one piece of each colour array");
 	const bool valid = t < G::CROWS;
 	const int xq = valid ? t / G::HC : 0;
-	const int x = 1 + xq, y = valid ? 1 + 2 * (t - xq * G::HC) + ((x + 1 + (PAR ? 1 : 0)) & 1) : 1;
-	const int b = y & 1;
-	const int i = x * HALF + (y >> 1);
+	const int kk = valid ? t - xq * G::HC : 0, dl = (xq + (PAR ? 1 : 0)) & 1;  // (dl = (x + 1 + PAR) & 1)
+	const int x = 1 + xq, y = valid ? 1 + dl + 2 * kk : 1;
+	const int i = x * G::HC + kk;  // the row's dense LDS number (= t + HC)
+	// the rows (x, y+1), (x, y-1) of the other parity: k + dl and k + dl - 1 in the same plane, or the plane's rim row beyond its ends
+	const int ep = (dl == 1 && kk == G::HC - 1) ? SbLdsDense<LB, K>::rim_row(x) : i + dl;
+	const int em = (dl == 0 && kk == 0) ? SbLdsDense<LB, K>::rim_row(x) : i + dl - 1;
 	const int dist = valid ? min(min(x, T - 1 - x), min(y, T - 1 - y)) : -1;
 	const int cx = (x - H + 8) >> 3, cy = (y - H + 8) >> 3;
 	const unsigned row_bytes = (unsigned)(((((x - H) & 7) << 3) | ((y - H) & 7)) * 32);
@@ -359,7 +380,7 @@ __device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, int* s_rec, const 
 	// parity along the side. (Red values of sides 0 and 1 have no place in LDS and no reader: SbLds.) Its leaf id is fetched together
 	// with the row's own, its load issued in front of the row's: one memory round trip for ids, one for data.
 	constexpr int NJ = (G::RIM * NCH + G::SEC - 1) / G::SEC;
-	bool rim_on[NJ], rim_red[NJ];
+	bool rim_on[NJ];
 	int rim_lds[NJ];       // float2 index of the piece in a colour array
 	unsigned rim_off[NJ];  // byte offset of the piece inside its leaf
 	int rim_id[NJ];
@@ -373,8 +394,7 @@ __device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, int* s_rec, const 
 		const int rx = side == 0 ? 0 : (side == 1 ? T - 1 : along), ry = side == 2 ? 0 : (side == 3 ? T - 1 : along);
 		const int rcx = (rx - H + 8) >> 3, rcy = (ry - H + 8) >> 3, rcz = (4 * j - H + 8) >> 3;
 		rim_off[n] = (unsigned)(((((rx - H) & 7) << 3) | ((ry - H) & 7)) * 32 + ((4 * j - H) & 7) * 4);
-		rim_red[n] = side >= 2;
-		rim_lds[n] = (rx * HALF + (ry >> 1)) * HS4 * 2 + j;
+		rim_lds[n] = (side >= 2 ? SbLdsDense<LB, K>::rim_row(rx) : SbLdsDense<LB, K>::row(rx, ry)) * HS4 * 2 + j;
 		rim_id[n] = (!ZERO && rim_on[n]) ? recs[(size_t)blockIdx.x * G::REC + (LB == 1 ? 1 : 0) + (rcx * C + rcy) * C + rcz] : -1;
 	}
 	unsigned base[C];
@@ -416,9 +436,7 @@ __device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, int* s_rec, const 
 	for (int n = 0; n < NJ; ++n) {
 		if (rim_on[n]) {
 			const sb4f v = rimv[n];
-			float2* LR = reinterpret_cast<float2*>(L.arr(PAR ? 1 : 0, 0)) + rim_lds[n];
-			float2* LK = reinterpret_cast<float2*>(L.arr(PAR ? 1 : 0, 1)) + rim_lds[n];
-			if (rim_red[n]) *LR = PAR ? make_float2(v.y, v.w) : make_float2(v.x, v.z);
+			float2* LK = reinterpret_cast<float2*>(L.arr(PAR ? 1 : 0, 1)) + rim_lds[n];  // (black only: nobody reads a rim row's red values)
 			*LK = PAR ? make_float2(v.x, v.z) : make_float2(v.y, v.w);
 		}
 	}
@@ -426,8 +444,8 @@ __device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, int* s_rec, const 
 	// row's LDS entry: its even z go to the red array of its parity if x+y is even, to the black one if odd
 	if (valid2) {
 		const int par2 = (x2 + y2) & 1;
-		float4* base = L.a + par2 * (SbLds<LB, K>::NB + SbLds<LB, K>::NR) + (x2 * HALF + (y2 >> 1)) * HS4;
-		constexpr int ROFF = SbLds<LB, K>::NB - HALF * HS4;  // a parity's red array behind its black one (SbLds::arr)
+		float4* base = L.a + par2 * SbLdsDense<LB, K>::PSTR + SbLdsDense<LB, K>::row(x2, y2) * HS4;
+		constexpr int ROFF = SbLdsDense<LB, K>::ROFF;  // a parity's red array behind its black one (SbLdsDense::arr)
 		float4* LE = base + (par2 ? 0 : ROFF);
 		float4* LO = base + (par2 ? ROFF : 0);
 #pragma unroll
@@ -455,9 +473,9 @@ __device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, int* s_rec, const 
 		all_present = __syncthreads_and(mine) != 0;
 	}
 	if (all_present)
-		SbSweepsLean<LB, K, 1, PAR, false>::run(r, L, i, b, dist, omega);
+		SbSweepsLean<LB, K, 1, PAR, false>::run(r, L, i, ep, em, dist, omega);
 	else
-		SbSweepsLean<LB, K, 1, PAR, true>::run(r, L, i, b, dist, omega);
+		SbSweepsLean<LB, K, 1, PAR, true>::run(r, L, i, ep, em, dist, omega);
 	// Store phase: the block's 16 x 16 rows x four 16-byte pieces, dealt over ALL threads in memory order (piece = ((x * 2 + z half) * 16 + y)
 	// * 2 + piece of the leaf row): a wave writes eight whole 128-byte lines. Written by the row owners instead -- lanes 64 bytes apart,
 	// half of them idle -- the stores cost as much as all the div loads (a fifth of the launch at 256^3). The values come out of the rows'
@@ -465,14 +483,14 @@ __device__ __forceinline__ void sb_body_lean(SbLds<LB, K>& L, int* s_rec, const 
 	__syncthreads();
 	{
 		const float2* A = reinterpret_cast<const float2*>(L.a);
-		constexpr int PSTR = (SbLds<LB, K>::NB + SbLds<LB, K>::NR) * 2, ROFF = (SbLds<LB, K>::NB - HALF * HS4) * 2;  // in float2: parity stride, offset of a red array
+		constexpr int PSTR = SbLdsDense<LB, K>::PSTR * 2, ROFF = SbLdsDense<LB, K>::ROFF * 2;  // in float2: parity stride, offset of a red array
 #pragma unroll
 		for (int n = 0; n < 2; ++n) {
 			const int pq = tid + n * G::NT;
 			const int jz = pq & 1, yy = (pq >> 1) & 15, czb = (pq >> 5) & 1, xx = pq >> 6;
 			const int x = xx + H, y = yy + H, j = H / 4 + 2 * czb + jz;
 			const int par = (x + y) & 1;
-			const int e = par * PSTR + (x * HALF + (y >> 1)) * HS4 * 2 + j;
+			const int e = par * PSTR + SbLdsDense<LB, K>::row(x, y) * HS4 * 2 + j;
 			const float2 rr = A[e + ROFF], bb = A[e];
 			const int id = s_rec[((1 + (xx >> 3)) * C + 1 + (yy >> 3)) * C + 1 + czb];
 			sb4f v;
@@ -490,7 +508,7 @@ template <int LB, int K, bool ZERO, bool LEAN = false>
 __global__ __attribute__((amdgpu_waves_per_eu(LEAN ? 6 : 1, 8))) __launch_bounds__((SbGeo<LB, K>::NT)) void k_rbgs_block(const int* __restrict__ recs, const int* __restrict__ any_absent, const float* __restrict__ div, const float* __restrict__ p_in,
                                                                 float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega, const int stagger) {
 	using G = SbGeo<LB, K>;
-	__shared__ SbLds<LB, K> L;
+	__shared__ typename std::conditional<LEAN, SbLdsDense<LB, K>, SbLds<LB, K>>::type L;
 	__shared__ int s_rec[LEAN ? 64 : 1];
 	const int t = threadIdx.x;
 	constexpr unsigned PER_CU = LEAN ? 3u : 2u;  // workgroups of this kernel a CU holds
