@@ -642,14 +642,14 @@ int hns_rbgs_block_shape(hns_grid* g, int* k_max) {
 	return lb;
 }
 
-// The lean form (row state in LDS, three workgroups per CU) wherever a launch does not fit the chip in one round of two workgroups per
-// CU (more than 512 blocks). One workgroup's latency is longer in it (128^3, 512 blocks: 6.8 against 6.6 us per iteration), its throughput
-// higher: 600-block plume 7.96 against 8.36, 1,000 blocks 10.3 against 11.5, 256^3 32.3 against 35.3, 66k-leaf plume 80.1 against 84.8,
-// 512^3 293 against 304 (profiles/r03_sorblock_notes.txt 11). Option "sor_block_lean" = auto | 0 | 1.
+// 16^3 blocks are swept by the lean form (row state in LDS, three workgroups per CU, dense LDS rows, p fetched and stored in memory
+// order); the rows-in-registers form remains for one-leaf blocks and as a cross-check. us per iteration, registers -> lean: 512 leaves
+// in 64 blocks 3.70 -> 3.37, 128^3 6.57 -> 5.62, 4k-leaf plume 8.34 -> 6.64, 256^3 35.3 -> 27.2, 512^3 304 -> 273, 66k-leaf plume
+// 84.8 -> 74.2 (profiles/r03_sorblock_notes.txt 11-12). Option "sor_block_lean" = auto | 0 | 1.
 bool hns_rbgs_block_lean(hns_grid* g, int lb, int k) {
+	(void)g;
 	if (lb != 2 || k != 2) return false;
-	const int lo = options().sor_block_lean.load();
-	return lo == 0 ? g->n_sb > 512 : lo == 2;
+	return options().sor_block_lean.load() != 1;  // (stored: 0 = auto, 1 = "0", 2 = "1")
 }
 
 // one launch: k iterations src -> dst
