@@ -309,37 +309,51 @@ __device__ __forceinline__ void sb_sweep_lean(Row& r, SbLdsDense<LB, K>& L, cons
 	float4* LXo = L.arr(PAR ? 1 : 0, red ? 0 : 1) + i * HS4;        // this row, the colour being updated (nobody else touches it in this sweep)
 	const float4* LYo = L.arr(PAR ? 1 : 0, red ? 1 : 0) + i * HS4;  // this row, the other colour: the z neighbours
 	constexpr bool up = red ? PAR : !PAR;  // as sb_sweep
-	constexpr int qlo = (S / 2) / 4, qhi = (HALF - S / 2 + 3) / 4;
-	constexpr int jlo = 4 * qlo, jhi = 4 * qhi < HALF ? 4 * qhi : HALF;
+	// Voxels closer than S to the tile's rim along z are stale at this sweep and beyond anyone's reach afterwards: they are not computed
+	// (38 instead of 48 updates per row over the four sweeps). X[j] sits at z' = 2j + (up ? 1 : 0). The LDS accesses stay whole 16-byte
+	// pieces -- pinned below, or the compiler narrows them to the elements used and the narrower accesses collide in the banks.
+	constexpr int zo = up ? 1 : 0;
+	constexpr int jlo = (S - zo + 1) / 2, jhi = (G::T - 1 - S - zo) / 2 + 1;  // updated: jlo <= j < jhi
+	constexpr int qlo = jlo / 4, qhi = (jhi + 3) / 4;
 	if (dist >= S) {
 		float Y[HALF];
+		const sb4f* LYo4 = reinterpret_cast<const sb4f*>(LYo);
 #pragma unroll
 		for (int q = 0; q < NQ; ++q) {
-			const float4 y4 = LYo[q];
+			const sb4f y4 = LYo4[q];
 			Y[4 * q] = y4.x, Y[4 * q + 1] = y4.y, Y[4 * q + 2] = y4.z, Y[4 * q + 3] = y4.w;
 		}
-		const float4* pxp = LY + (i + G::HC) * HS4;  // rows (x+1, y), (x-1, y): same k, the planes next door
-		const float4* pxm = LY + (i - G::HC) * HS4;
-		const float4* pyp = LY + ep * HS4;           // rows (x, y+1), (x, y-1): numbers from the body (a rim row at the ends of a plane)
-		const float4* pym = LY + em * HS4;
+		const sb4f* pxp = reinterpret_cast<const sb4f*>(LY + (i + G::HC) * HS4);  // rows (x+1, y), (x-1, y): same k, the planes next door
+		const sb4f* pxm = reinterpret_cast<const sb4f*>(LY + (i - G::HC) * HS4);
+		const sb4f* pyp = reinterpret_cast<const sb4f*>(LY + ep * HS4);           // rows (x, y+1), (x, y-1): numbers from the body (a rim row at the ends of a plane)
+		const sb4f* pym = reinterpret_cast<const sb4f*>(LY + em * HS4);
+		sb4f* LXo4 = reinterpret_cast<sb4f*>(LXo);
 #pragma unroll
 		for (int q = qlo; q < qhi; ++q) {
-			const float4 x4 = LXo[q];
-			const float4 xp4 = pxp[q], xm4 = pxm[q], yp4 = pyp[q], ym4 = pym[q];
+			sb4f x4 = LXo4[q], xp4 = pxp[q], xm4 = pxm[q], yp4 = pyp[q], ym4 = pym[q];
+			if (4 * q < jlo || 4 * q + 4 > jhi) {  // a piece only part of which is updated: keep its accesses whole
+				asm volatile("" : "+v"(x4));
+				asm volatile("" : "+v"(xp4));
+				asm volatile("" : "+v"(xm4));
+				asm volatile("" : "+v"(yp4));
+				asm volatile("" : "+v"(ym4));
+			}
 			float X[4] = {x4.x, x4.y, x4.z, x4.w};
-			const float lat[4] = {xp4.x + xm4.x + yp4.x + ym4.x, xp4.y + xm4.y + yp4.y + ym4.y, xp4.z + xm4.z + yp4.z + ym4.z, xp4.w + xm4.w + yp4.w + ym4.w};
+			const float xp[4] = {xp4.x, xp4.y, xp4.z, xp4.w}, xm[4] = {xm4.x, xm4.y, xm4.z, xm4.w}, yp[4] = {yp4.x, yp4.y, yp4.z, yp4.w}, ym[4] = {ym4.x, ym4.y, ym4.z, ym4.w};
 #pragma unroll
 			for (int e = 0; e < 4; ++e) {
 				const int j = 4 * q + e;
 				if (j < jlo || j >= jhi) continue;
 				const float below = j > 0 ? Y[j > 0 ? j - 1 : 0] : 0.0f, above = j + 1 < HALF ? Y[j + 1 < HALF ? j + 1 : 0] : 0.0f;
 				const float zm = up ? Y[j] : below, zp = up ? above : Y[j];
-				const float pGS = ((lat[e] + zp + zm) - dX[j]) * kInv6;  // Kernel.cu:621 (dX = div * dx^2)
-				const float cand = X[e] + omega * (pGS - X[e]);          // Kernel.cu:622
+				const float pGS = ((xp[e] + xm[e] + yp[e] + ym[e] + zp + zm) - dX[j]) * kInv6;  // Kernel.cu:621 (dX = div * dx^2)
+				const float cand = X[e] + omega * (pGS - X[e]);                                   // Kernel.cu:622
 				const int cz = (2 * j - H + 8) >> 3;
 				X[e] = MASKED ? __uint_as_float(__float_as_uint(cand) & r.ok[cz]) : cand;
 			}
-			LXo[q] = make_float4(X[0], X[1], X[2], X[3]);
+			sb4f o4 = sb4f{X[0], X[1], X[2], X[3]};
+			if (4 * q < jlo || 4 * q + 4 > jhi) asm volatile("" : "+v"(o4));
+			LXo4[q] = o4;
 			__builtin_amdgcn_sched_barrier(0);
 		}
 	}
