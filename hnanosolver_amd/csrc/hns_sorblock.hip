@@ -389,20 +389,24 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 	static_assert(LB == 2 && K == 2, "the store phase below is written for 16^3 blocks with a 4-voxel halo");
 	if (!PAR && t < 64) s_rec[t] = recs[(size_t)blockIdx.x * G::REC + t];  // the block record for the store phase (visible behind the staging barrier)
 	const int* __restrict__ rec = recs + (size_t)blockIdx.x * G::REC + (LB == 1 ? 1 : 0) + (cx * C + cy) * C;
-	// Rim duty: the RIM rim rows of this parity (nobody updates them: p only, straight into LDS) as RIM * NCH 16-byte pieces dealt over
-	// the section's threads -- six lanes per 96-byte row. Side 0: x = 0, 1: x = T-1, 2: y = 0, 3: y = T-1; the m-th row of the right
-	// parity along the side. (Red values of sides 0 and 1 have no place in LDS and no reader: SbLds.) Its leaf id is fetched together
-	// with the row's own, its load issued in front of the row's: one memory round trip for ids, one for data.
-	constexpr int NJ = (G::RIM * NCH + G::SEC - 1) / G::SEC;
+	// Rim duty: the RIM rim rows of this parity (nobody updates them: the black values of p only, straight into LDS) as 16-byte pieces
+	// dealt over the section's threads. Side 0: x = 0, 1: x = T-1, 2: y = 0, 3: y = T-1; the m-th row of the right parity along the side.
+	// Only the pieces j = 1 .. NCH-2 are fetched: a rim row is H voxels from the block in x or y, so what it holds within H of the
+	// tile's z ends is more than H steps from every block voxel and never reaches one in 2K sweeps; those two pieces are zeroed.
+	// The piece's leaf id is fetched together with the row's own ids, its load issued in front of the row's: one memory round trip
+	// for ids, one for data.
+	constexpr int NJ = 1, RJ = NCH - 2;
+	static_assert(G::RIM * RJ <= G::SEC && RJ == 4, "one rim piece per thread");
 	bool rim_on[NJ];
 	int rim_lds[NJ];       // float2 index of the piece in a colour array
 	unsigned rim_off[NJ];  // byte offset of the piece inside its leaf
 	int rim_id[NJ];
-#pragma unroll
-	for (int n = 0; n < NJ; ++n) {
-		const int q = n * G::SEC + t;
-		rim_on[n] = q < G::RIM * NCH;
-		const int mr = rim_on[n] ? q / NCH : 0, j = rim_on[n] ? q - mr * NCH : 0;
+	int rim_zero = 0;      // float2 offset of the end piece this thread zeroes (0: none)
+	{
+		constexpr int n = 0;
+		const int q = t;
+		rim_on[n] = q < G::RIM * RJ;
+		const int mr = rim_on[n] ? q >> 2 : 0, j = 1 + (q & 3);
 		const int side = mr / G::HC, m = mr - side * G::HC;
 		const int along = 2 * m + (((side & 1) != 0) == PAR ? 2 : 1);  // sides 0, 2: along + 0 has parity PAR; sides 1, 3: along + T-1 (odd)
 		const int rx = side == 0 ? 0 : (side == 1 ? T - 1 : along), ry = side == 2 ? 0 : (side == 3 ? T - 1 : along);
@@ -410,6 +414,7 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 		rim_off[n] = (unsigned)(((((rx - H) & 7) << 3) | ((ry - H) & 7)) * 32 + ((4 * j - H) & 7) * 4);
 		rim_lds[n] = (side >= 2 ? SbLdsDense<LB, K>::rim_row(rx) : SbLdsDense<LB, K>::row(rx, ry)) * HS4 * 2 + j;
 		rim_id[n] = (!ZERO && rim_on[n]) ? recs[(size_t)blockIdx.x * G::REC + (LB == 1 ? 1 : 0) + (rcx * C + rcy) * C + rcz] : -1;
+		rim_zero = j == 1 ? -1 : (j == RJ ? 1 : 0);
 	}
 	unsigned base[C];
 	SbLeanRow<C, HALF> r;
@@ -452,6 +457,7 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 			const sb4f v = rimv[n];
 			float2* LK = reinterpret_cast<float2*>(L.arr(PAR ? 1 : 0, 1)) + rim_lds[n];  // (black only: nobody reads a rim row's red values)
 			*LK = PAR ? make_float2(v.x, v.z) : make_float2(v.y, v.w);
+			if (rim_zero) LK[rim_zero] = make_float2(0.0f, 0.0f);
 		}
 	}
 	// the fetched row's p, split by colour (even z of a row with even x+y are red: colour = (x + y + z) & 1, Kernel.cu:599-601), into that
