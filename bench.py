@@ -358,6 +358,10 @@ def main():
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
+                "traffic_achieved": (traffic / (ms_launch * 1e-3) / 1e9) if (traffic and ms_launch) else None,  # GB/s of HBM-side bytes actually moved
+                "note": ("`achieved` prices the ALGORITHMIC bytes of SURVEY 8d -- one pass over p, p and div per red+black iteration, 12 B/voxel -- against the "
+                         "launch time; the temporally blocked kernel does several iterations per pass (iterations_per_launch), so it can exceed the HBM peak: "
+                         "`traffic` / `traffic_achieved` are the bytes it really moves") if iters_per_launch > 1 else None,
                 # per KERNEL LAUNCH, as rocprofv3 --stats lists the kernel: a launch of the temporally blocked form holds several red+black
                 # iterations (SURVEY 8d's unit of 12 B/voxel is the iteration), so its algorithmic bytes are 12 B/voxel x iterations per launch
                 "algorithmic_bytes_per_launch": BYTES_PER_VOXEL_ITER * n_vox_rank * iters_per_launch,
