@@ -22,6 +22,13 @@
 // neighbour); after 2K sweeps exactly the halo is, and the block inside it is what the reference computes.
 // Voxels of absent leaves load as 0 (hardware bounds check of a buffer descriptor), are never updated, and their stores
 // are dropped by the same check: "outside the domain p = 0" (Stencils.hpp:83) without a branch.
+//
+// Two forms of the kernel. The one described above (sb_body / sb_sweep: rows in registers) serves one-leaf blocks. 16^3 blocks
+// use the LEAN form (sb_body_lean / sb_sweep_lean, further down): the row state stays in LDS, where the neighbours need it
+// anyway, the thread keeps only div * dx^2; three workgroups fit a CU; LDS rows are numbered densely (no bank conflicts); p is
+// fetched and the block stored in memory order by whichever thread that makes coalesced; and only the part of the tile that
+// can reach the block in 2K sweeps is fetched and computed. DESIGN.md section 4 and profiles/r03_sorblock_notes.txt 10-12
+// have the measurements behind each of these.
 #include "hns_device.hpp"
 
 namespace hns {
