@@ -1,6 +1,8 @@
 #!/bin/bash
 # Experiment builds of libhns: the product sources plus ONE of the patches in this directory (timing switches and instrumentation live
 # here, not in the product kernels), compiled with extra -D flags into profiles/micro/exp/libhns_<name>.so (load with HNS_LIBRARY=...).
+# A patch is a record of an experiment: it applies to the product sources of the commit that added it (git log -- <patch>), not
+# necessarily to today's.
 #   build.sh <name> <patch file or -> [-Dflag ...]
 #     build.sh halo4   sor_halo_exp.patch   -DHNS_EXP=4           # pair SOR kernel without its y-face halo (results wrong, timing only)
 #     build.sh trace   sorblock_trace.patch -DHNS_SB_TRACE=2048   # s_memtime stamps of workgroups 2048..2111 (profiles/micro/sb_trace.py)
