@@ -2,7 +2,8 @@
 """bench.py -- solver substeps/s of the HNanoSolver hot path on MI355X, with the pressure stencil's HBM roofline.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 256|128|64|plume] [--iterations 50]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    (N > 1 without a launcher: bench.py starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself,
+    as a child process, before it touches the GPU; under a launcher -- WORLD_SIZE set -- it is a rank, as before)
 
 A "step" is one core substep on device-resident fields: advect_vector -> divergence -> 50 red-black
 SOR iterations -> pressure-gradient subtraction -> advect_scalars (S=1), i.e. 688 algorithmic bytes per voxel. Inputs
@@ -181,8 +182,29 @@ def cpu_baseline(origins, R, iterations, budget_s=25.0):
     }
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, as a CHILD process
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), let rank 0's JSON line
+    through on the inherited stdout and hand back the child's exit code. This parent never touches the GPU (no torch
+    import, no hns_* call) and never replaces itself with another program."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:  # a free rendezvous port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL and hipIpc need on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
 
@@ -190,7 +212,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE is {world}: launch N>1 with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE = {world} ranks: pass the same N to both")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     if args.share_one_gpu:
         local_rank = 0

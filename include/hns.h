@@ -6,11 +6,11 @@
  * conditions, but with plain pointers/sizes and int return codes instead of C++ types and exceptions:
  *
  *   hns_grid_create                 <- CreateIndexGrid          src/Cuda/HNanoSolver.cu:375-390   (decl. src/SOP/HNanoSolver/SOP_HNanoSolver.hpp:82)
- *   hns_compute_sim                 <- Compute_Sim              src/Cuda/HNanoSolver.cu:9-372,393-396 (decl. SOP_HNanoSolver.hpp:84-85)
- *   hns_advect_index_grid           <- AdvectIndexGrid          src/Cuda/Advection.cu:13-112,169-171  (decl. src/SOP/VDBAdvect/SOP_VDBAdvect.hpp:66)
- *   hns_advect_index_grid_velocity  <- AdvectIndexGridVelocity  src/Cuda/Advection.cu:114-166,173-175 (decl. src/SOP/VDBAdvectVelocity/SOP_VDBAdvectVelocity.hpp:60)
- *   hns_project_non_divergent       <- ProjectNonDivergent      src/Cuda/PressureProjection.cu:9-78,132-135 (decl. src/SOP/VDBProjectNonDivergent/SOP_VDBProjectNonDivergent.hpp:69)
- *   hns_divergence                  <- Divergence               src/Cuda/PressureProjection.cu:81-129       (decl. SOP_VDBProjectNonDivergent.hpp:70)
+ *   hns_compute_sim                 <- Compute_Sim              src/Cuda/HNanoSolver.cu:9-372,393-396 (decl. src/SOP/HNanoSolver/SOP_HNanoSolver.hpp:84-85)
+ *   hns_advect_index_grid           <- AdvectIndexGrid          src/Cuda/Advection.cu:13-112,169-171  (decl. src/SOP/Advection/SOP_VDBAdvect.hpp:66)
+ *   hns_advect_index_grid_velocity  <- AdvectIndexGridVelocity  src/Cuda/Advection.cu:114-166,173-175 (decl. src/SOP/VelocityAdvection/SOP_VDBAdvectVelocity.hpp:60)
+ *   hns_project_non_divergent       <- ProjectNonDivergent      src/Cuda/PressureProjection.cu:9-78,132-135 (decl. src/SOP/ProjectNonDivergent/SOP_VDBProjectNonDivergent.hpp:69)
+ *   hns_divergence                  <- Divergence               src/Cuda/PressureProjection.cu:81-129       (decl. src/SOP/ProjectNonDivergent/SOP_VDBProjectNonDivergent.hpp:70)
  *
  * The type crossing the boundary in the reference is HNS::GridIndexedData (src/Utils/GridData.hpp:16-166): a
  * coordinate array plus named float / Vec3f blocks in insertion order. Here it is `hns_field[]` (same order) and the
@@ -251,9 +251,13 @@ int hns_dev_advect_scalars(hns_grid*, const float* vel3, const float* const* in,
 int hns_dev_divergence(hns_grid*, const float* vel3, float* div, float inv_dx, void* stream);
 /* One colour of redBlackGaussSeidelUpdate(_opt) in place (Kernel.cu:521-623): the two-launch form. */
 int hns_dev_rbgs_color(hns_grid*, const float* div, float* p, float dx, float omega, int color, void* stream);
-/* `iterations` full (red, black) iterations with one fused launch per iteration, ping-ponging p_a -> p_b -> p_a ...
- * Bit-identical to 2*iterations calls of hns_dev_rbgs_color. Result is in p_a when iterations is even, else p_b
- * (*result_in_b tells). p_a and p_b must not alias. */
+/* `iterations` full (red, black) iterations, starting from p_a and ping-ponging p_a -> p_b -> p_a ... once per LAUNCH.
+ * Bit-identical to 2*iterations calls of hns_dev_rbgs_color. How many iterations a launch holds depends on the form the
+ * library picks for this grid (hns_grid_rbgs_plan: the temporally blocked form does 2 or 4 per launch, the others 1), so
+ * WHICH BUFFER HOLDS THE RESULT IS NOT A FUNCTION OF `iterations`: *result_in_b is 1 when it is p_b, 0 when it is p_a
+ * (e.g. blocked form: iterations = 2 -> p_b, 4 -> p_b or p_a, 6 -> p_b or p_a). A caller that wants the result must pass
+ * result_in_b and read it (NULL is accepted from callers that only time the solve). The other buffer holds an intermediate
+ * iterate. p_a and p_b must not alias. */
 int hns_dev_rbgs_iterate(hns_grid*, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int* result_in_b,
                          void* stream);
 /* subtractPressureGradient(_opt) (Kernel.cu:694-829); out3 may alias vel3 (each voxel reads only its own velocity) */

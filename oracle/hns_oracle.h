@@ -21,10 +21,16 @@
  *     code, compiled by oracle/Makefile from /root/reference);
  *   - sampler known answers from Tests/IndexGrid.cpp:212-223 and the index
  *     known answer from externals/nanovdb/unittest/TestNanoVDB.cu:311-355;
- *   - the kernel bodies (Kernel.cu) cannot be built here (they need the CUDA
- *     toolkit headers and CUB), the reference has no test that pins any
- *     kernel output, so the per-kernel arithmetic is "restated, pinned only
- *     through its samplers".
+ *   - the kernel bodies: the reference's src/Cuda/Kernel.cu itself, compiled
+ *     where it lies for the host into oracle/_ref/libhns_refk.so (g++, the
+ *     CUDA runtime headers the image ships, command-line macros for the nvcc
+ *     intrinsics; oracle/ref_kernels.cpp is the launch). tests/test_ref_kernels.py
+ *     holds every function below to it BIT FOR BIT: each kernel alone on
+ *     random sparse grids and fields, the "_opt" forms, and the three host
+ *     drivers against the reference's launch order. The committed goldens
+ *     tests/golden/kernel_goldens_v1.npz are that build's outputs.
+ *     Not pinned: nvcc's own FMA contraction (measured on the reference's
+ *     own code instead: `make ref_fma`, <= 1e-5 relative L-inf).
  *
  * Layout: flat leaf-dense arrays, index = leaf*512 + (x<<6 | y<<3 | z)
  * (src/Utils/GridBuilder.hpp:160-163), Vec3f as AoS float[3].

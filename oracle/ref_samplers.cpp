@@ -86,6 +86,21 @@ void ref_leaf_origins(void* h, int32_t* out) {
 	}
 }
 
+// the NanoGrid<ValueOnIndex>* itself, for ref_kernels.cpp (the reference's kernels take it as `domainGrid`)
+const void* ref_grid_nanogrid(void* h) { return static_cast<RefGrid*>(h)->grid; }
+
+// d_coords as the reference builds it: the coordinate of every value, in value order (offset(coords[i]) == i + 1)
+void ref_coords(void* h, int32_t* out) {
+	const auto* grid = static_cast<RefGrid*>(h)->grid;
+	const auto* leaf = grid->tree().getFirstNode<0>();
+	const uint32_t n = grid->tree().nodeCount(0);
+	for (uint32_t l = 0; l < n; ++l)
+		for (int v = 0; v < 512; ++v) {
+			const nanovdb::Coord c = leaf[l].offsetToGlobalCoord(v);
+			for (int a = 0; a < 3; ++a) out[(size_t(l) * 512 + v) * 3 + a] = c[a];
+		}
+}
+
 void ref_offsets(void* h, const int32_t* ijk, int64_t n, uint64_t* out) {
 	const IndexOffsetSampler<0> s(static_cast<RefGrid*>(h)->grid);
 	for (int64_t t = 0; t < n; ++t) out[t] = s.offset(ijk[3 * t], ijk[3 * t + 1], ijk[3 * t + 2]);

@@ -20,10 +20,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session", autouse=True)
 def _build_oracle():
     """The oracle is test infrastructure: make sure liboracle.so (and, when the reference checkout is present,
-    oracle/_ref/libhns_ref.so) exist before any test imports them."""
+    oracle/_ref/libhns_ref.so and libhns_refk.so = the reference's samplers and kernel bodies) exist before any test
+    imports them."""
     odir = os.path.join(ROOT, "oracle")
+    have_ref = os.path.exists("/root/reference/src/Utils/Stencils.hpp")
     if not os.path.exists(os.path.join(odir, "liboracle.so")) or (
-        os.path.exists("/root/reference/src/Utils/Stencils.hpp") and not os.path.exists(os.path.join(odir, "_ref", "libhns_ref.so"))
+        have_ref and not all(os.path.exists(os.path.join(odir, "_ref", n)) for n in ("libhns_ref.so", "libhns_refk.so"))
     ):
         subprocess.run(["make", "-C", odir], check=True, capture_output=True)
     yield

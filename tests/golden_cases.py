@@ -2,11 +2,13 @@
 outputs are recorded. TEST INFRASTRUCTURE shared by the generator (tests/golden/make_kernel_goldens.py, oracle engine),
 the CPU test (oracle reproduces the fixture) and the -m gpu test (HIP kernels reproduce the fixture).
 
-Status of these vectors: they are outputs of oracle/hns_oracle.c, NOT of the reference binary -- reference
-src/Cuda/Kernel.cu cannot be built in this image. They freeze today's agreed answer so that (a) any later
-change of the oracle or the kernels shows, and (b) an image that can build Kernel.cu can check the reference against
-them in one step: every input below is closed-form and uses only IEEE +, -, *, comparisons (no libm), so another
-machine regenerates bit-identical inputs.
+Status of these vectors (round 4): they are outputs of THE REFERENCE'S OWN KERNELS -- src/Cuda/Kernel.cu compiled where it
+lies for the host (oracle/Makefile -> oracle/_ref/libhns_refk.so, strict IEEE; oracle/ref_kernels.cpp is the launch) and
+launched in the reference's order (tests/oracle_lib.py: RefKernelGrid), written by tests/golden/make_kernel_goldens.py
+only after oracle/hns_oracle.c agreed bit for bit. tests/test_ref_kernels.py re-derives them from the reference where it
+can be built. (Rounds 1-3: the same bits, then produced by the oracle alone.) Not covered: nvcc's own FMA contraction
+(DESIGN.md 2). Every input below is closed-form and uses only IEEE +, -, *, comparisons (no libm), so another machine
+regenerates bit-identical inputs.
 """
 from __future__ import annotations
 

@@ -302,6 +302,27 @@ def test_bench_py_as_two_processes_sharing_the_gpu(extra, tmp_path):
     assert j["config"]["halo"]["sweeps_per_exchange"] == 1 and j["config"]["halo"]["bytes_sent"]["p"] > 0
 
 
+def test_bench_py_launches_its_own_ranks():
+    """`python bench.py --gpus 2 --share-one-gpu`, no launcher around it (the form the driver uses for --gpus 1): bench.py
+    starts its two ranks itself as a child process and exactly one JSON line comes out."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-one-gpu", "--steps", "3", "--warmup", "1", "--iterations", "10", "--config", "64"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["value"] > 0
+    assert "bit-identical to the single-GPU run of the whole domain" in j["config"]["verified"], j["config"]["verified"]
+    assert "bit-equal to their owners' values" in j["config"]["ghosts"], j["config"]["ghosts"]
+
+
 def test_unconnected_ranks_refuse_to_step():
     import hnanosolver_amd as H
 

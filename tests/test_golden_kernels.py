@@ -1,4 +1,5 @@
-"""The frozen golden set G1-G4 (tests/golden_cases.py): the oracle must reproduce the committed vectors
+"""The frozen golden set G1-G4 (tests/golden_cases.py) -- outputs of the reference's own Kernel.cu built
+for the host (tests/test_ref_kernels.py re-derives them): the oracle must reproduce the committed vectors
 (CPU suite: any drift of oracle/hns_oracle.c shows), and the HIP kernels and drop-in operators must reproduce them
 bit for bit on the GPU (-m gpu), from the fixture alone -- no oracle involved on that side."""
 import json

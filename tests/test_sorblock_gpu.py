@@ -120,3 +120,31 @@ def test_every_occupancy_pattern_of_a_block():
         for lb, k in SHAPES:
             got = solve(grid, div, p0, 4, rbgs="block", sor_block_lb=lb, sor_block_k=k)
             assert torch.equal(want, got), (pattern, lb, k, float((want - got).abs().max()))
+
+
+@pytest.mark.parametrize("leaves", [8, 512, 4096])
+def test_result_buffer_is_the_one_result_in_b_names(leaves):
+    """include/hns.h, hns_dev_rbgs_iterate: which of p_a / p_b holds the result depends on the form the library picks, not on
+    the parity of `iterations` -- the documented contract is *result_in_b, for every iteration count, under
+    rbgs=auto. Checked through the raw C ABI: the named buffer holds the two-launch result, and it follows the plan's
+    launch count."""
+    import ctypes as C
+
+    lib = H.load_library()
+    R = {8: 16, 512: 64, 4096: 128}[leaves]
+    origins = fields.dense_leaves(R)
+    grid = api.create_grid_from_leaves(origins, 1.0 / R)
+    n = len(origins) * 512
+    g = torch.Generator(device="cpu").manual_seed(leaves)
+    div = torch.randn(n, generator=g).cuda()
+    p0 = torch.randn(n, generator=g).cuda()
+    for iters in (1, 2, 3, 4, 6):
+        want = solve(grid, div, p0, iters, rbgs="color")
+        p_a, p_b = p0.clone(), torch.full_like(p0, 7.0)
+        in_b = C.c_int(-1)
+        rc = lib.hns_dev_rbgs_iterate(grid.ptr, div.data_ptr(), p_a.data_ptr(), p_b.data_ptr(), C.c_float(0.013), C.c_float(1.93), iters, C.byref(in_b), D.current_stream())
+        assert rc == 0 and in_b.value in (0, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(p_b if in_b.value else p_a, want), f"iterations = {iters}: the buffer named by result_in_b does not hold the result"
+        _, launches, _ = D.rbgs_plan(grid, iters)
+        assert in_b.value == (launches & 1), f"iterations = {iters}: result_in_b = {in_b.value} but the plan says {launches} launches"
