@@ -669,7 +669,14 @@ PhaseMirror phase_args(hns_dist* d, int t, const std::vector<std::pair<const flo
 	return m;
 }
 
-bool mirror_wanted(const hns_dist* d) { return d->k == 1 && d->world > 1 && options().dist_mirror.load() != 0; }
+// Round 4: sweeps_per_exchange = 2 mirrors as well -- its sweeps are the temporally blocked form, two iterations per chained launch
+// (hns_sorblock.hip: k_rbgs_block<2, 2, ., true, PhaseMirror>), whose mirror region is the plan's reach-4 region of p. All ranks must
+// take the same path (they count launches alike), so the decision uses only what every rank knows: the smallest owned range must be
+// swept in 16^3 blocks (more than 600 leaves, hns_rbgs_block_shape) and the option must say so.
+bool blocked_mirror(const hns_dist* d) {
+	return d->k == 2 && options().dist_block.load() != 0 && options().sor_block_lb.load() != 1 && d->world > 0 && d->n_global / d->world > 600 && d->n_global <= 2000000;
+}
+bool mirror_wanted(const hns_dist* d) { return (d->k == 1 || blocked_mirror(d)) && d->world > 1 && options().dist_mirror.load() != 0; }
 
 }  // namespace
 
@@ -741,7 +748,7 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 		if (!*gs[i]) return bail(rc);
 		// the owned range deals the boundary leaves out to all eight XCDs first (the mirroring pressure loop sweeps this range: its
 		// boundary waves poll, store twice and signal, and as the head of XCD 0's chunk they made that XCD the last to finish)
-		if (i == 2 && sweeps_per_exchange == 1 && options().dist_spread.load() != 0) (*gs[i])->sched_prefix = (uint64_t)d->nB;
+		if (i == 2 && (sweeps_per_exchange == 1 || blocked_mirror(d)) && options().dist_spread.load() != 0) (*gs[i])->sched_prefix = (uint64_t)d->nB;
 		if ((rc = hns_grid_set_active_range(*gs[i], first[i], count[i])) != HNS_OK) return bail(rc);
 		if ((rc = hns_grid_set_outside_element(*gs[i], outside)) != HNS_OK) return bail(rc);
 	}
@@ -1418,6 +1425,18 @@ struct Step {
 	}
 	const float* sdf() const { return coll ? d->phi[(size_t)fi[4]] : nullptr; }
 
+	// Do both launch ranges of the split sweep take two iterations in ONE launch each (result in dst for both)? Asked of the library's own
+	// plan, so that whatever hns_rbgs_iterate does with `2` is what this loop assumes.
+	bool split_blocked() const {
+		if (d->k < 2 || options().dist_block.load() == 0) return false;
+		for (hns_grid* g : {d->gB, d->gI}) {
+			if (!g->n_active) continue;
+			int launches = 0, per = 0;
+			if (hns_grid_rbgs_plan(g, 2, nullptr, 0, &launches, &per) != HNS_OK || launches != 1) return false;
+		}
+		return true;
+	}
+
 	int sweep(hns_grid* g, bool from_zero, hipStream_t s) const {
 		return hns_rbgs_iterate(g, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), 1, nullptr, s, from_zero);
 	}
@@ -1460,17 +1479,27 @@ struct Step {
 			if (d->timing && d->tev_used + 2 <= d->tev.size()) HNS_HIP(hipEventRecord(d->tev[d->tev_used], st));
 		}
 		const int n = std::min(d->k, iterations - it);
-		if (n > 1) {  // the sweeps over owned + ghost leaves as ONE solve of n - 1 iterations: the library picks the form (two iterations per launch where that pays)
+		// Round 4: the sweeps of the block that the exchange follows are TWO iterations in one temporally blocked launch per range
+		// (hns_sorblock.hip over a launch range: the ghost leaves are tile sources, 2K = 4 voxels deep, and are not swept; the X_P region
+		// of a plan with k >= 2 reaches 2k >= 4 voxels, its div region 2k - 1 >= 3), where the library's plan for the ranges says so.
+		// With k = 2 that is the whole pressure loop: no sweep ever touches a ghost leaf.
+		const int tail = (n >= 2 && split_blocked()) ? 2 : 1;
+		if (n > tail) {  // the sweeps over owned + ghost leaves as ONE solve of n - tail iterations: the library picks the form (two iterations per launch where that pays)
 			int in_b = 0;
-			HNS_TRY(hns_rbgs_iterate(d->gA, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), n - 1, &in_b, st, it == 0));
+			HNS_TRY(hns_rbgs_iterate(d->gA, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), n - tail, &in_b, st, it == 0));
 			if (in_b) std::swap(src, dst);
-			it += n - 1;
+			it += n - tail;
 		}
-		const bool last = it + 1 == iterations, zero = it == 0;
-		HNS_TRY(post(d, last ? X_D1 : X_P, Fields{{dst, 1}}, st, [=](hipStream_t s) { return sweep(D->gB, zero, s); }));
-		HNS_TRY(sweep(d->gI, zero, st));
+		const bool last = it + tail == iterations, zero = it == 0;
+		float *s0 = src, *d0 = dst;
+		const float vs = d->voxel_size;
+		auto part = [=](hns_grid* g, hipStream_t s) {
+			return g->n_active ? hns_rbgs_iterate(g, D->div, s0, d0, vs, omega_compute(vs), tail, nullptr, s, zero) : (int)HNS_OK;
+		};
+		HNS_TRY(post(d, last ? X_D1 : X_P, Fields{{dst, 1}}, st, [=](hipStream_t s) { return part(D->gB, s); }));
+		HNS_TRY(part(d->gI, st));
 		std::swap(src, dst);
-		++it;
+		it += tail;
 		if (last) d->p_result = src;
 		return HNS_OK;
 	}
@@ -1625,6 +1654,15 @@ struct Step {
 			if (b == 0) {
 				it = 0, src = d->p_a, dst = d->p_b;  // never warm-started (reference HNanoSolver.cu:113): the first sweep reads no p
 				if (d->timing && d->tev_used + 2 <= d->tev.size()) HNS_HIP(hipEventRecord(d->tev[d->tev_used], st));
+			}
+			if (d->k == 2 && iterations - it >= 2) {  // two iterations in ONE chained launch of the temporally blocked form (every rank alike: blocked_mirror)
+				const PhaseMirror m = phase_args(d, X_P, Outs{{dst, 1}});
+				const bool zero = it == 0;
+				HNS_TRY(chained(m, [&] { return hns_rbgs_block_mirror_launch(d->gO, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), zero, &m, st); }));
+				std::swap(src, dst);
+				it += 2;
+				if (it == iterations) d->p_result = src;
+				return launch_status("hns_dist: blocked mirror sweep");
 			}
 			{  // the sweep delivers its boundary rows itself (k_rbgs_pair_mirror): no exchange, no second stream
 				const PhaseMirror m = phase_args(d, X_P, Outs{{dst, 1}});

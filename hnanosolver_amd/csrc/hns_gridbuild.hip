@@ -406,6 +406,7 @@ void hns_grid_free_device(hns_grid* g) {
 	if (!g) return;
 	(void)hns_grid_release_cache(g);
 	if (g->d_sb_tab) hns_arena_put(g->d_sb_tab, g->sb_bytes, g->device);
+	hns_grid_retire_blocks(g);
 	g->d_sb_tab = nullptr;
 	g->sb_bytes = 0;
 	g->n_sb = 0;

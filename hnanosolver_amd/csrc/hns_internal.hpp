@@ -40,6 +40,7 @@ struct Options {
 	std::atomic<int> dist_wire_us{0};          // "dist_wire_us": loopback transport only, emulated time on the wire per exchange
 	std::atomic<int> dist_mirror{1};           // "dist_mirror": multi-GPU pressure loop with sweeps_per_exchange = 1 over the ipc / local transport delivers its halo inside the sweep kernel
 	std::atomic<int> dist_chain{1};            // "dist_chain": with dist_mirror, EVERY kernel of the substep of such a rank is one launch that delivers its own halo (read when the ranks connect)
+	std::atomic<int> dist_block{1};            // "dist_block": a rank with sweeps_per_exchange >= 2 sweeps its launch ranges two iterations per launch (hns_sorblock.hip over a range)
 	std::atomic<int> dist_spread{1};           // "dist_spread": the owned launch range of a sweeps_per_exchange = 1 rank deals its boundary leaves out to all XCDs (read at hns_dist_create)
 	std::atomic<int> sor_lds_pad{0};           // "sor_lds_pad": extra dynamic LDS bytes per wave of the pair kernel (an occupancy experiment: fewer waves in flight per XCD)
 	std::atomic<int> sor_block_lb{0};          // "sor_block_lb": temporally blocked SOR (hns_sorblock.hip), block edge in leaves: 0 = by size, 1, 2
@@ -151,6 +152,8 @@ struct hns_grid {
 	uint64_t n_sb = 0;
 	bool sb_built = false;
 	int sb_seg = 0;
+	uint64_t sb_first = 0, sb_count = 0;                  // the launch range the records were built for
+	std::vector<std::pair<void*, size_t>> sb_retired;     // superseded tables: back to the pool only when the grid goes
 	std::mutex build_mutex;              // guards the tables built on first use (tile groups, block records): cooks from several host threads may share a grid
 	std::mutex host_mutex;               // guards the lazy host copy of the device-built tables and sim_cache
 	std::vector<hns_sim*> sim_cache;     // device-resident state kept between operator calls (hns_api.hip: make_sim)
@@ -166,6 +169,8 @@ extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_iterate(hns_grid* 
 namespace hns { struct PhaseMirror; }
 extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_mirror_sweep(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero,
                                                                            const hns::PhaseMirror* m, void* stream, bool backwards);
+extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_block_mirror_launch(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero,
+                                                                                   const hns::PhaseMirror* m, void* stream);  // hns_sorblock.hip: two iterations per chained launch
 extern "C" __attribute__((visibility("hidden"))) int hns_chain_divergence(hns_grid* g, const float* vel3, float* div, float inv_dx, const hns::PhaseMirror* m, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int hns_chain_subtract_pressure_gradient(hns_grid* g, const float* vel3, const float* p, float* out3, float inv_dx,
                                                                                           const hns::PhaseMirror* m, void* stream);
@@ -188,7 +193,8 @@ void hns_grid_free_device(hns_grid* g);
 int hns_grid_upload_schedule(hns_grid* g);  // launch-order tables for the current n_active
 int hns_grid_build_tiles(hns_grid* g);      // tile groups of the blocked SOR kernel for the current wave records
 // implemented in hns_sorblock.hip: the temporally blocked SOR form (k iterations per launch)
-int hns_grid_build_blocks(hns_grid* g);     // records of the 16^3-voxel blocks
+int hns_grid_build_blocks(hns_grid* g);     // records of the 16^3-voxel blocks of the grid's launch range
+void hns_grid_retire_blocks(hns_grid* g);   // superseded records back to the pool (grid destruction / rebuild only)
 int hns_rbgs_block_shape(hns_grid* g, int* k_max);  // block edge in leaves this grid is swept with (0: not by this form) and the iterations per launch
 bool hns_rbgs_block_lean(hns_grid* g, int lb, int k);  // is that launch the lean form of the kernel (row state in LDS, three workgroups per CU)?
 int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const float* div, const float* src, float* dst, float dx2, float omega, void* stream);

@@ -30,6 +30,7 @@
 // can reach the block in 2K sweeps is fetched and computed. DESIGN.md section 4 and profiles/r03_sorblock_notes.txt 10-12
 // have the measurements behind each of these.
 #include "hns_device.hpp"
+#include "hns_flags.hpp"
 
 namespace hns {
 
@@ -376,9 +377,29 @@ struct SbSweepsLean {
 	}
 };
 
-template <int LB, int K, bool ZERO, bool PAR>
+// 16 bytes (z = 4 * half .. 4 * half + 3 of z-row `row`) of boundary leaf `leaf` into the ghost copies the peers keep of it: the chained
+// blocked sweep of a multi-GPU rank (hns_flags.hpp). `mine` = this lane's piece belongs to `leaf`; the table walk is wave-uniform.
+__device__ __forceinline__ void chain_store_piece(const PhaseMirror& m, int leaf, bool mine, int row, int half, sb4f v) {
+	const int e1 = m.first[leaf + 1];
+	for (int e = m.first[leaf]; e < e1; ++e) {
+		const int2 t = m.entry[e];
+		if (!mine) continue;
+		const unsigned bits = m.mask ? (m.mask[(size_t)e * 64 + row] >> (4 * half)) & 0xFu : 0xFu;
+		float* r = chain_out(m, t.x, 0) + (size_t)t.y * 512 + row * 8 + 4 * half;
+		if (bits == 0xFu) {
+			store_through(r, chain_v4f{v.x, v.y, v.z, v.w});
+		} else if (bits) {
+			const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+			for (int z = 0; z < 4; ++z)
+				if (bits >> z & 1) store_through(r + z, f[z]);
+		}
+	}
+}
+
+template <int LB, int K, bool ZERO, bool PAR, class M = NoMirror>
 __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, const int t, const int* __restrict__ recs, const int* __restrict__ any_absent, const float* __restrict__ div,
-                                             const float* __restrict__ p_in, float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega) {
+                                             const float* __restrict__ p_in, float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega, const M& m = M{}) {
 	using G = SbGeo<LB, K>;
 	constexpr int H = G::H, T = G::T, C = G::C, HALF = G::HALF, NQ = G::NQ, NCH = G::NCH, HS4 = G::HS4;
 	static_assert(NCH == 2 * NQ, "two 16-byte pieces of a row in memory make one piece of each colour array");
@@ -505,8 +526,10 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 	}
 	// (the barrier behind the staging; whether a leaf under the tile is absent -- voxels need masking then -- is in the block table)
 	bool all_present;
+	int meta = 0xFF00;  // (bits 8..15: the block's leaves this launch stores -- all of them on a whole grid; see k_sb_table)
 	if (any_absent) {
-		all_present = __builtin_amdgcn_readfirstlane(any_absent[blockIdx.x]) == 0;
+		meta = __builtin_amdgcn_readfirstlane(any_absent[blockIdx.x]);
+		all_present = (meta & 1) == 0;
 		__syncthreads();
 	} else {
 		bool mine = true;
@@ -534,10 +557,23 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 			const int par = (x + y) & 1;
 			const int e = par * PSTR + SbLdsDense<LB, K>::row(x, y) * HS4 * 2 + j;
 			const float2 rr = A[e + ROFF], bb = A[e];
-			const int id = s_rec[((1 + (xx >> 3)) * C + 1 + (yy >> 3)) * C + 1 + czb];
+			const int cell = (((xx >> 3) << 1) | (yy >> 3)) << 1 | czb;
+			const int id = (meta >> (8 + cell)) & 1 ? s_rec[((1 + (xx >> 3)) * C + 1 + (yy >> 3)) * C + 1 + czb] : -1;  // (a leaf outside the launch range is a source only)
 			sb4f v;
 			v.x = par ? bb.x : rr.x, v.y = par ? rr.x : bb.x, v.z = par ? bb.y : rr.y, v.w = par ? rr.y : bb.y;
 			sb_store4(v, ro, (int)((unsigned)id * 2048u + (unsigned)((((xx & 7) << 3) | (yy & 7)) * 32 + jz * 16)), 0, 0);
+			if constexpr (!std::is_same<M, NoMirror>::value) {
+				// a chained multi-GPU rank: what the peers read of this block's boundary leaves (the plan's reach-2K region of p) goes into
+				// their ghost copies as well, write-through. The walk over the block's eight leaves and their table entries is wave-uniform.
+				if (meta & 2) {
+#pragma unroll 1
+					for (int c = 0; c < 8; ++c) {
+						const int lc = __builtin_amdgcn_readfirstlane(s_rec[((1 + (c >> 2)) * C + 1 + ((c >> 1) & 1)) * C + 1 + (c & 1)]);
+						if (!((meta >> (8 + c)) & 1) || lc < 0 || lc >= m.n_boundary) continue;
+						chain_store_piece(m, lc, c == cell, ((xx & 7) << 3) | (yy & 7), jz, v);
+					}
+				}
+			}
 		}
 	}
 }
@@ -546,13 +582,23 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 // under the tile, cell (cx, cy, cz) at (cx*4 + cy)*4 + cz, -1 = absent. ZERO: p_in is known to be 0 (first launch of a solve,
 // HNanoSolver.cu:113) and is not read. The first half of the workgroup's waves takes the rows with even x+y, the second half
 // those with odd x+y; both halves meet at the same number of barriers.
-template <int LB, int K, bool ZERO, bool LEAN = false>
+// M = NoMirror, or PhaseMirror for the chained sweep of a multi-GPU rank (hns_flags.hpp; lean form only): the workgroups of blocks that
+// hold a boundary leaf (bit 1 of the block's meta word; first in the launch order) wait for the peers' previous launch before they read a
+// ghost voxel, and store what the peers read of their boundary leaves into the peers' ghost copies too.
+template <int LB, int K, bool ZERO, bool LEAN = false, class M = NoMirror>
 __global__ __attribute__((amdgpu_waves_per_eu(LEAN ? 6 : 1, 8))) __launch_bounds__((SbGeo<LB, K>::NT)) void k_rbgs_block(const int* __restrict__ recs, const int* __restrict__ any_absent, const float* __restrict__ div, const float* __restrict__ p_in,
-                                                                float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega, const int stagger) {
+                                                                float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega, const int stagger, const M m = M{}) {
 	using G = SbGeo<LB, K>;
 	__shared__ typename std::conditional<LEAN, SbLdsDense<LB, K>, SbLds<LB, K>>::type L;
 	__shared__ int s_rec[LEAN ? 64 : 1];
 	const int t = threadIdx.x;
+	int chain_leaf = 0x7fffffff;  // (chain_begin / chain_end take a leaf number: below n_boundary = "this workgroup waits and mirrors")
+	if constexpr (!std::is_same<M, NoMirror>::value) {
+		static_assert(LEAN, "the chained form is the lean form");
+		if (__builtin_amdgcn_readfirstlane(any_absent[blockIdx.x]) & 2) chain_leaf = 0;
+		chain_begin(m, chain_leaf);
+		__syncthreads();
+	}
 	constexpr unsigned PER_CU = LEAN ? 3u : 2u;  // workgroups of this kernel a CU holds
 	if (stagger > 0 && blockIdx.x < 256 * PER_CU) {  // (the first round: PER_CU workgroups on each of 256 CUs)
 		__shared__ unsigned s_slot;
@@ -569,9 +615,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(LEAN ? 6 : 1, 8))) __launch_bounds
 	if constexpr (LEAN) {
 		static_assert(G::CAN_LEAN, "the lean form is written for 24-voxel tiles");
 		if (__builtin_amdgcn_readfirstlane(t >= G::SEC))
-			sb_body_lean<LB, K, ZERO, true>(L, s_rec, t - G::SEC, recs, any_absent, div, p_in, p_out, field_bytes, dx2, omega);
+			sb_body_lean<LB, K, ZERO, true, M>(L, s_rec, t - G::SEC, recs, any_absent, div, p_in, p_out, field_bytes, dx2, omega, m);
 		else
-			sb_body_lean<LB, K, ZERO, false>(L, s_rec, t, recs, any_absent, div, p_in, p_out, field_bytes, dx2, omega);
+			sb_body_lean<LB, K, ZERO, false, M>(L, s_rec, t, recs, any_absent, div, p_in, p_out, field_bytes, dx2, omega, m);
+		if constexpr (!std::is_same<M, NoMirror>::value) chain_end(m, chain_leaf);
 	} else {
 		if (__builtin_amdgcn_readfirstlane(t >= G::SEC))
 			sb_body<LB, K, ZERO, true>(L, t - G::SEC, recs, div, p_in, p_out, field_bytes, dx2, omega);
@@ -584,21 +631,28 @@ __global__ __attribute__((amdgpu_waves_per_eu(LEAN ? 6 : 1, 8))) __launch_bounds
 // block tables for LB = 2: aligned 16^3-voxel blocks (2 x 2 x 2 leaves, any of them may be absent)
 // ---------------------------------------------------------------------------------------------------------------
 
-// flag[l] = 1 if leaf l is the first existing leaf (corner order x, y, z) of its block
-__global__ __launch_bounds__(256) void k_sb_leader(GridDev g, int* __restrict__ flag) {
+// flag[l] = 1 if leaf l is the lowest-numbered leaf OF THE LAUNCH RANGE [first, first + count) in its block. A launch
+// range is what a multi-GPU rank sweeps (its boundary leaves, its interior leaves, ...: hns_grid_set_active_range); the leaves of the
+// grid outside it -- ghost leaves among them -- are sources of the tiles and are never stored.
+__global__ __launch_bounds__(256) void k_sb_leader(GridDev g, int first, int count, int* __restrict__ flag) {
 	const int l = blockIdx.x * 256 + threadIdx.x;
 	if (l >= g.n_leaves) return;
-	const int4 o = g.origins[l];
-	const int bx = o.x & ~15, by = o.y & ~15, bz = o.z & ~15;
-	const int me = (((o.x >> 3) & 1) << 2) | (((o.y >> 3) & 1) << 1) | ((o.z >> 3) & 1);
-	int lead = 1;
-	for (int c = 0; c < me; ++c)
-		if (d_find_leaf(g, bx + 8 * (c >> 2), by + 8 * ((c >> 1) & 1), bz + 8 * (c & 1)) >= 0) lead = 0;
+	int lead = (l >= first && l < first + count) ? 1 : 0;
+	if (lead) {  // the leaf of the range with the LOWEST NUMBER in its block leads it: the blocks then come out ordered by that number, and a
+		// multi-GPU rank's boundary leaves -- the first of its leaf order -- put the blocks that hold one in front of all others
+		const int4 o = g.origins[l];
+		const int bx = o.x & ~15, by = o.y & ~15, bz = o.z & ~15;
+		for (int c = 0; c < 8; ++c) {
+			const int q = d_find_leaf(g, bx + 8 * (c >> 2), by + 8 * ((c >> 1) & 1), bz + 8 * (c & 1));
+			if (q >= first && q < l) lead = 0;
+		}
+	}
 	flag[l] = lead;
 }
 
 // exclusive scan of flag[0..n) by ONE workgroup; leaders[pos] = l for flagged l; *total = number of flags
-__global__ __launch_bounds__(1024) void k_sb_compact(const int* __restrict__ flag, int n, int* __restrict__ leaders, int* __restrict__ total) {
+// total[1] = number of flagged l below `n_head` (the blocks led by a boundary leaf of a multi-GPU rank)
+__global__ __launch_bounds__(1024) void k_sb_compact(const int* __restrict__ flag, int n, int* __restrict__ leaders, int* __restrict__ total, int n_head) {
 	__shared__ int s_part[1024];
 	const int per = (n + 1023) / 1024;
 	const int lo = threadIdx.x * per, hi = min(n, lo + per);
@@ -613,22 +667,34 @@ __global__ __launch_bounds__(1024) void k_sb_compact(const int* __restrict__ fla
 		__syncthreads();
 	}
 	int run = s_part[threadIdx.x] - sum;
-	for (int i = lo; i < hi; ++i)
+	for (int i = lo; i < hi; ++i) {
+		if (i == n_head) total[1] = run;
 		if (flag[i]) leaders[run++] = i;
-	if (threadIdx.x == 1023) *total = s_part[1023];
+	}
+	if (threadIdx.x == 1023) {
+		total[0] = s_part[1023];
+		if (n_head >= n) total[1] = s_part[1023];
+	}
 }
 
 // record of launch position b: the 64 leaves under the tile of block order[b]
-__global__ __launch_bounds__(256) void k_sb_table(GridDev g, const int* __restrict__ leaders, int n_blocks, int seg, int* __restrict__ tab) {
+// Behind the records one word per block (zeroed by the host): bit 0 = "a leaf under this block's tile is absent" (its voxels must not be
+// updated), bit 8 + c = leaf c of the block (c = (cx*2 + cy)*2 + cz) lies in the launch range [first, first + count) and is stored.
+// Bit 1 = the block holds a leaf of the range below n_boundary: a boundary leaf of a multi-GPU rank (the chained sweep's workgroup waits / mirrors).
+__global__ __launch_bounds__(256) void k_sb_table(GridDev g, const int* __restrict__ leaders, int n_blocks, int seg, int pre, int first, int count, int n_boundary, int* __restrict__ tab) {
 	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= (int64_t)n_blocks * 64) return;
 	const int b = (int)(i >> 6), c = (int)(i & 63);
-	const int4 o = g.origins[leaders[sched_leaf(b, n_blocks, seg)]];
-	const int64_t x = (int64_t)(o.x & ~15) + 8 * ((c >> 4) - 1), y = (int64_t)(o.y & ~15) + 8 * (((c >> 2) & 3) - 1), z = (int64_t)(o.z & ~15) + 8 * ((c & 3) - 1);
+	const int4 o = g.origins[leaders[sched_leaf(b, n_blocks, seg, pre)]];
+	const int cx = c >> 4, cy = (c >> 2) & 3, cz = c & 3;
+	const int64_t x = (int64_t)(o.x & ~15) + 8 * (cx - 1), y = (int64_t)(o.y & ~15) + 8 * (cy - 1), z = (int64_t)(o.z & ~15) + 8 * (cz - 1);
 	int leaf = -1;
 	if (x >= INT32_MIN && x <= INT32_MAX && y >= INT32_MIN && y <= INT32_MAX && z >= INT32_MIN && z <= INT32_MAX) leaf = d_find_leaf(g, (int)x, (int)y, (int)z);
 	tab[i] = leaf;
-	if (leaf < 0) tab[(int64_t)n_blocks * 64 + b] = 1;  // behind the records: "a leaf under this block's tile is absent" (zeroed by the host)
+	int* meta = tab + (int64_t)n_blocks * 64 + b;
+	if (leaf < 0) atomicOr(meta, 1);
+	const bool inner = ((cx - 1) | (cy - 1) | (cz - 1)) >= 0 && cx <= 2 && cy <= 2 && cz <= 2;
+	if (inner && leaf >= first && leaf < first + count) atomicOr(meta, (1 << (8 + ((((cx - 1) << 1) | (cy - 1)) << 1 | (cz - 1)))) | (leaf < n_boundary ? 2 : 0));
 }
 
 }  // namespace hns
@@ -637,40 +703,70 @@ using namespace hns;
 
 // Block records of the 16^3 form for the whole grid, built on first use (most small grids never ask). The table comes
 // out of the arena pool and goes back with the grid.
+//
+// Round 4: (1) the records cover the grid's LAUNCH RANGE (hns_grid_set_active_range): blocks that hold a leaf of the range, every leaf
+// of the grid under their tiles as a source, stores to the leaves of the range only -- what a multi-GPU rank's boundary / interior /
+// owned ranges need (the ghost layer, 8 voxels deep, holds everything 2K = 4 sweeps can carry into an owned voxel). (2) The build runs
+// on a stream of its own and waits for that stream only: it used to launch on the NULL stream and call hipDeviceSynchronize() from
+// inside an asynchronous per-stream entry point, stalling every stream of the device on first use (concurrent cooks). (3) A table that
+// was handed to launches is never returned to the pool while the grid lives (another host thread's launch may still read it): tables
+// superseded by an option or range change are parked until the grid goes (hns_grid_retire_blocks).
 int hns_grid_build_blocks(hns_grid* g) {
 	std::lock_guard<std::mutex> lock(g->build_mutex);
 	const int seg = options().sor_block_seg.load();
-	if (g->sb_built && g->sb_seg == seg) return HNS_OK;
-	if (g->d_sb_tab) hns_arena_put(g->d_sb_tab, g->sb_bytes, g->device);
+	if (g->sb_built && g->sb_seg == seg && g->sb_first == g->first_active && g->sb_count == g->n_active) return HNS_OK;
+	if (g->d_sb_tab) g->sb_retired.emplace_back(g->d_sb_tab, g->sb_bytes);
 	g->d_sb_tab = nullptr;
 	g->sb_bytes = 0;
 	g->n_sb = 0;
 	g->sb_built = true;
 	g->sb_seg = seg;
+	g->sb_first = g->first_active, g->sb_count = g->n_active;
 	const int n = (int)g->topo.n_leaves;
-	if (n == 0 || !g->d_tile_mem) return HNS_OK;
-	int* flag = (int*)g->d_tile_mem;  // scratch shared with hns_grid_build_tiles (same lock): flag[n] | leaders[n] | total
+	if (n == 0 || g->n_active == 0 || !g->d_tile_mem) return HNS_OK;
+	int* flag = (int*)g->d_tile_mem;  // scratch shared with hns_grid_build_tiles (same lock): flag[n] | leaders[n] | total[2]
 	int* leaders = flag + n;
 	int* total = leaders + n;
 	GridDev gd = g->dev();
-	k_sb_leader<<<(n + 255) / 256, 256, 0, 0>>>(gd, flag);
-	k_sb_compact<<<1, 1024, 0, 0>>>(flag, n, leaders, total);
-	int nb = 0;
-	HNS_HIP(hipMemcpy(&nb, total, sizeof(int), hipMemcpyDeviceToHost));
+	const int first = (int)g->first_active, count = (int)g->n_active;
+	// (sched_prefix: the leading leaves of the range that are a multi-GPU rank's boundary leaves -- hns_dist.hip sets it on the range its
+	// chained sweeps run over; 0 everywhere else)
+	const int n_boundary = (int)std::min<uint64_t>(g->sched_prefix, g->n_active) ? first + (int)std::min<uint64_t>(g->sched_prefix, g->n_active) : 0;
+	hipStream_t st = nullptr;
+	HNS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+	struct Drop {
+		hipStream_t s;
+		~Drop() { (void)hipStreamDestroy(s); }
+	} drop{st};
+	hipLaunchKernelGGL(k_sb_leader, dim3((n + 255) / 256), dim3(256), 0, st, gd, first, count, flag);
+	hipLaunchKernelGGL(k_sb_compact, dim3(1), dim3(1024), 0, st, (const int*)flag, n, leaders, total, n_boundary);
+	int tot[2] = {0, 0};
+	HNS_HIP(hipMemcpyAsync(tot, total, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+	HNS_HIP(hipStreamSynchronize(st));
+	const int nb = tot[0];
 	if (nb <= 0) return fail(HNS_ERR_RUNTIME, "hns_grid_build_blocks: no block leader found");
 	if (int rc = hns_arena_get(sizeof(int) * 65 * (size_t)nb, g->device, &g->d_sb_tab, &g->sb_bytes)) return rc;
-	HNS_HIP(hipMemsetAsync((int*)g->d_sb_tab + (size_t)nb * 64, 0, sizeof(int) * (size_t)nb, 0));
-	k_sb_table<<<(unsigned)(((int64_t)nb * 64 + 255) / 256), 256, 0, 0>>>(gd, leaders, nb, seg, (int*)g->d_sb_tab);
-	HNS_HIP(hipDeviceSynchronize());
+	HNS_HIP(hipMemsetAsync((int*)g->d_sb_tab + (size_t)nb * 64, 0, sizeof(int) * (size_t)nb, st));
+	// the blocks led by a boundary leaf are dealt out to all XCDs first (as hns_grid_upload_schedule does with the boundary leaves themselves)
+	const int pre = n_boundary ? (std::min(tot[1], nb) & ~7) : 0;
+	hipLaunchKernelGGL(k_sb_table, dim3((unsigned)(((int64_t)nb * 64 + 255) / 256)), dim3(256), 0, st, gd, (const int*)leaders, nb, seg, pre, first, count, n_boundary, (int*)g->d_sb_tab);
+	HNS_HIP(hipStreamSynchronize(st));
 	g->n_sb = (uint64_t)nb;
 	return HNS_OK;
+}
+
+void hns_grid_retire_blocks(hns_grid* g) {  // (the grid is being destroyed or rebuilt: the device is idle for it)
+	for (auto& t : g->sb_retired) hns_arena_put(t.first, t.second, g->device);
+	g->sb_retired.clear();
 }
 
 // Can this grid be swept by the blocked form, and with which block edge (in leaves)? 0 = no.
 int hns_rbgs_block_shape(hns_grid* g, int* k_max) {
 	*k_max = 0;
-	// whole grids only (a multi-GPU rank sweeps launch ranges), fields addressable with 32-bit byte offsets
-	if (g->first_active != 0 || g->n_active != (uint64_t)g->topo.n_leaves || g->n_active == 0 || g->topo.n_leaves > 2000000) return 0;
+	// fields addressable with 32-bit byte offsets. A launch range (a multi-GPU rank's boundary / interior / owned leaves) is swept like a
+	// whole grid: blocks that hold a leaf of the range, the other leaves of the grid as sources only (hns_grid_build_blocks). The CALLER
+	// vouches that p within 2K voxels of the range, and div within 2K - 1, are current in the leaves outside it (hns_dist.hip).
+	if (g->n_active == 0 || g->topo.n_leaves > 2000000) return 0;
 	int lb = options().sor_block_lb.load(), k = options().sor_block_k.load();
 	// by size (profiles/r03_sor_forms.txt): one-leaf blocks while the grid cannot fill the chip with 16^3 blocks, four iterations per
 	// launch while even those leave most of it idle
@@ -689,8 +785,8 @@ int hns_rbgs_block_shape(hns_grid* g, int* k_max) {
 // in 64 blocks 3.70 -> 3.37, 128^3 6.57 -> 5.62, 4k-leaf plume 8.34 -> 6.64, 256^3 35.3 -> 27.2, 512^3 304 -> 273, 66k-leaf plume
 // 84.8 -> 74.2 (profiles/r03_sorblock_notes.txt 11-12). Option "sor_block_lean" = auto | 0 | 1.
 bool hns_rbgs_block_lean(hns_grid* g, int lb, int k) {
-	(void)g;
 	if (lb != 2 || k != 2) return false;
+	if (g->first_active != 0 || g->n_active != (uint64_t)g->topo.n_leaves) return true;  // (only the lean form knows which leaves of a block a launch range stores)
 	return options().sor_block_lean.load() != 1;  // (stored: 0 = auto, 1 = "0", 2 = "1")
 }
 
@@ -722,6 +818,22 @@ int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const fl
 	} else if (lb == 2 && k == 2) SB_LAUNCH(2, 2, g->d_sb_tab, g->n_sb);
 	else return fail(HNS_ERR_INVALID_ARGUMENT, "hns_rbgs_block_launch: unsupported block shape");
 #undef SB_LAUNCH
+	return HNS_OK;
+}
+
+// The chained sweep of a multi-GPU rank, two iterations per launch (hns_dist.hip; hns_flags.hpp): ONE launch over the rank's owned leaves
+// that waits for the peers where it reads their values and delivers its own boundary values into their ghost voxels. 16^3 blocks only.
+extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_block_mirror_launch(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero,
+                                                                                   const hns::PhaseMirror* m, void* stream) {
+	int k = 0;
+	if (hns_rbgs_block_shape(g, &k) != 2 || !hns_rbgs_block_lean(g, 2, 2)) return fail(HNS_ERR_RUNTIME, "hns_rbgs_block_mirror_launch: this launch range is not swept in 16^3 blocks");
+	const unsigned bytes = (unsigned)((size_t)g->topo.n_leaves * 2048u);
+	const int* tab = (const int*)g->d_sb_tab;
+	const float dx2 = dx * dx;  // Kernel.cu:608
+	if (src_is_zero)
+		hipLaunchKernelGGL((k_rbgs_block<2, 2, true, true, PhaseMirror>), dim3((unsigned)g->n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)g->n_sb * 64, div, src, dst, bytes, dx2, omega, 0, *m);
+	else
+		hipLaunchKernelGGL((k_rbgs_block<2, 2, false, true, PhaseMirror>), dim3((unsigned)g->n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)g->n_sb * 64, div, src, dst, bytes, dx2, omega, 0, *m);
 	return HNS_OK;
 }
 

@@ -159,6 +159,7 @@ const OptionDesc kOptions[] = {
     {"dist_wire_us", &Options::dist_wire_us, nullptr},
     {"dist_mirror", &Options::dist_mirror, kWordsMirror},
     {"dist_spread", &Options::dist_spread, kWordsBool},
+    {"dist_block", &Options::dist_block, kWordsBool},
     {"dist_chain", &Options::dist_chain, kWordsBool},
 };
 const Options kDefaults;

@@ -81,9 +81,17 @@ def test_local_ranks_match_single_grid(name, world, k):
     return _local_ranks_match_single_grid(name, world, k)
 
 
-def _local_ranks_match_single_grid(name, world, k):
-    origins, R = {"dense32": (fields.dense_leaves(32), 32), "plume": (fields.plume_leaves(8, 1.5, 0.35), 64), "scattered": (scattered_leaves(), 96)}[name]
-    names, iters, substeps = ["density", "temperature"], 7, 2
+def big_scattered_leaves():
+    rng = np.random.default_rng(9)
+    lat = np.stack(np.meshgrid(*[np.arange(-9, 9)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    o = (lat[rng.random(len(lat)) < 0.7] * 8).astype(np.int32)
+    return np.ascontiguousarray(o[fields.nanovdb_order(o)])
+
+
+def _local_ranks_match_single_grid(name, world, k, iters=7):
+    origins, R = {"dense32": (fields.dense_leaves(32), 32), "plume": (fields.plume_leaves(8, 1.5, 0.35), 64), "scattered": (scattered_leaves(), 96),
+                  "dense64": (fields.dense_leaves(64), 64), "plume16": (fields.plume_leaves(16, 1.5, 0.3), 128), "scattered_big": (big_scattered_leaves(), 144)}[name]
+    names, substeps = ["density", "temperature"], 2
     _, want = single_grid(origins, R, names, iters, substeps)
     ranks, b = run_local(origins, R, world, k, names, iters, substeps)
     check(ranks, b, want, names)
@@ -93,12 +101,36 @@ def _local_ranks_match_single_grid(name, world, k):
     assert all(sum(i["bytes_sent"].values()) > 0 for i in info if i["peers"])
 
 
-@pytest.mark.parametrize("k", [0, 1])
+@pytest.mark.parametrize("name,world,k,block", [("plume", 3, 2, 0), ("plume", 5, 2, 1), ("scattered", 5, 2, 1), ("scattered", 3, 4, 1), ("dense32", 2, 2, 1), ("plume", 8, 3, 0)])
+def test_exchanged_ranks_with_and_without_blocked_range_sweeps(name, world, k, block):
+    """Round 4: with sweeps_per_exchange >= 2 a rank's boundary and interior launch ranges take the last two iterations in front of
+    every exchange in ONE temporally blocked launch each (ghost leaves = tile sources; k = 2: no ghost leaf is ever swept). Option
+    dist_block = 0 is the round-3 loop (one iteration per launch on the ranges). Both must equal the single grid bit for bit."""
+    import hnanosolver_amd as H
+
+    H.set_option("dist_block", str(block))
+    try:
+        _local_ranks_match_single_grid(name, world, k)
+    finally:
+        H.set_option("dist_block", None)
+
+
+@pytest.mark.parametrize("name,world,iters", [("dense64", 2, 7), ("dense64", 5, 6), ("plume16", 3, 7), ("scattered_big", 4, 9), ("scattered_big", 2, 2)])
+def test_chained_ranks_two_iterations_per_launch(name, world, iters):
+    """Round 4: sweeps_per_exchange = 2 over the local / ipc transport with more than 600 leaves per rank = the chained substep whose
+    pressure loop is the temporally blocked kernel, two iterations per launch, boundary blocks waiting for the peers' previous launch
+    and writing the reach-4 region of p into the peers' ghost voxels themselves (k_rbgs_block<2, 2, ., true, PhaseMirror>); an odd
+    iteration left over goes through the one-iteration mirror sweep. Bit-identical to the single grid."""
+    _local_ranks_match_single_grid(name, world, 2, iters)
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
 def test_plume1024_in_8_ranges_matches_single_grid(k):
     """BASELINE.json configs[4]: the 1024^3-extent sparse plume (65,944 leaves) as the 8-GPU decomposition -- 8 contiguous
     leaf ranges, each with its ghost layer, boundary-first launch ranges and voxel-granular halo messages -- emulated on one
     device, 50 iterations, against the single-grid run of the same substep. k = 0: the exchanged pressure loop (refresh every
-    4th sweep); k = 1: the loop whose sweep kernel writes its boundary rows into the peers' ghost voxels itself."""
+    4th sweep); k = 1: the loop whose sweep kernel writes its boundary rows into the peers' ghost voxels itself; k = 2 (round 4):
+    the same with the temporally blocked kernel, two iterations per chained launch."""
     origins, R = fields.config_leaves("plume1024")
     names, iters = ["density"], 50
     _, want = single_grid(origins, R, names, iters, 1)
@@ -110,9 +142,9 @@ def test_plume1024_in_8_ranges_matches_single_grid(k):
         if k == 0:  # payload accounting: the pressure loop dominates; with k = 4 that is 12 refreshes of depth 8 plus the final depth-1 one
             assert i["exchanges"] == 1 + 1 + 1 + 13 + 1 + 1
             assert i["bytes_sent"]["p"] == 12 * 4 * i["region_voxels_sent"]["p"]
-        else:  # no exchange in the pressure loop: 50 sweeps each mirror the reach-2 region
+        else:  # no exchange in the pressure loop: 50 sweeps each mirror the reach-2 region (k = 2: 25 blocked launches, the reach-4 region)
             assert i["exchanges"] == 1  # the advection inputs of the first substep; every kernel after that delivers its own halo
-            assert i["bytes_sent"]["p"] == 50 * 4 * i["region_voxels_sent"]["p"]
+            assert i["bytes_sent"]["p"] == (50 // k) * 4 * i["region_voxels_sent"]["p"]
 
 
 def test_new_fields_between_substeps_and_many_substeps():
@@ -248,7 +280,7 @@ def _run_processes(world, case, k, iters, substeps, tmp_path, timeout=420):
     return [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
 
 
-@pytest.mark.parametrize("case,world,k,iters", [("plume", 3, 2, 7), ("plume12", 4, 3, 9), ("dense64", 2, 0, 50), ("dense64", 2, 1, 50), ("plume12", 4, 1, 9)])
+@pytest.mark.parametrize("case,world,k,iters", [("plume", 3, 2, 7), ("plume12", 4, 3, 9), ("dense64", 2, 0, 50), ("dense64", 2, 1, 50), ("plume12", 4, 1, 9), ("dense64", 2, 2, 50), ("dense64", 3, 2, 7)])
 def test_one_process_per_rank_over_mapped_peer_memory(case, world, k, iters, tmp_path):
     """The multi-process path for real: `world` PROCESSES (here sharing the one GPU), each a rank with its own streams, the
     halos put into the peer's memory through hipIpc mappings and the ranks meeting through device-side flags while their

@@ -148,3 +148,37 @@ def test_result_buffer_is_the_one_result_in_b_names(leaves):
         assert torch.equal(p_b if in_b.value else p_a, want), f"iterations = {iters}: the buffer named by result_in_b does not hold the result"
         _, launches, _ = D.rbgs_plan(grid, iters)
         assert in_b.value == (launches & 1), f"iterations = {iters}: result_in_b = {in_b.value} but the plan says {launches} launches"
+
+
+@pytest.mark.parametrize("name", ["dense40", "plume", "scatter", "node_borders"])
+def test_blocked_sor_over_a_launch_range(name):
+    """Round 4: the blocked form over a LAUNCH RANGE [first, first + count) of the grid's leaves (what a multi-GPU rank's
+    boundary / interior ranges are): two iterations in one launch, every leaf of the grid a tile source, only the leaves of
+    the range stored. Owned leaves must equal two iterations of the two-launch form on the whole grid bit for bit; the other
+    leaves of the output buffer must not be touched."""
+    origins = leaf_sets()[name]
+    n_leaves = len(origins)
+    n = n_leaves * 512
+    g = torch.Generator(device="cpu").manual_seed(n_leaves)
+    div = torch.randn(n, generator=g).cuda()
+    p0 = torch.randn(n, generator=g).cuda()
+    whole = api.create_grid_from_leaves(origins, 0.013)
+    want = solve(whole, div, p0, 2, rbgs="color")
+    for first, count in ((0, n_leaves // 3), (n_leaves // 3, n_leaves // 2), (n_leaves - 5, 5), (7, 1), (0, n_leaves)):
+        count = max(1, min(count, n_leaves - first))
+        part = api.create_grid_from_leaves(origins, 0.013)
+        part.set_active_range(first, count)
+        for lb in (0, 1, 2):  # by size, one-leaf blocks, 16^3 blocks
+            H.set_option("sor_block_lb", str(lb))
+            desc, launches, per = D.rbgs_plan(part, 2)
+            assert launches == 1 and "k_rbgs_block" in desc, (desc, launches)
+            p_a, p_b = p0.clone(), torch.full_like(p0, 7.0)
+            out = D.rbgs_iterate(part, div, p_a, p_b, 0.013, 1.93, 2)
+            assert out is p_b
+            sl = slice(first * 512, (first + count) * 512)
+            assert torch.equal(out[sl], want[sl]), f"{name} range [{first}, +{count}) lb={lb}: owned leaves differ"
+            keep = torch.ones(n, dtype=torch.bool, device="cuda")
+            keep[sl] = False
+            assert bool((out[keep] == 7.0).all()), f"{name} range [{first}, +{count}) lb={lb}: a leaf outside the range was written"
+            assert torch.equal(p_a, p0)
+        H.set_option("sor_block_lb", None)
