@@ -339,16 +339,23 @@ class SlabBench:
         def make(k):
             return DistRank(glob, world, rank, self.vs, n_scalars=1, sweeps_per_exchange=k)
 
+        self._glob, self._world = glob, world
         if world > 1 and connect and transport == "auto":
             self.rank_obj = self._verified_one_sided(make, sweeps_per_exchange, reference_transport)
         else:
-            # the one-sided transport runs the pressure loop whose sweep kernel delivers its own halo (sweeps_per_exchange = 1)
-            self.rank_obj = make(sweeps_per_exchange or (1 if transport == "ipc" else 0))
+            # the one-sided transport runs the pressure loop whose sweep kernel delivers its own halo
+            self.rank_obj = make(sweeps_per_exchange or (self._one_sided_k(len(glob), world) if transport == "ipc" else 0))
             if world > 1 and connect:
                 self.rank_obj.connect_ipc() if transport == "ipc" else self.rank_obj.connect_rccl()
         self.rank_obj.upload(*self._fields)
         self._glob, self._R, self._partition, self._first, self._count, self._world = glob, R, partition, first, count, world
         self.verified_note = "single GPU" if world == 1 else "not checked"
+
+    @staticmethod
+    def _one_sided_k(n_leaves: int, world: int) -> int:
+        """sweeps_per_exchange of the chained one-sided substep: 2 = the temporally blocked sweep, two iterations per chained launch,
+        where every rank's owned range is swept in 16^3 blocks (more than 600 leaves per rank: hns_dist.hip blocked_mirror); else 1."""
+        return 2 if n_leaves // max(1, world) > 600 else 1
 
     def verify_against_single_gpu(self, substeps: int = 2, max_voxels: int = 600_000_000) -> bool:
         """Every rank computes `substeps` substeps of the WHOLE domain on its own GPU with the single-GPU path (the same on every rank, bit
@@ -364,13 +371,13 @@ class SlabBench:
             self.verified_note = f"not checked against the single-GPU result (whole domain of {n_vox} voxels kept off one GPU)"
             return True
         d = self.rank_obj
-        d.upload(*self._fields)
-        for _ in range(substeps):
-            d.core_substep(self.iterations, self.dt, self.stream)
-        d.synchronize(self.stream)
-        got = d.download()
         why = ""
-        try:  # (whatever goes wrong on one rank, every rank reaches the collective below)
+        try:  # (whatever goes wrong on one rank -- the partitioned substeps included -- every rank reaches the collective below)
+            d.upload(*self._fields)
+            for _ in range(substeps):
+                d.core_substep(self.iterations, self.dt, self.stream)
+            d.synchronize(self.stream)
+            got = d.download()
             if self._partition:
                 f = fields.synthetic_fields(self._glob, self._R)
                 vel, den = f["vel"], f["density"]
@@ -389,14 +396,14 @@ class SlabBench:
             same = np.array_equal(got["vel"], arrays["vel"][sl]) and np.array_equal(got["scalars"][0], arrays["density"][sl])
             sim.close()
         except Exception as e:  # noqa: BLE001
-            same, why = False, f" [the single-GPU side failed on a rank: {type(e).__name__}: {e}]"[:200]
+            same, why = False, f" [the check failed on a rank: {type(e).__name__}: {e}]"[:200]
         import torch.distributed as dist
 
         t = self.torch.tensor([1 if same else 0, 0 if why else 1], dtype=self.torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         ok, ran = bool(int(t[0].item())), bool(int(t[1].item()))
         if not ran:
-            self.verified_note = "NOT checked: the single-GPU run of the whole domain failed on a rank" + why
+            self.verified_note = "NOT checked: the partitioned or the single-GPU run of the check failed on a rank" + why
         else:
             self.verified_note = (f"owned velocity and density after {substeps} substeps bit-identical to the single-GPU run of the whole domain on every rank" if ok else
                                   "MISMATCH against the single-GPU run of the whole domain: THIS RUN'S PHYSICS IS WRONG, its throughput means nothing")
@@ -427,7 +434,7 @@ class SlabBench:
         ref = make(sweeps_per_exchange)
         ref.connect_rccl() if reference_transport == "rccl" else ref.connect_ipc()
         want = two_substeps(ref)
-        cand = make(1)
+        cand = make(self._one_sided_k(len(self._glob), self._world))
         ok, why = cand.try_connect_ipc()
         if ok:
             try:

@@ -67,6 +67,12 @@ g = fields.synthetic_fields(own, R)
 lone.upload(g["vel"], [g["density"]])
 alone = timed(lambda: lone.core_substep(iters, dt, st))
 torch.cuda.synchronize()
+lone.timing(8)  # hipEvents around the pressure loop of the next substeps: us per red+black iteration of this rank
+for _ in range(8):
+    lone.core_substep(iters, dt, st)
+lone.synchronize(st)
+p_ms, p_sweeps = lone.pressure_time()
+alone_us_per_iteration = 1e3 * p_ms / max(1, p_sweeps)
 t0 = time.perf_counter()
 for _ in range(5):
     lone.core_substep(iters, dt, st)
@@ -87,7 +93,7 @@ print(json.dumps({
     "config": config, "world": world, "partition": partition, "sweeps_per_exchange": info[0]["sweeps_per_exchange"],
     "single_gpu_substep_ms": round(single, 3), "all_ranks_lockstep_ms": round(lock, 3), "same_work_on_one_grid_ms": round(work, 3),
     "lockstep_overhead": round(lock / work - 1.0, 4), "lockstep_host_enqueue_ms_per_rank_per_substep": round(enqueue, 3),
-    "one_rank_loopback": {"rank": lone_rank, "owned_leaves": alone_info["boundary_leaves"] + alone_info["interior_leaves"], "substep_ms": round(alone, 3),
+    "one_rank_loopback": {"rank": lone_rank, "owned_leaves": alone_info["boundary_leaves"] + alone_info["interior_leaves"], "substep_ms": round(alone, 3), "pressure_us_per_iteration": round(alone_us_per_iteration, 2),
                           "host_enqueue_ms": round(alone_enqueue, 3),
                           "overhead_vs_single_gpu_per_leaf": round((alone / (alone_info["boundary_leaves"] + alone_info["interior_leaves"])) / (single / len(origins) * (world if partition else 1)) - 1.0, 4)},
     "rank0": {x: info[0][x] for x in ("boundary_leaves", "interior_leaves", "ghost_leaves", "peers", "exchanges", "messages_sent", "bytes_sent")},
