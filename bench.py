@@ -23,8 +23,10 @@ their ratio either way. Times come from hipEvents recorded on the launch stream 
 on the launch stream, in a short pass of its own after the timed region) and `roofline.substep` the whole substep
 against 688 B/voxel. `traffic` is NOT measured by this
 run (bench.py cannot run rocprofv3 on itself): it is the PMC-derived HBM bytes per launch from the builder's committed
-rocprofv3 profile of this same command (profiles/pmc_latest.json), reported only while that profile was taken from the
-kernel source this library was built from, and labelled with `traffic_source`. `cpu_baseline`: the oracle (C restatement
+rocprofv3 passes of this same command (profiles/pmc_latest.json: per configuration and kernel), reported only while they
+were taken from the kernel source this library was built from, and labelled with `traffic_source`. Three fractions of the
+8 TB/s peak: `frac` (contractual: 12 B/voxel per ITERATION), `frac_compulsory` (12 B/voxel per LAUNCH: what the kernel must
+move) and `frac_moved` (what it did move, PMC); `roofline.kernels` carries `traffic` / `frac_moved` for all five kernels. `cpu_baseline`: the oracle (C restatement
 of the reference kernels, OpenMP over leaves) on the host cores, rank 0 at N=1 only, on a bounded sample.
 """
 from __future__ import annotations
@@ -53,7 +55,7 @@ STAGE_KERNEL = {"advect_vector": "k_advect_vector_n", "divergence": "k_divergenc
 def kernel_source_sha16():
     """Identifies the kernel source a PMC profile belongs to (profiles/pmc_latest.json carries the same stamp)."""
     h = hashlib.sha256()
-    for f in ("hns_pressure.hip", "hns_sorblock.hip", "hns_device.hpp", "hns_internal.hpp"):
+    for f in ("hns_pressure.hip", "hns_sorblock.hip", "hns_advect.hip", "hns_device.hpp", "hns_internal.hpp", "hns_flags.hpp"):
         h.update(open(os.path.join(ROOT, "hnanosolver_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -320,16 +322,26 @@ def main():
         iters_per_launch = args.iterations / max(1, sor_launches)
         ms_launch = ms_iter * iters_per_launch
         achieved = BYTES_PER_VOXEL_ITER * n_vox_rank / (ms_iter * 1e-3) / 1e9 if launches else None
-        traffic, traffic_source = None, None
+        # HBM-side bytes per kernel launch from the builder's committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), per
+        # configuration and kernel, quoted only while they were taken from the kernel sources this library was built from
+        traffic, traffic_source, pmc_kernels = None, None, {}
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc) and world == 1:
             try:
                 j = json.load(open(pmc))
-                if j.get("config") == args.config and j.get("kernel") == sor_form.split(":")[0].split("<")[0] and j.get("kernel_source_sha16") == kernel_source_sha16():
-                    traffic = j.get("hbm_bytes_per_launch") * iters_per_launch  # (the profile stores bytes per iteration)
-                    traffic_source = "profiles/pmc_latest.json: builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on this kernel source; not measured by this run"
+                if j.get("kernel_source_sha16") == kernel_source_sha16():
+                    pmc_kernels = j.get("configs", {}).get(args.config, {}).get("kernels", {})
+                    traffic_source = ("profiles/pmc_latest.json: builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate) of `bench.py --config " + args.config +
+                                      "` on this kernel source, 2 x FETCH_SIZE + WRITE_SIZE; not measured by this run")
             except Exception:
-                traffic = None
+                pmc_kernels = {}
+
+        def pmc_of(kernel_name):  # the profile keys kernels by their name without template arguments
+            return (pmc_kernels.get(kernel_name.split("<")[0].split(":")[0]) or {}).get("hbm_bytes_per_kernel_launch")
+
+        traffic = pmc_of(sor_form) if sor_form else None
+        if traffic is None:
+            traffic_source = None if not pmc_kernels else traffic_source
         kernels = {}
         if n_sub:
             for st, ms in stages.items():
@@ -337,8 +349,17 @@ def main():
                 per = ms / n_sub / n_l  # ms per kernel launch
                 alg = STAGE_BYTES[st] * n_vox_rank * (args.iterations / n_l if st == "pressure" else 1)
                 gbs = alg / (per * 1e-3) / 1e9 if per > 0 else None
-                kernels[STAGE_KERNEL[st] if st != "pressure" else sor_form.split(":")[0]] = {"stage": st, "ms_per_launch": per, "launches_per_substep": n_l,
-                                             "algorithmic_bytes_per_launch": alg, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS if gbs else None}
+                kname = STAGE_KERNEL[st] if st != "pressure" else sor_form.split(":")[0]
+                moved = pmc_of(kname)
+                ent = {"stage": st, "ms_per_launch": per, "launches_per_substep": n_l, "algorithmic_bytes_per_launch": alg, "achieved": gbs,
+                       "frac": gbs / HBM_PEAK_GBS if gbs else None,
+                       # what the kernel really moves per launch (PMC) and that rate against the peak
+                       "traffic": moved, "frac_moved": (moved / (per * 1e-3) / 1e9 / HBM_PEAK_GBS) if (moved and per > 0) else None}
+                if st == "pressure" and n_l != args.iterations:
+                    ent["frac_compulsory"] = (BYTES_PER_VOXEL_ITER * n_vox_rank / (per * 1e-3) / 1e9 / HBM_PEAK_GBS) if per > 0 else None
+                    ent["note"] = (f"one launch = {args.iterations / n_l:g} red+black iterations: `frac` prices SURVEY 8d's 12 B/voxel PER ITERATION and can exceed 1; "
+                                   "`frac_compulsory` prices one pass over p, p, div per LAUNCH (what the kernel must move), `frac_moved` the PMC bytes")
+                kernels[kname] = ent
         sub_bytes = (BYTES_PER_VOXEL_SUBSTEP - 600 + 12 * args.iterations) * n_vox_rank
         sub_gbs = sub_bytes / (ms_per_step * 1e-3) / 1e9
         out = {
@@ -381,9 +402,14 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_source,
                 "traffic_achieved": (traffic / (ms_launch * 1e-3) / 1e9) if (traffic and ms_launch) else None,  # GB/s of HBM-side bytes actually moved
-                "note": ("`achieved` prices the ALGORITHMIC bytes of SURVEY 8d -- one pass over p, p and div per red+black iteration, 12 B/voxel -- against the "
-                         "launch time; the temporally blocked kernel does several iterations per pass (iterations_per_launch), so it can exceed the HBM peak: "
-                         "`traffic` / `traffic_achieved` are the bytes it really moves") if iters_per_launch > 1 else None,
+                # the physical roofline next to the contractual one: bytes really moved (PMC) and bytes that MUST move per launch (one pass
+                # over p in, p out and div = 12 B/voxel per LAUNCH, however many iterations it holds), both against the same 8 TB/s
+                "frac_moved": (traffic / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and ms_launch) else None,
+                "frac_compulsory": (BYTES_PER_VOXEL_ITER * n_vox_rank / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS) if (launches and ms_launch) else None,
+                "note": ("`achieved` / `frac` price the ALGORITHMIC bytes of SURVEY 8d -- one pass over p, p and div per red+black iteration, 12 B/voxel -- against the "
+                         "launch time; the temporally blocked kernel does several iterations per pass (iterations_per_launch), so `frac` can exceed 1: it is an accounting "
+                         "figure in the contract's unit, not HBM utilisation. `frac_compulsory` = the bytes one launch must move (12 B/voxel per LAUNCH) / time / peak; "
+                         "`frac_moved` = the HBM-side bytes it really moved (PMC `traffic`) / time / peak") if iters_per_launch > 1 else None,
                 # per KERNEL LAUNCH, as rocprofv3 --stats lists the kernel: a launch of the temporally blocked form holds several red+black
                 # iterations (SURVEY 8d's unit of 12 B/voxel is the iteration), so its algorithmic bytes are 12 B/voxel x iterations per launch
                 "algorithmic_bytes_per_launch": BYTES_PER_VOXEL_ITER * n_vox_rank * iters_per_launch,
