@@ -104,17 +104,19 @@ def cook_equivalent(args):
            "active_voxels": len(coords), "bytes_over_pcie_per_cook": int(len(coords) * (12 + 5 * 4) * 2)}
     # cold: what the reference does every cook -- release the previous grid and device buffers, build new ones. warm: the same handle again; CreateIndexGrid finds the topology unchanged and the grid
     # keeps the device buffers of the previous cook.
-    for mode in ("cold", "warm"):
+    # feedback: warm, and the caller vouches that its arrays still hold what the previous cook handed back -- what the reference's SOP does
+    # with its feedback input (SOP_HNanoSolver.cpp:106): nothing is uploaded, the cook is the substep plus the downloads (hns_compute_sim_resident)
+    for mode in ("cold", "warm", "feedback"):
         times = {"release_ms": [], "create_index_grid_ms": [], "compute_sim_ms": [], "total_ms": []}
         h = api.IndexGridHandle()
-        for _ in range(args.warmup + args.steps):
+        for it in range(args.warmup + args.steps):
             ta = time.perf_counter()
             if mode == "cold":
                 h.reset()
             t0 = time.perf_counter()
             api.CreateIndexGrid(d, h, 1.0 / R)
             t1 = time.perf_counter()
-            api.Compute_Sim(d, h, args.iterations, 1.0 / 24.0, 1.0 / R, p, False)
+            api.Compute_Sim(d, h, args.iterations, 1.0 / 24.0, 1.0 / R, p, False, feedback=(mode == "feedback" and it > 0) or None)
             t2 = time.perf_counter()
             times["release_ms"].append(1e3 * (t0 - ta))
             times["create_index_grid_ms"].append(1e3 * (t1 - t0))

@@ -82,6 +82,7 @@ SIGNATURES = {
     "hns_dilate_leaves": (_i, [_vp, _u64, _vp, _i, _vp, _u64, C.POINTER(C.c_uint64)]),
     "hns_union_leaves": (_i, [_vp, _u64, _vp, _u64, _vp, _u64, C.POINTER(C.c_uint64)]),
     "hns_compute_sim": (_i, [_vp, C.POINTER(hns_field), _i, _i, _f, _f, C.POINTER(hns_combustion_params), _i, _vp]),
+    "hns_compute_sim_resident": (_i, [_vp, C.POINTER(hns_field), _i, C.c_char_p, C.POINTER(C.c_int), _i, _f, _f, C.POINTER(hns_combustion_params), _i, _vp]),
     "hns_advect_index_grid": (_i, [_vp, C.POINTER(hns_field), _i, _f, _f, _vp]),
     "hns_advect_index_grid_velocity": (_i, [_vp, C.POINTER(hns_field), _i, _f, _f, _vp]),
     "hns_project_non_divergent": (_i, [_vp, C.POINTER(hns_field), _i, _u64, _f, _vp]),

@@ -272,7 +272,10 @@ def CreateIndexGrid(data: GridIndexedData, handle: IndexGridHandle, voxelSize: f
 
 
 def Compute_Sim(data: GridIndexedData, handle: IndexGridHandle, iteration: int, dt: float, voxelSize: float, params: CombustionParams,
-                hasCollision: bool, stream=None) -> None:
+                hasCollision: bool, stream=None, feedback=None) -> Optional[int]:
+    """feedback (not in the reference's signature): True, or the names of the blocks whose arrays still hold what the previous
+    Compute_Sim on this handle handed back (the SOP feeds its output back in as the next frame's input, SOP_HNanoSolver.cpp:106):
+    those blocks are not uploaded again (hns_compute_sim_resident; the promise is checked). Returns the number of uploads skipped."""
     if handle is None or handle.isEmpty():
         # argument checks come first in the reference (HNanoSolver.cu:12-23)
         if voxelSize <= 0.0:
@@ -284,7 +287,14 @@ def Compute_Sim(data: GridIndexedData, handle: IndexGridHandle, iteration: int, 
         raise ValueError("Invalid grid handle provided (null grid).")
     fields, n, keep = data._fields()
     p = params._c()
+    if feedback:
+        flags = bytes(1 if (feedback is True or fields[i].name.decode() in feedback) else 0 for i in range(n))
+        skipped = C.c_int(0)
+        _raise(lib.hns_compute_sim_resident(handle.ptr, fields, n, flags, C.byref(skipped), int(iteration), float(dt), float(voxelSize), C.byref(p),
+                                            int(bool(hasCollision)), _stream(stream)))
+        return skipped.value
     _raise(lib.hns_compute_sim(handle.ptr, fields, n, int(iteration), float(dt), float(voxelSize), C.byref(p), int(bool(hasCollision)), _stream(stream)))
+    return None
 
 
 def _grid_for(data: GridIndexedData, voxelSize: float) -> IndexGridHandle:

@@ -111,9 +111,12 @@ __device__ __forceinline__ Taps make_taps(const GridDev& g, const int* s_nbr, co
 			T.t[c] = b < 0 ? -1 : b + (lx[di] | ly[dj] | lz[dk]);
 		}
 	} else {
-		if (g.far_flag) *g.far_flag = 1;  // a multi-GPU rank: this back-trace left the ghost layer (hns_dist reports it)
+		int any = 0;
 #pragma unroll
-		for (int c = 0; c < 8; ++c) T.t[c] = tap_index(g, s_nbr, org, i + (c >> 2), j + ((c >> 1) & 1), k + (c & 1));  // unrolled: see make_taps_b
+		for (int c = 0; c < 8; ++c) any |= (T.t[c] = tap_index(g, s_nbr, org, i + (c >> 2), j + ((c >> 1) & 1), k + (c & 1)));  // unrolled: see make_taps_b
+		// a multi-GPU rank: a tap beyond the 27-leaf neighbourhood whose leaf is not HERE may exist on another rank (hns_dist reports
+		// it); one that resolves to a local leaf -- owned or ghost, both hold current values -- is answered as the single domain answers it
+		if (any < 0 && g.far_flag) *g.far_flag = 1;
 	}
 	return T;
 }
@@ -140,12 +143,14 @@ __device__ __forceinline__ TapsB make_taps_b(const GridDev& g, const int* s_nbr,
 			T.o[c] = s_b4[sx[di] + sy[dj] + sz[dk]] + (lx[di] | ly[dj] | lz[dk]);
 		}
 	} else {
-		if (g.far_flag) *g.far_flag = 1;  // a multi-GPU rank: this back-trace left the ghost layer (hns_dist reports it)
+		int any = 0;
 #pragma unroll
 		for (int c = 0; c < 8; ++c) {  // unrolled: a rolled loop would index T.o dynamically and push the whole array into LDS
 			const int t = tap_index(g, s_nbr, org, i + (c >> 2), j + ((c >> 1) & 1), k + (c & 1));
+			any |= t;
 			T.o[c] = t < 0 ? kOutside : (unsigned)t << 2;
 		}
+		if (any < 0 && g.far_flag) *g.far_flag = 1;  // a multi-GPU rank: a far tap whose leaf is not here may exist on another rank (see make_taps)
 	}
 	return T;
 }

@@ -2,6 +2,7 @@
 // include/hns.h. The launch orders follow the reference's host drivers (reference src/Cuda/HNanoSolver.cu:150-356,
 // src/Cuda/PressureProjection.cu:43-66, src/Cuda/Advection.cu:76-91,148-155); what differs is that fields can stay
 // resident across substeps and that nothing is allocated inside a substep.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -81,6 +82,10 @@ struct hns_sim {
 	hipStream_t xfer = nullptr;  // transfer stream + hand-off events of the pipelined operator path (compute_sim_pipelined)
 	hipEvent_t xev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 	bool cached = false, in_use = false;  // owned by the grid's cook cache / currently lent to an operator call
+	// Device-resident feedback across cooks (hns_compute_sim_resident): a signature of what the last hns_compute_sim on this state handed
+	// back for the velocity and for float field i -- those bytes are still in `vel` / cur[i]. 0 = nothing to vouch for (any upload clears it).
+	uint64_t sig_vel = 0;
+	std::vector<uint64_t> sig_cur;
 	void* arena = nullptr;  // every field above is a slice of this one allocation (see the arena pool below)
 	size_t arena_bytes = 0;
 	int device = -1;
@@ -306,6 +311,7 @@ extern "C" int hns_sim_upload(hns_sim* s, const hns_field* fields, int n_fields,
 			return HNS_ERR_RUNTIME;
 		}
 		if (f.ncomp == 3) {
+			s->sig_vel = 0;
 			HNS_HIP(hipMemcpyAsync(s->vel, f.host, sizeof(float) * 3 * (size_t)s->n, hipMemcpyHostToDevice, st));
 		} else if (f.ncomp == 1) {
 			const int k = f.name ? s->find(f.name) : -1;
@@ -313,6 +319,7 @@ extern "C" int hns_sim_upload(hns_sim* s, const hns_field* fields, int n_fields,
 				set_error("hns_sim_upload: no float field named '%s' in this sim", f.name ? f.name : "?");
 				return HNS_ERR_RUNTIME;
 			}
+			if ((size_t)k < s->sig_cur.size()) s->sig_cur[(size_t)k] = 0;
 			HNS_HIP(hipMemcpyAsync(s->cur[k], f.host, sizeof(float) * (size_t)s->n, hipMemcpyHostToDevice, st));
 		} else {
 			return fail(HNS_ERR_INVALID_ARGUMENT, "hns_sim_upload: ncomp must be 1 or 3");
@@ -697,16 +704,61 @@ int make_sim(hns_grid* g, const FieldSplit& fs, SimGuard& guard, void* stream) {
 // run under the upload of fuel and waste, the pressure solve under the upload of every other field (Substep::part_b1),
 // and advect_scalars under the download of the final velocity. Same kernels, same order per buffer; only the overlap
 // differs. Option "cook_pipeline" = 0 falls back to upload-all / run / download-all.
+// What a host array and the device buffer it was downloaded from have in common afterwards: element count and 4,096 evenly spread
+// elements, hashed (FNV-1a over their bits). Never 0. Cheap next to a transfer (16 KB read out of 67 - 201 MB), and what a caller's
+// "this array is what you gave me last cook" promise is checked against before an upload is skipped on the strength of it.
+static uint64_t host_signature(const float* a, size_t count) {
+	uint64_t h = 1469598103934665603ull ^ (uint64_t)count;
+	const size_t samples = count < 4096 ? count : 4096;
+	for (size_t i = 0; i < samples; ++i) {
+		uint32_t bits;
+		memcpy(&bits, a + (samples == count ? i : (size_t)(((unsigned __int128)i * count) / samples)), 4);
+		h = (h ^ bits) * 1099511628211ull;
+	}
+	return h ? h : 1;
+}
+
+// `resident` (hns_compute_sim_resident): per field of `fields` (by position), non-zero = the caller vouches that the host array still
+// holds what the previous hns_compute_sim on this grid handed back for the block of that name. The field is then not uploaded -- if
+// the device state lent to this call is the one that produced it and the array's signature still matches; uploaded as usual otherwise.
 static int compute_sim_pipelined(hns_sim* s, FieldSplit& fs, int iterations, float dt, float voxel_size, const hns_combustion_params* params,
-                                 int has_collision, void* stream) {
+                                 int has_collision, void* stream, const std::vector<const hns_field*>& resident, int* skipped) {
 	Substep step;
+	const size_t count = (size_t)s->n;
+	s->sig_cur.resize(s->names.size(), 0);
+	auto stays = [&](const hns_field* f) {
+		if (std::find(resident.begin(), resident.end(), f) == resident.end()) return false;
+		uint64_t have = 0;
+		size_t n = count;
+		if (f->ncomp == 3) have = s->sig_vel, n = 3 * count;
+		else {
+			const int k = s->find(f->name);
+			if (k >= 0) have = s->sig_cur[(size_t)k];
+		}
+		if (!have || have != host_signature(f->host, n)) return false;
+		if (skipped) ++*skipped;
+		return true;
+	};
+	auto upload = [&](hns_field* f, void* on) { return stays(f) ? (int)HNS_OK : hns_sim_upload(s, f, 1, on); };
+	auto sign = [&]() {  // (the downloads have completed: what the host arrays hold now is what vel / cur[] hold)
+		s->sig_vel = host_signature(fs.velocity->host, 3 * count);
+		for (hns_field* f : fs.floats) {
+			const int k = s->find(f->name);
+			if (k >= 0) s->sig_cur[(size_t)k] = strcmp(f->name, "collision_sdf") ? host_signature(f->host, count) : 0;  // (the SDF comes back zeroed, the device keeps it)
+		}
+	};
 	if (!options().cook_pipeline.load()) {
 		std::vector<hns_field> all;
+		HNS_TRY(upload(fs.velocity, stream));
 		all.push_back(*fs.velocity);
-		for (hns_field* f : fs.floats) all.push_back(*f);
-		HNS_TRY(hns_sim_upload(s, all.data(), (int)all.size(), stream));
+		for (hns_field* f : fs.floats) {
+			HNS_TRY(upload(f, stream));
+			all.push_back(*f);
+		}
 		HNS_TRY(hns_sim_substep(s, iterations, dt, voxel_size, params, has_collision, stream));
-		return hns_sim_download(s, all.data(), (int)all.size(), stream);
+		HNS_TRY(hns_sim_download(s, all.data(), (int)all.size(), stream));
+		sign();
+		return HNS_OK;
 	}
 	if (!s->xfer) {
 		HNS_HIP(hipStreamCreateWithFlags(&s->xfer, hipStreamNonBlocking));
@@ -724,15 +776,15 @@ static int compute_sim_pipelined(hns_sim* s, FieldSplit& fs, int iterations, flo
 	if (step.coll)
 		for (hns_field* f : fs.floats)
 			if (!strcmp(f->name, "collision_sdf")) HNS_TRY(hns_sim_upload(s, f, 1, xf));
-	HNS_TRY(hns_sim_upload(s, fs.velocity, 1, xf));
+	HNS_TRY(upload(fs.velocity, xf));
 	HNS_TRY(handoff(s->xev[1], xf, st));
 	HNS_TRY(step.part_a());
 	for (hns_field* f : fs.floats)
-		if (is_fuel_or_waste(f->name)) HNS_TRY(hns_sim_upload(s, f, 1, xf));
+		if (is_fuel_or_waste(f->name)) HNS_TRY(upload(f, xf));
 	HNS_TRY(handoff(s->xev[2], xf, st));
 	HNS_TRY(step.part_b1());  // the solve runs while every remaining field is still on its way
 	for (hns_field* f : fs.floats)  // "collision_sdf" went up first if this call uses it; if not, nothing reads it and it returns zeroed
-		if (!is_fuel_or_waste(f->name) && strcmp(f->name, "collision_sdf") != 0) HNS_TRY(hns_sim_upload(s, f, 1, xf));
+		if (!is_fuel_or_waste(f->name) && strcmp(f->name, "collision_sdf") != 0) HNS_TRY(upload(f, xf));
 	HNS_TRY(handoff(s->xev[4], xf, st));
 	HNS_TRY(step.part_b2());
 	HNS_HIP(hipEventRecord(s->xev[3], st));  // s->vel is final here
@@ -745,11 +797,18 @@ static int compute_sim_pipelined(hns_sim* s, FieldSplit& fs, int iterations, flo
 		if (strcmp(f->name, "collision_sdf") != 0) outs.push_back(*f);  // the caller's SDF array comes back zeroed (hns_compute_sim): no bytes to fetch
 	HNS_TRY(hns_sim_download(s, outs.data(), (int)outs.size(), xf));  // synchronises xf
 	HNS_HIP(hipStreamSynchronize(st));
+	sign();
 	return HNS_OK;
 }
 
 extern "C" int hns_compute_sim(hns_grid* g, hns_field* fields, int n_fields, int iterations, float dt, float voxel_size,
                                const hns_combustion_params* params, int has_collision, void* stream) {
+	return hns_compute_sim_resident(g, fields, n_fields, nullptr, nullptr, iterations, dt, voxel_size, params, has_collision, stream);
+}
+
+extern "C" int hns_compute_sim_resident(hns_grid* g, hns_field* fields, int n_fields, const unsigned char* resident, int* uploads_skipped, int iterations, float dt,
+                                        float voxel_size, const hns_combustion_params* params, int has_collision, void* stream) {
+	if (uploads_skipped) *uploads_skipped = 0;
 	HNS_TRY(validate_step(voxel_size, dt, iterations, true));
 	if (!g) return fail(HNS_ERR_INVALID_ARGUMENT, "Invalid grid handle provided (null grid).");  // HNanoSolver.cu:21-23
 	if (!params) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_compute_sim: null combustion params");
@@ -768,9 +827,15 @@ extern "C" int hns_compute_sim(hns_grid* g, hns_field* fields, int n_fields, int
 			return HNS_ERR_RUNTIME;
 		}
 	if (!g->on_device) return fail(HNS_ERR_NO_DEVICE, "hns_compute_sim: grid has no device tables (there is no CPU fallback)");
+	std::vector<const hns_field*> res;
+	if (resident)
+		for (int i = 0; i < n_fields; ++i)
+			if (resident[i]) res.push_back(&fields[i]);
 	SimGuard guard;
 	HNS_TRY(make_sim(g, fs, guard, stream));
-	if (int rc = compute_sim_pipelined(guard.s, fs, iterations, dt, voxel_size, params, has_collision, stream)) {
+	if (int rc = compute_sim_pipelined(guard.s, fs, iterations, dt, voxel_size, params, has_collision, stream, res, uploads_skipped)) {
+		guard.s->sig_vel = 0;  // whatever the buffers hold now, nobody was handed it
+		std::fill(guard.s->sig_cur.begin(), guard.s->sig_cur.end(), 0);
 		// copies on the transfer stream and kernels on the caller's may still be queued: let them finish before the
 		// guard hands the buffers on (and before the caller reuses its host arrays)
 		if (guard.s->xfer) (void)hipStreamSynchronize(guard.s->xfer);

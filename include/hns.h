@@ -193,6 +193,16 @@ typedef struct { /* CombustionParams, src/Cuda/Kernels.cuh:6-13 */
  * temperature, flame (HNanoSolver.cu:42-63,193-201). omega = 2/(1+sinf(3.14159f*voxel_size)) (:257). */
 int hns_compute_sim(hns_grid*, hns_field* fields, int n_fields, int iterations, float dt, float voxel_size,
                     const hns_combustion_params* params, int has_collision, void* stream);
+/* The same cook when the caller feeds the previous cook's output straight back in -- what the reference's SOP does with its first
+ * input (src/SOP/HNanoSolver/SOP_HNanoSolver.cpp:106: the "feedback" VDBs of frame n are frame n+1's state): resident[i] != 0 vouches
+ * that fields[i].host still holds, untouched, what the previous hns_compute_sim(_resident) on this grid handed back for the block of
+ * that name. Such a field is not uploaded again: the device buffer it was downloaded from still holds it (the cook cache keeps
+ * operator state with the grid, "cook_cache"). The promise is checked, not trusted: a signature of the array (its size and 4,096
+ * evenly spread elements) is compared with the one taken when it was handed back, and the field is uploaded as usual when they differ,
+ * when the topology changed, or when another operator used the state in between. resident == NULL: hns_compute_sim. *uploads_skipped
+ * (may be NULL) receives the number of fields that stayed on the device. Results are bit-identical to hns_compute_sim. */
+int hns_compute_sim_resident(hns_grid*, hns_field* fields, int n_fields, const unsigned char* resident, int* uploads_skipped, int iterations, float dt,
+                             float voxel_size, const hns_combustion_params* params, int has_collision, void* stream);
 /* AdvectIndexGrid: every float field through the single-field BFECC kernel (advect_scalar), no collision. */
 int hns_advect_index_grid(hns_grid*, hns_field* fields, int n_fields, float dt, float voxel_size, void* stream);
 /* AdvectIndexGridVelocity: BFECC self-advection of the one Vec3f field. */
@@ -287,11 +297,13 @@ int hns_dev_unpack_leaves(const float* packed, const int32_t* leaf_ids, uint64_t
 /* Leaf-partitioned multi-GPU core substep (new: the reference is single-GPU). One hns_dist per rank = per GPU.      */
 /* Rank r owns leaves [n*r/world, n*(r+1)/world) of the global leaf list (NanoVDB order: x-slabs for box domains), */
 /* keeps one layer of ghost leaves and refreshes exactly the ghost voxels the next kernel can read (hns_dist.hip). */
-/* Owned results are bit-identical to the single-domain hns_sim_core_substep -- as long as no advection back-trace    */
-/* leaves the 27-leaf neighbourhood of its voxel's leaf (|u| dt / dx up to ~8 voxels): a rank holds ONE layer of      */
-/* ghost leaves. A longer back-trace is detected on the device and the next hns_dist_*_substep / hns_dist_synchronize */
-/* / hns_dist_download returns HNS_ERR_RUNTIME saying so; hns_dist_upload clears it (the single-GPU path follows any  */
-/* back-trace through its origin hash and has no such limit).                                                         */
+/* Owned results are bit-identical to the single-domain hns_sim_core_substep -- as long as every tap of an advection   */
+/* back-trace that leaves the 27-leaf neighbourhood of its voxel's leaf (|u| dt / dx above ~8 voxels) still lands in   */
+/* a leaf this rank holds (owned or ghost: a rank holds ONE layer of ghost leaves). A far tap whose leaf is not here   */
+/* may exist on another rank: it is detected on the device and the next hns_dist_*_substep / hns_dist_synchronize /    */
+/* hns_dist_download returns HNS_ERR_RUNTIME saying so; hns_dist_upload clears it. (Far taps deep inside a rank are    */
+/* answered through the origin hash like on one GPU; a far tap beyond the true edge of the domain is reported too --   */
+/* the rank cannot tell it from one beyond its ghost layer. The single-GPU path has no such limit.)                    */
 /* ------------------------------------------------------------------------------------------------------------ */
 
 typedef struct hns_dist hns_dist;

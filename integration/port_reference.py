@@ -72,7 +72,12 @@ EDITS = [
 
 
 def apply(root: str, write: bool = True):
-    """Returns (matched, problems). With write=False nothing is modified."""
+    """Returns (matched, problems). With write=False nothing is modified. With write=True NOTHING is written unless every anchor
+    of every file matched: a checkout that has moved on is reported, never left half edited."""
+    if write:
+        matched, problems = apply(root, write=False)
+        if problems:
+            return matched, problems
     by_file = {}
     for e in EDITS:
         by_file.setdefault(e[0], []).append(e)

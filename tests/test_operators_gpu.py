@@ -502,3 +502,53 @@ def test_random_sparse_domains_against_the_oracle(seed):
     for n in names + ["vel"]:
         assert np.array_equal(d.pValues(n), want[n]), f"seed {seed} ({len(origins)} leaves, {iters} iterations, collision={collision}, fs={fs}): {n} differs, rel L-inf {rel_linf(d.pValues(n), want[n]):.2e}"
     h.reset()
+
+
+@pytest.mark.parametrize("collision", [False, True])
+def test_feedback_cooks_keep_fields_on_the_device(collision):
+    """Round 4: the SOP feeds frame n's output back in as frame n+1's input (SOP_HNanoSolver.cpp:106).
+    Compute_Sim(..., feedback=True) vouches for that, and fields whose host arrays still carry the signature of what the previous
+    cook handed back are not uploaded again. Same bits as plain cooks; a broken promise (an array that changed) is noticed and
+    uploaded; another operator on the same state in between invalidates what it touched."""
+    origins, R = fields.plume_leaves(8, 1.0, 0.3), 64
+    vs, dt, iters = 1.0 / R, 1.0 / 24.0, 9
+    params = api.CombustionParams(factorScale=1.0, vorticityScale=0.3)
+    names = ["density", "temperature", "fuel", "waste", "flame", "vel"]
+
+    def cooks(feedback, n=4, poke=None, project_before=None):
+        d = build_data(origins, R, with_sdf=collision)
+        sdf = d.pValues("collision_sdf").copy() if collision else None
+        h = api.IndexGridHandle()
+        api.CreateIndexGrid(d, h, vs)
+        skipped = []
+        for c in range(n):
+            if collision:
+                d.pValues("collision_sdf")[:] = sdf  # the SOP reads the collider every cook; Compute hands it back zeroed
+            if poke == c:
+                d.pValues("density")[0] += 1.0  # element 0 is one of the signature's samples
+            if project_before == c:
+                api.ProjectNonDivergent(d, 3, vs, handle=h)
+            skipped.append(api.Compute_Sim(d, h, iters, dt, vs, params, collision, feedback=feedback if c else None))
+        out = snapshot(d)
+        h.reset()
+        return out, skipped
+
+    want, _ = cooks(None)
+    got, skipped = cooks(True)
+    assert skipped == [None, 6, 6, 6], skipped  # velocity + five float blocks stay on the device (the SDF goes up every cook)
+    for n in names:
+        assert np.array_equal(got[n], want[n]), n
+    got, skipped = cooks(["density", "vel", "fuel"])
+    assert skipped == [None, 3, 3, 3], skipped
+    for n in names:
+        assert np.array_equal(got[n], want[n]), n
+    want, _ = cooks(None, poke=2)
+    got, skipped = cooks(True, poke=2)
+    assert skipped == [None, 6, 5, 6], skipped  # the changed array is noticed and uploaded
+    for n in names:
+        assert np.array_equal(got[n], want[n]), n
+    want, _ = cooks(None, project_before=2)
+    got, skipped = cooks(True, project_before=2)
+    assert skipped == [None, 6, 5, 6], skipped  # ProjectNonDivergent uploaded a velocity of its own into the shared state
+    for n in names:
+        assert np.array_equal(got[n], want[n]), n
