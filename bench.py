@@ -174,7 +174,27 @@ def cpu_baseline(origins, R, iterations, budget_s=25.0):
         one = {"value": 1.0 / (time.perf_counter() - t3), "unit": "substeps/s", "cores": 1, "workload": "64^3 dense-active grid, the whole core substep"}
     finally:
         L.orc_set_threads(cores)
+    # the REFERENCE ITSELF (src/Cuda/Kernel.cu built for the host into oracle/_ref/libhns_refk.so; one thread, serial launch emulation)
+    # on BASELINE.json's configs[0], the 64^3 smoke plume: the same core substep, when that prebuilt library travelled with the repo
+    ref64 = None
+    try:
+        from oracle_lib import RefKernelGrid, reference_kernels, reference_samplers
+
+        if reference_kernels() is not None and reference_samplers() is not None:
+            o64 = fields.dense_leaves(64)
+            K, f1 = RefKernelGrid(o64), fields.synthetic_fields(o64, 64)
+            t4 = time.perf_counter()
+            a1 = K.advect_vector(f1["vel"], dt, 64.0)
+            d1 = K.divergence(a1, 64.0)
+            p1 = K.rbgs_iterations(d1, 1.0 / 64, float(L.orc_omega_compute(1.0 / 64)), iterations)
+            u1 = K.subtract_pressure_gradient(a1, p1, 64.0)
+            K.advect_scalars(u1, [f1["density"]], dt, 64.0)
+            ref64 = {"value": 1.0 / (time.perf_counter() - t4), "unit": "substeps/s", "cores": 1, "kind": "reference",
+                     "workload": "64^3 dense-active grid, the whole core substep, the reference's own kernels compiled for the host"}
+    except Exception as e:  # noqa: BLE001 -- a reported extra, never the reason a bench line is missing
+        ref64 = {"error": f"{type(e).__name__}: {e}"[:200]}
     return {
+        "reference_64": ref64,
         "one_core_64": one,
         "value": 1.0 / per_substep,
         "unit": "substeps/s",

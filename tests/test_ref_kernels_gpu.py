@@ -87,3 +87,25 @@ def test_drop_in_operators_equal_reference_launch_sequences(collision):
         state.append({"vel": vel, "proj": u, **{n: cur[n] for n in names}})
     for k in state[0]:
         same(state[1][k], state[0][k], k)
+
+
+def test_config0_the_64_cube_smoke_plume_against_the_reference_itself():
+    """BASELINE.json configs[0]: the 64^3 dense-active smoke plume, one substep of the WHOLE Compute sequence with 50 pressure
+    iterations, "CPU reference path": the reference's own kernels (Kernel.cu built for the host, one thread, launched in
+    HNanoSolver.cu:150-356's order) against Compute_Sim through the drop-in API on the GPU -- every field bit for bit."""
+    from hip_kernels import HipKernels
+
+    from hnanosolver_amd import fields
+
+    R = 64
+    o = fields.dense_leaves(R)
+    f = fields.synthetic_fields(o, R)
+    names = ["density", "temperature", "fuel", "waste", "flame"]
+    state = []
+    for E in (RefKernelGrid(o), HipKernels(o, 1.0 / R)):
+        cur = {n: f[n].copy() for n in names}
+        vel = f["vel"].copy()
+        assert E.compute_sim(vel, cur, 50, 1.0 / 24.0, 1.0 / R, api.CombustionParams(), False) == 0
+        state.append({"vel": vel, **cur})
+    for k in state[0]:
+        same(state[1][k], state[0][k], k)
