@@ -68,7 +68,11 @@ __device__ __forceinline__ void ld_zpair(const v4i& r, unsigned lo, unsigned hi,
 
 // stage nbr27 (for the generic path), the neighbours' base indices leaf*512 (-1 = absent) and, for the 32-bit path, their
 // base byte offsets in a float field (kOutside = absent)
-__device__ __forceinline__ LeafCtx stage_leaf_base(const GridDev& g, int* s_nbr, int* s_base, int block, unsigned* s_b4 = nullptr) {
+// s_b4p (32-bit kernels): the same byte bases again in a table padded to 4 x 4 x 4, entry (ax*4 + ay)*4 + az for the neighbour leaf
+// (ax, ay, az) in 0..2 -- its byte index ax<<6 | ay<<4 | az<<2 is shifts and ORs of the tap's coordinates, where 9*ax + 3*ay + az cost
+// four quarter-rate multiplies per trilinear sample (make_taps_b).
+constexpr int kPadTab = 48;
+__device__ __forceinline__ LeafCtx stage_leaf_base(const GridDev& g, int* s_nbr, int* s_base, int block, unsigned* s_b4 = nullptr, unsigned* s_b4p = nullptr) {
 	LeafCtx c;
 	const int pos = (int)launch_pos(g, (unsigned)block);
 	c.leaf = g.sched ? g.sched[pos] : g.first + pos;
@@ -78,6 +82,10 @@ __device__ __forceinline__ LeafCtx stage_leaf_base(const GridDev& g, int* s_nbr,
 		s_nbr[threadIdx.x] = nb;
 		s_base[threadIdx.x] = nb < 0 ? -1 : nb * 512;
 		if (s_b4) s_b4[threadIdx.x] = nb < 0 ? kOutside : (unsigned)nb * 2048u;
+		if (s_b4p) {
+			const int t = threadIdx.x, ax = t / 9, ay = (t - 9 * ax) / 3, az = t - 9 * ax - 3 * ay;
+			s_b4p[(ax * 4 + ay) * 4 + az] = nb < 0 ? kOutside : (unsigned)nb * 2048u;
+		}
 	}
 	__syncthreads();
 	return c;
@@ -121,26 +129,31 @@ __device__ __forceinline__ Taps make_taps(const GridDev& g, const int* s_nbr, co
 	return T;
 }
 
-// the same for the 32-bit path: byte offsets, and an absent leaf needs no test (its base is kOutside)
-__device__ __forceinline__ TapsB make_taps_b(const GridDev& g, const int* s_nbr, const unsigned* s_b4, const int4 org, float x, float y, float z) {
+// the same for the 32-bit path: byte offsets, and an absent leaf needs no test (its base is kOutside).
+// Round 4: the kernels that call this keep the VALU 86 % busy (4 cycles per wave instruction; SQ_ACTIVE_INST_VALU) next to a texture
+// addresser at 84 %, and a good half of their instructions address taps. So: d = cell - (corner of the 3 x 3 x 3 leaves around the
+// workgroup's leaf) per axis, "near" <=> every d in [0, 22] (cell and cell + 1 inside the 24 voxels: ONE max3 and ONE compare instead of
+// six range tests), neighbour slot and voxel-in-leaf are bit fields of d, the table is padded so that its index is ORs (s_b4p), and
+// the eight offsets are add3's of three precombined terms.
+__device__ __forceinline__ TapsB make_taps_b(const GridDev& g, const int* s_nbr, const unsigned* s_b4p, const int4 org, float x, float y, float z) {
 	TapsB T;
 	const int i = __float2int_rd(x), j = __float2int_rd(y), k = __float2int_rd(z);
 	T.fx = x - (float)i;
 	T.fy = y - (float)j;
 	T.fz = z - (float)k;
-	const int ax0 = (i >> 3) - (org.x >> 3) + 1, ax1 = ((i + 1) >> 3) - (org.x >> 3) + 1;
-	const int ay0 = (j >> 3) - (org.y >> 3) + 1, ay1 = ((j + 1) >> 3) - (org.y >> 3) + 1;
-	const int az0 = (k >> 3) - (org.z >> 3) + 1, az1 = ((k + 1) >> 3) - (org.z >> 3) + 1;
-	const bool near = ((unsigned)ax0 <= 2u) & ((unsigned)ax1 <= 2u) & ((unsigned)ay0 <= 2u) & ((unsigned)ay1 <= 2u) & ((unsigned)az0 <= 2u) &
-	                  ((unsigned)az1 <= 2u);
-	if (near) {
-		const int sx[2] = {ax0 * 9, ax1 * 9}, sy[2] = {ay0 * 3, ay1 * 3}, sz[2] = {az0, az1};
-		const unsigned lx[2] = {(unsigned)(i & 7) << 8, (unsigned)((i + 1) & 7) << 8}, ly[2] = {(unsigned)(j & 7) << 5, (unsigned)((j + 1) & 7) << 5},
-		               lz[2] = {(unsigned)(k & 7) << 2, (unsigned)((k + 1) & 7) << 2};
+	const unsigned dx = (unsigned)(i - (org.x - 8)), dy = (unsigned)(j - (org.y - 8)), dz = (unsigned)(k - (org.z - 8));
+	if (max(dx, max(dy, dz)) < 23u) {
+		const unsigned ex = dx + 1u, ey = dy + 1u, ez = dz + 1u;
+		// table byte index (d >> 3) << {6, 4, 2} and voxel-in-leaf byte offset (d & 7) << {8, 5, 2}, for the cell (0) and cell + 1 (1)
+		const unsigned X[2] = {(dx & 24u) << 3, (ex & 24u) << 3}, Y[2] = {(dy & 24u) << 1, (ey & 24u) << 1}, Z[2] = {(dz & 24u) >> 1, (ez & 24u) >> 1};
+		const unsigned lx[2] = {(dx & 7u) << 8, (ex & 7u) << 8}, ly[2] = {(dy & 7u) << 5, (ey & 7u) << 5}, lz[2] = {(dz & 7u) << 2, (ez & 7u) << 2};
+		const unsigned XY[4] = {X[0] | Y[0], X[0] | Y[1], X[1] | Y[0], X[1] | Y[1]};
+		const unsigned lxy[4] = {lx[0] | ly[0], lx[0] | ly[1], lx[1] | ly[0], lx[1] | ly[1]};
+		const char* tab = reinterpret_cast<const char*>(s_b4p);
 #pragma unroll
 		for (int c = 0; c < 8; ++c) {
-			const int di = c >> 2, dj = (c >> 1) & 1, dk = c & 1;
-			T.o[c] = s_b4[sx[di] + sy[dj] + sz[dk]] + (lx[di] | ly[dj] | lz[dk]);
+			const int dij = c >> 1, dk = c & 1;
+			T.o[c] = *reinterpret_cast<const unsigned*>(tab + (XY[dij] | Z[dk])) + lxy[dij] + lz[dk];
 		}
 	} else {
 		int any = 0;
@@ -195,15 +208,32 @@ __device__ __forceinline__ f3 tri_v_t(const float* __restrict__ u, const Taps& T
 	return r;
 }
 
-__device__ __forceinline__ f3 tri_v_b(const v4i& ru, const TapsB& T) {
-	f3 c[8];
-#pragma unroll
-	for (int q = 0; q < 8; ++q) c[q] = ldv(ru, T.o[q]);
-	f3 r;
-	r.x = tri_c8(c[0].x, c[1].x, c[2].x, c[3].x, c[4].x, c[5].x, c[6].x, c[7].x, T);
-	r.y = tri_c8(c[0].y, c[1].y, c[2].y, c[3].y, c[4].y, c[5].y, c[6].y, c[7].y, T);
-	r.z = tri_c8(c[0].z, c[1].z, c[2].z, c[3].z, c[4].z, c[5].z, c[6].z, c[7].z, T);
+// One Vec3f lerp of the device branch, fmaf(w, b - a, a) per component (Stencils.hpp:131-135), written on the (x, y) pair and on z: a
+// 12-byte load lands x and y in an aligned register pair, so the pair goes through v_pk_add_f32 / v_pk_fma_f32 as it is (the same IEEE
+// operations per component). Left to the SLP vectoriser the seven lerps of a sample paired components of DIFFERENT taps and paid 16
+// register moves per sample for it.
+struct V3 {
+	v2f32 xy;
+	float z;
+};
+__device__ __forceinline__ V3 lerp_v3(const V3& a, const V3& b, float w) {
+	V3 r;
+	r.xy = __builtin_elementwise_fma(v2f32{w, w}, b.xy - a.xy, a.xy);
+	r.z = __fmaf_rn(w, b.z - a.z, a.z);
 	return r;
+}
+__device__ __forceinline__ f3 tri_v_b(const v4i& ru, const TapsB& T) {
+	V3 c[8];
+#pragma unroll
+	for (int q = 0; q < 8; ++q) {
+		const v3f v = hns_buffer_load_v3f32(ru, (int)(T.o[q] + (T.o[q] << 1)), 0, 0);
+		c[q].xy = v2f32{v.x, v.y};
+		c[q].z = v.z;
+	}
+	const V3 z0 = lerp_v3(c[0], c[1], T.fz), z1 = lerp_v3(c[2], c[3], T.fz), z2 = lerp_v3(c[4], c[5], T.fz), z3 = lerp_v3(c[6], c[7], T.fz);
+	const V3 y0 = lerp_v3(z0, z1, T.fy), y1 = lerp_v3(z2, z3, T.fy);
+	const V3 r = lerp_v3(y0, y1, T.fx);
+	return f3{r.xy.x, r.xy.y, r.z};
 }
 
 __device__ __forceinline__ float tri_f_b(const v4i& rf, const TapsB& T) {
@@ -275,7 +305,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 	__shared__ int s_nbr[27];
 	__shared__ int s_base[27];
 	__shared__ unsigned s_b4[27];
-	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4);
+	__shared__ unsigned s_b4p[kPadTab];
+	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4, s_b4p);
 	const int n = threadIdx.x;
 	const int idx = L.leaf * 512 + n;
 	const float px = (float)(L.org.x + (n >> 6)), py = (float)(L.org.y + ((n >> 3) & 7)), pz = (float)(L.org.z + (n & 7));
@@ -293,7 +324,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 	f3 vf = {0.0f, 0.0f, 0.0f}, vb = {0.0f, 0.0f, 0.0f};
 #pragma unroll 1
 	for (int pass = 0; pass < 2; ++pass) {
-		const TapsB T = make_taps_b(g, s_nbr, s_b4, L.org, sx, sy, sz);
+		const TapsB T = make_taps_b(g, s_nbr, s_b4p, L.org, sx, sy, sz);
 		const f3 v = tri_v_b(ru, T);
 		if (pass == 0) {
 			vf = v;
@@ -410,7 +441,8 @@ __global__ __launch_bounds__(512) void k_advect_scalar_n(const GridDev g, const 
 	__shared__ int s_nbr[27];
 	__shared__ int s_base[27];
 	__shared__ unsigned s_b4[27];
-	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4);
+	__shared__ unsigned s_b4p[kPadTab];
+	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4, s_b4p);
 	const int n = threadIdx.x;
 	const int idx = L.leaf * 512 + n;
 	const float px = (float)(L.org.x + (n >> 6)), py = (float)(L.org.y + ((n >> 3) & 7)), pz = (float)(L.org.z + (n & 7));
@@ -426,7 +458,7 @@ __global__ __launch_bounds__(512) void k_advect_scalar_n(const GridDev g, const 
 	float phiForward = 0.0f, phiBackward = 0.0f;
 #pragma unroll 1
 	for (int pass = 0; pass < 2; ++pass) {
-		const TapsB T = make_taps_b(g, s_nbr, s_b4, L.org, sx, sy, sz);
+		const TapsB T = make_taps_b(g, s_nbr, s_b4p, L.org, sx, sy, sz);
 		const float phi = tri_f_b(rf, T);
 		if (pass == 0) {
 			phiForward = phi;
@@ -538,7 +570,8 @@ __global__ __launch_bounds__(512) void k_advect_scalars_n(const GridDev g, const
 	__shared__ int s_nbr[27];
 	__shared__ int s_base[27];
 	__shared__ unsigned s_b4[27];
-	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4);
+	__shared__ unsigned s_b4p[kPadTab];
+	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4, s_b4p);
 	const int n = threadIdx.x;
 	const int idx = L.leaf * 512 + n;
 	const float px = (float)(L.org.x + (n >> 6)), py = (float)(L.org.y + ((n >> 3) & 7)), pz = (float)(L.org.z + (n & 7));
@@ -552,7 +585,7 @@ __global__ __launch_bounds__(512) void k_advect_scalars_n(const GridDev g, const
 	float bw[8], fw[8];
 	const int perm[8] = {0, 4, 2, 6, 1, 5, 3, 7};  // setupInterpolation's order 000,100,010,110,001,... of (x,y,z) (Kernel.cu:163-196)
 	{
-		const TapsB T = make_taps_b(g, s_nbr, s_b4, L.org, bx, by, bz);
+		const TapsB T = make_taps_b(g, s_nbr, s_b4p, L.org, bx, by, bz);
 		const float tx = T.fx, ty = T.fy, tz = T.fz, itx = 1.0f - tx, ity = 1.0f - ty, itz = 1.0f - tz;
 		const float w00 = itx * ity, w10 = tx * ity, w01 = itx * ty, w11 = tx * ty;
 		bw[0] = w00 * itz, bw[1] = w10 * itz, bw[2] = w01 * itz, bw[3] = w11 * itz, bw[4] = w00 * tz, bw[5] = w10 * tz, bw[6] = w01 * tz, bw[7] = w11 * tz;
@@ -568,7 +601,7 @@ __global__ __launch_bounds__(512) void k_advect_scalars_n(const GridDev g, const
 		vf.z = vf.z + bw[q] * v.z;
 	}
 	{
-		const TapsB T = make_taps_b(g, s_nbr, s_b4, L.org, bx + scaled_dt * vf.x, by + scaled_dt * vf.y, bz + scaled_dt * vf.z);
+		const TapsB T = make_taps_b(g, s_nbr, s_b4p, L.org, bx + scaled_dt * vf.x, by + scaled_dt * vf.y, bz + scaled_dt * vf.z);
 		const float tx = T.fx, ty = T.fy, tz = T.fz, itx = 1.0f - tx, ity = 1.0f - ty, itz = 1.0f - tz;
 		const float w00 = itx * ity, w10 = tx * ity, w01 = itx * ty, w11 = tx * ty;
 		fw[0] = w00 * itz, fw[1] = w10 * itz, fw[2] = w01 * itz, fw[3] = w11 * itz, fw[4] = w00 * tz, fw[5] = w10 * tz, fw[6] = w01 * tz, fw[7] = w11 * tz;

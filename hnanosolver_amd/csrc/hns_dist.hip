@@ -749,6 +749,8 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 		// the owned range deals the boundary leaves out to all eight XCDs first (the mirroring pressure loop sweeps this range: its
 		// boundary waves poll, store twice and signal, and as the head of XCD 0's chunk they made that XCD the last to finish)
 		if (i == 2 && (sweeps_per_exchange == 1 || blocked_mirror(d)) && options().dist_spread.load() != 0) (*gs[i])->sched_prefix = (uint64_t)d->nB;
+		// the chained blocked sweep (hns_sorblock.hip) must know which leaves of the owned range are boundary leaves whatever the launch order is
+		if (i == 2) (*gs[i])->chain_boundary = (uint64_t)d->nB;
 		if ((rc = hns_grid_set_active_range(*gs[i], first[i], count[i])) != HNS_OK) return bail(rc);
 		if ((rc = hns_grid_set_outside_element(*gs[i], outside)) != HNS_OK) return bail(rc);
 	}

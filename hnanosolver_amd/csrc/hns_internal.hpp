@@ -132,6 +132,7 @@ struct hns_grid {
 	void* d_sched = nullptr;
 	void* d_blk = nullptr;
 	void* d_pairs = nullptr;    // launch-ordered wave records {leaf0, nbr27, leaf1 or -1, nbr27} (56 ints): z-adjacent pairs and lone leaves
+	uint64_t chain_boundary = 0;  // leaves at the head of the active range that are a multi-GPU rank's BOUNDARY leaves (hns_dist: the range its chained sweeps run over); correctness, not speed
 	uint64_t sched_prefix = 0;    // leaves at the head of the active range that the launch order deals out to all XCDs first (hns_dist: boundary leaves)
 	void* d_sched_mem = nullptr;  // storage of d_sched (d_sched itself is null under the linear schedule)
 	void* d_scratch = nullptr;    // schedule-build scratch

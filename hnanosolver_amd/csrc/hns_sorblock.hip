@@ -729,9 +729,9 @@ int hns_grid_build_blocks(hns_grid* g) {
 	int* total = leaders + n;
 	GridDev gd = g->dev();
 	const int first = (int)g->first_active, count = (int)g->n_active;
-	// (sched_prefix: the leading leaves of the range that are a multi-GPU rank's boundary leaves -- hns_dist.hip sets it on the range its
-	// chained sweeps run over; 0 everywhere else)
-	const int n_boundary = (int)std::min<uint64_t>(g->sched_prefix, g->n_active) ? first + (int)std::min<uint64_t>(g->sched_prefix, g->n_active) : 0;
+	// (chain_boundary: the leading leaves of the range that are a multi-GPU rank's boundary leaves -- hns_dist.hip sets it on the range its
+	// chained sweeps run over; 0 everywhere else. sched_prefix != 0: deal the blocks they lead out to all XCDs first, option dist_spread)
+	const int n_boundary = g->chain_boundary ? first + (int)std::min<uint64_t>(g->chain_boundary, g->n_active) : 0;
 	hipStream_t st = nullptr;
 	HNS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 	struct Drop {
@@ -748,7 +748,7 @@ int hns_grid_build_blocks(hns_grid* g) {
 	if (int rc = hns_arena_get(sizeof(int) * 65 * (size_t)nb, g->device, &g->d_sb_tab, &g->sb_bytes)) return rc;
 	HNS_HIP(hipMemsetAsync((int*)g->d_sb_tab + (size_t)nb * 64, 0, sizeof(int) * (size_t)nb, st));
 	// the blocks led by a boundary leaf are dealt out to all XCDs first (as hns_grid_upload_schedule does with the boundary leaves themselves)
-	const int pre = n_boundary ? (std::min(tot[1], nb) & ~7) : 0;
+	const int pre = (n_boundary && g->sched_prefix) ? (std::min(tot[1], nb) & ~7) : 0;
 	hipLaunchKernelGGL(k_sb_table, dim3((unsigned)(((int64_t)nb * 64 + 255) / 256)), dim3(256), 0, st, gd, (const int*)leaders, nb, seg, pre, first, count, n_boundary, (int*)g->d_sb_tab);
 	HNS_HIP(hipStreamSynchronize(st));
 	g->n_sb = (uint64_t)nb;

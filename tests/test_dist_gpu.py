@@ -115,6 +115,18 @@ def test_exchanged_ranks_with_and_without_blocked_range_sweeps(name, world, k, b
         H.set_option("dist_block", None)
 
 
+def test_chained_blocked_sweep_does_not_depend_on_the_launch_order_option():
+    """dist_spread = 0 (boundary leaves / blocks not dealt out to all XCDs first) changes the launch order only: which blocks wait
+    for the peers and mirror their boundary leaves is a property of the plan."""
+    import hnanosolver_amd as H
+
+    H.set_option("dist_spread", "0")
+    try:
+        _local_ranks_match_single_grid("dense64", 3, 2, 6)
+    finally:
+        H.set_option("dist_spread", None)
+
+
 @pytest.mark.parametrize("name,world,iters", [("dense64", 2, 7), ("dense64", 5, 6), ("plume16", 3, 7), ("scattered_big", 4, 9), ("scattered_big", 2, 2)])
 def test_chained_ranks_two_iterations_per_launch(name, world, iters):
     """Round 4: sweeps_per_exchange = 2 over the local / ipc transport with more than 600 leaves per rank = the chained substep whose
