@@ -40,6 +40,7 @@ struct Options {
 	std::atomic<int> dist_wire_us{0};          // "dist_wire_us": loopback transport only, emulated time on the wire per exchange
 	std::atomic<int> dist_mirror{1};           // "dist_mirror": multi-GPU pressure loop with sweeps_per_exchange = 1 over the ipc / local transport delivers its halo inside the sweep kernel
 	std::atomic<int> dist_chain{1};            // "dist_chain": with dist_mirror, EVERY kernel of the substep of such a rank is one launch that delivers its own halo (read when the ranks connect)
+	std::atomic<int> divergence_form{0};       // "divergence": 0 auto (by size) | 1 row | 2 coalesced (own leaf fetched in memory order, handed to the row owners through LDS)
 	std::atomic<int> dist_block{1};            // "dist_block": a rank with sweeps_per_exchange >= 2 sweeps its launch ranges two iterations per launch (hns_sorblock.hip over a range)
 	std::atomic<int> dist_spread{1};           // "dist_spread": the owned launch range of a sweeps_per_exchange = 1 rank deals its boundary leaves out to all XCDs (read at hns_dist_create)
 	std::atomic<int> sor_lds_pad{0};           // "sor_lds_pad": extra dynamic LDS bytes per wave of the pair kernel (an occupancy experiment: fewer waves in flight per XCD)

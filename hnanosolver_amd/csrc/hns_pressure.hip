@@ -863,16 +863,39 @@ __device__ __forceinline__ void face_duty(int l, int& slot, int& src, int& R) {
 }
 
 // divergence (reference Kernel.cu:499-519): (xp - xm + yp - ym + zp - zm) * inv_dx with xp = (c.x + u(+x).x) * 0.5f, ...
-template <class M>
+// COAL (round 4; grids of 16k leaves and more, hns_dev_divergence): the leaf's own 6 KB are fetched in memory order -- lane l takes the
+// 16-byte pieces l, 64 + l, ... so that an instruction touches 8 whole cache lines instead of a piece of each of the 48 -- and handed to
+// the row owners through LDS (the wave's own 6 KB; one wave per workgroup, so only the wave's LDS order matters). Round 3 measured it
+// (64.1 -> 62.9 us at 256^3, 133 -> 123 on the 66k-leaf plume, but 11.8 -> 13.4 at 128^3: 12.6 KB of LDS per wave halve the waves in
+// flight where the grid is small) and dropped it; it is now switched by size instead.
+template <class M, bool COAL = false>
 __global__ __launch_bounds__(64) void k_divergence_row(const GridDev g, const float* __restrict__ u, float* __restrict__ div, const float inv_dx, const M m) {
 	__shared__ __attribute__((aligned(16))) RowTile TX, TY;  // ux rows (x faces), uy rows (y faces)
+	__shared__ __attribute__((aligned(16))) float4 s_own[COAL ? 384 : 1];
 	const int l = threadIdx.x, x = l >> 3, y = l & 7;
 	const int* __restrict__ rec = g.blk + (size_t)launch_pos(g, blockIdx.x) * 28;
 	const int leaf = __builtin_amdgcn_readfirstlane(rec[0]);
 	chain_begin(m, leaf);
 	const int n_zm = __builtin_amdgcn_readfirstlane(rec[1 + 12]), n_zp = __builtin_amdgcn_readfirstlane(rec[1 + 14]);
 	float r[24];
-	glb_row3(u, leaf, l, r);
+	if constexpr (COAL) {
+		const float4* q = reinterpret_cast<const float4*>(u + (size_t)leaf * 1536);
+		float4 v[6];
+#pragma unroll
+		for (int k = 0; k < 6; ++k) v[k] = q[k * 64 + l];
+#pragma unroll
+		for (int k = 0; k < 6; ++k) s_own[k * 64 + l] = v[k];
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+		for (int k = 0; k < 6; ++k) {
+			const float4 w = s_own[l * 6 + k];
+			r[4 * k] = w.x, r[4 * k + 1] = w.y, r[4 * k + 2] = w.z, r[4 * k + 3] = w.w;
+		}
+	} else {
+		glb_row3(u, leaf, l, r);
+	}
 	const float uz_m = n_zm < 0 ? 0.0f : u[((size_t)n_zm * 512 + l * 8 + 7) * 3 + 2];
 	const float uz_p = n_zp < 0 ? 0.0f : u[((size_t)n_zp * 512 + l * 8) * 3 + 2];
 	int slot, src, RF;
@@ -934,7 +957,12 @@ int hns_dev_divergence(hns_grid* g, const float* vel3, float* div, float inv_dx,
 		// backwards: advect_vector has just written the velocity front to back, so its tail is what the Infinity Cache holds
 		// (256^3: 74 -> 66 us). Option "rev" = 0 walks every kernel forwards.
 		gd.rev = options().rev.load();
-		hipLaunchKernelGGL(k_divergence_row<NoMirror>, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, vel3, div, inv_dx, NoMirror{});
+		// option "divergence" = auto | row | coalesced: by size (k_divergence_row's COAL form from 16k leaves; loses below, see the kernel)
+		const int form = options().divergence_form.load();
+		if (form == 2 || (form == 0 && g->n_active >= 16384))
+			hipLaunchKernelGGL((k_divergence_row<NoMirror, true>), dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, vel3, div, inv_dx, NoMirror{});
+		else
+			hipLaunchKernelGGL((k_divergence_row<NoMirror, false>), dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, vel3, div, inv_dx, NoMirror{});
 	}
 	return launch_status("hns_dev_divergence");
 }

@@ -139,6 +139,7 @@ const char* const kWordsSchedule[] = {"auto", "linear", "chunk", nullptr};
 const char* const kWordsBool[] = {"0", "1", nullptr};
 const char* const kWordsMirror[] = {"0", "1", "guarded", nullptr};
 const char* const kWordsAuto01[] = {"auto", "0", "1", nullptr};
+const char* const kWordsDivergence[] = {"auto", "row", "coalesced", nullptr};
 const OptionDesc kOptions[] = {
     {"rbgs", &Options::rbgs, kWordsRbgs},
     {"advect", &Options::advect_generic, kWordsAdvect},
@@ -158,6 +159,7 @@ const OptionDesc kOptions[] = {
     {"schedule_segment", &Options::schedule_segment, nullptr},
     {"dist_wire_us", &Options::dist_wire_us, nullptr},
     {"dist_mirror", &Options::dist_mirror, kWordsMirror},
+    {"divergence", &Options::divergence_form, kWordsDivergence},
     {"dist_spread", &Options::dist_spread, kWordsBool},
     {"dist_block", &Options::dist_block, kWordsBool},
     {"dist_chain", &Options::dist_chain, kWordsBool},

@@ -82,6 +82,8 @@ int hns_trim_memory(void);
  *   "dist_wire_us"  N: the loopback transport of hns_dist holds every exchange N microseconds (emulated wire time)
  *   "dist_chain"    1 | 0: with dist_mirror, every kernel of the substep of such a rank delivers its own halo (no exchanges at all
  *                   after the first substep); 0 = only the SOR sweeps do (read when the ranks connect; all ranks must agree)
+ *   "divergence"    auto | row | coalesced: the divergence kernel fetches its own leaf row by row, or in memory order with a hand-over through
+ *                   LDS (auto: the latter from 16,384 leaves)
  *   "dist_block"    1 | 0: a rank with sweeps_per_exchange >= 2 sweeps its boundary and interior launch ranges with the temporally
  *                   blocked SOR form, two iterations per launch, ghost leaves as tile sources (0 = one iteration per launch)
  *   "dist_spread"   1 | 0: hns_dist_create with sweeps_per_exchange = 1 deals the boundary leaves of the owned launch range out

@@ -58,6 +58,7 @@ VARIANTS = {
     "sor_one_direction": {"alternate": "0", "rbgs": "pair"},
     "all_kernels_forwards": {"rev": "0"},
     "divergence_block": {"stencil": "block"},
+    "divergence_own_leaf_in_memory_order": {"divergence": "coalesced"},  # the default from 16,384 leaves (round 4)
     "cook_unpipelined_uncached": {"cook_pipeline": "0", "cook_cache": "0"},
 }
 ALL_OPTIONS = sorted({k for v in VARIANTS.values() for k in v})
