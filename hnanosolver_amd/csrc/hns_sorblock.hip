@@ -547,6 +547,14 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 	// LDS entries (every thread wrote its last sweep there), the leaf ids out of the record's LDS copy.
 	__syncthreads();
 	{
+		int mirror_id[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // chained rank: the block's leaves this launch stores, as scalars (-1: not stored)
+		if constexpr (!std::is_same<M, NoMirror>::value) {
+			if (meta & 2) {
+#pragma unroll
+				for (int c = 0; c < 8; ++c)
+					mirror_id[c] = (meta >> (8 + c)) & 1 ? __builtin_amdgcn_readfirstlane(s_rec[((1 + (c >> 2)) * C + 1 + ((c >> 1) & 1)) * C + 1 + (c & 1)]) : -1;
+			}
+		}
 		const float2* A = reinterpret_cast<const float2*>(L.a);
 		constexpr int PSTR = SbLdsDense<LB, K>::PSTR * 2, ROFF = SbLdsDense<LB, K>::ROFF * 2;  // in float2: parity stride, offset of a red array
 #pragma unroll
@@ -564,12 +572,15 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 			sb_store4(v, ro, (int)((unsigned)id * 2048u + (unsigned)((((xx & 7) << 3) | (yy & 7)) * 32 + jz * 16)), 0, 0);
 			if constexpr (!std::is_same<M, NoMirror>::value) {
 				// a chained multi-GPU rank: what the peers read of this block's boundary leaves (the plan's reach-2K region of p) goes into
-				// their ghost copies as well, write-through. The walk over the block's eight leaves and their table entries is wave-uniform.
+				// their ghost copies as well, write-through. Piece n of every thread lies in the block's x half n (NT = 512 pieces per half), so the
+				// walk covers that half's four leaves; it and the walk over a leaf's table entries are wave-uniform (leaf ids in scalar registers).
+				static_assert(G::NT == 512, "piece n of a thread lies in the x half n of the block");
 				if (meta & 2) {
-#pragma unroll 1
-					for (int c = 0; c < 8; ++c) {
-						const int lc = __builtin_amdgcn_readfirstlane(s_rec[((1 + (c >> 2)) * C + 1 + ((c >> 1) & 1)) * C + 1 + (c & 1)]);
-						if (!((meta >> (8 + c)) & 1) || lc < 0 || lc >= m.n_boundary) continue;
+#pragma unroll
+					for (int cc = 0; cc < 4; ++cc) {
+						const int c = 4 * n + cc;
+						const int lc = mirror_id[c];
+						if (lc < 0 || lc >= m.n_boundary) continue;
 						chain_store_piece(m, lc, c == cell, ((xx & 7) << 3) | (yy & 7), jz, v);
 					}
 				}
@@ -797,8 +808,17 @@ int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const fl
 	// (16^3 blocks only, and only launches that need a second round of workgroups -- 512 are resident at once; at 512 blocks and below the
 	// wait is pure loss: 128^3 6.58 -> 7.26 us per iteration, while 600 blocks gain 2.5 % and 1,000 blocks 4 %. Option
 	// "sor_block_stagger" = 0 switches it off, N sets the wait)
+	// (the records' address and count as ONE snapshot: another host thread sharing the grid may be rebuilding them -- an option changed --,
+	// and a superseded table stays valid until the grid goes, but its count must be its own)
+	const int* sb_tab;
+	uint64_t n_sb;
+	{
+		std::lock_guard<std::mutex> lock(g->build_mutex);
+		sb_tab = (const int*)g->d_sb_tab, n_sb = g->n_sb;
+	}
+	if (lb == 2 && (!sb_tab || !n_sb)) return fail(HNS_ERR_RUNTIME, "hns_rbgs_block_launch: no block records");
 	const int so = options().sor_block_stagger.load();
-	const int stag = (lb == 2 && g->n_sb >= 576) ? so : 0;
+	const int stag = (lb == 2 && n_sb >= 576) ? so : 0;
 	const bool lean = hns_rbgs_block_lean(g, lb, k);
 #define SB_LAUNCH(LB_, K_, recs, nblk)                                                                                                            \
 	do {                                                                                                                                           \
@@ -812,10 +832,10 @@ int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const fl
 	else if (lb == 2 && k == 2 && lean) {
 		const int sl = options().sor_block_lean_stagger.load();
 		if (src_is_zero)
-			hipLaunchKernelGGL((k_rbgs_block<2, 2, true, true>), dim3((unsigned)g->n_sb), dim3(SbGeo<2, 2>::NT), 0, st, (const int*)g->d_sb_tab, (const int*)g->d_sb_tab + (size_t)g->n_sb * 64, div, src, dst, bytes, dx2, omega, sl);
+			hipLaunchKernelGGL((k_rbgs_block<2, 2, true, true>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, sl);
 		else
-			hipLaunchKernelGGL((k_rbgs_block<2, 2, false, true>), dim3((unsigned)g->n_sb), dim3(SbGeo<2, 2>::NT), 0, st, (const int*)g->d_sb_tab, (const int*)g->d_sb_tab + (size_t)g->n_sb * 64, div, src, dst, bytes, dx2, omega, sl);
-	} else if (lb == 2 && k == 2) SB_LAUNCH(2, 2, g->d_sb_tab, g->n_sb);
+			hipLaunchKernelGGL((k_rbgs_block<2, 2, false, true>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, sl);
+	} else if (lb == 2 && k == 2) SB_LAUNCH(2, 2, sb_tab, n_sb);
 	else return fail(HNS_ERR_INVALID_ARGUMENT, "hns_rbgs_block_launch: unsupported block shape");
 #undef SB_LAUNCH
 	return HNS_OK;
@@ -828,12 +848,18 @@ extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_block_mirror_launc
 	int k = 0;
 	if (hns_rbgs_block_shape(g, &k) != 2 || !hns_rbgs_block_lean(g, 2, 2)) return fail(HNS_ERR_RUNTIME, "hns_rbgs_block_mirror_launch: this launch range is not swept in 16^3 blocks");
 	const unsigned bytes = (unsigned)((size_t)g->topo.n_leaves * 2048u);
-	const int* tab = (const int*)g->d_sb_tab;
+	const int* tab;
+	uint64_t n_sb;
+	{
+		std::lock_guard<std::mutex> lock(g->build_mutex);
+		tab = (const int*)g->d_sb_tab, n_sb = g->n_sb;
+	}
+	if (!tab || !n_sb) return fail(HNS_ERR_RUNTIME, "hns_rbgs_block_mirror_launch: no block records");
 	const float dx2 = dx * dx;  // Kernel.cu:608
 	if (src_is_zero)
-		hipLaunchKernelGGL((k_rbgs_block<2, 2, true, true, PhaseMirror>), dim3((unsigned)g->n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)g->n_sb * 64, div, src, dst, bytes, dx2, omega, 0, *m);
+		hipLaunchKernelGGL((k_rbgs_block<2, 2, true, true, PhaseMirror>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, 0, *m);
 	else
-		hipLaunchKernelGGL((k_rbgs_block<2, 2, false, true, PhaseMirror>), dim3((unsigned)g->n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)g->n_sb * 64, div, src, dst, bytes, dx2, omega, 0, *m);
+		hipLaunchKernelGGL((k_rbgs_block<2, 2, false, true, PhaseMirror>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, 0, *m);
 	return HNS_OK;
 }
 

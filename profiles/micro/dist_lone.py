@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One rank of a decomposition alone on the device (loopback transport), N substeps: for rocprofv3 --kernel-trace.
-argv: config world rank sweeps_per_exchange [--partition]"""
+argv: config world rank sweeps_per_exchange [--partition] [option=value ...]"""
 import os
 import sys
 import time
@@ -10,7 +10,12 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from hnanosolver_amd import device as D, dist as HD, fields  # noqa: E402
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+import hnanosolver_amd as H  # noqa: E402
+
+for a in sys.argv[1:]:  # name=value: library options (hns_set_option) for this run
+    if "=" in a and not a.startswith("--"):
+        H.set_option(*a.split("=", 1))
+args = [a for a in sys.argv[1:] if not a.startswith("--") and "=" not in a]
 config, world, rank, k = args[0], int(args[1]), int(args[2]), int(args[3])
 partition = "--partition" in sys.argv
 origins, R = fields.config_leaves(config)
