@@ -109,3 +109,27 @@ def test_config0_the_64_cube_smoke_plume_against_the_reference_itself():
         state.append({"vel": vel, **cur})
     for k in state[0]:
         same(state[1][k], state[0][k], k)
+
+
+@pytest.mark.parametrize("config,iterations", [("128", 50), ("plume", 50), ("256", 6), ("plume1024", 4)])
+def test_configs_1_to_4_whole_cook_against_the_reference_itself(config, iterations):
+    """BASELINE.json configs[1] (128^3 dense, 50 iterations) and configs[3] (the sparse rising plume, ~3.9k leaves): one whole
+    Compute_Sim cook through the drop-in API on the GPU against the reference's own kernels (host build, one thread), bit for bit
+    on every field. configs[2] (256^3) and configs[4] (the 1024^3-extent plume, 65,944 leaves, on one GPU) likewise at full SIZE
+    with fewer pressure iterations, so that the single-threaded reference finishes in tens of seconds (their 50-iteration runs
+    are held to the oracle in test_fullsize_gpu.py, and the oracle to the reference in test_ref_kernels.py)."""
+    from hip_kernels import HipKernels
+
+    from hnanosolver_amd import fields
+
+    o, R = fields.config_leaves(config)
+    f = fields.synthetic_fields(o, R)
+    names = ["density", "temperature", "fuel", "waste", "flame"]
+    state = []
+    for E in (RefKernelGrid(o), HipKernels(o, 1.0 / R)):
+        cur = {n: f[n].copy() for n in names}
+        vel = f["vel"].copy()
+        assert E.compute_sim(vel, cur, iterations, 1.0 / 24.0, 1.0 / R, api.CombustionParams(), False) == 0
+        state.append({"vel": vel, **cur})
+    for k in state[0]:
+        same(state[1][k], state[0][k], k)
