@@ -72,10 +72,9 @@ __device__ __forceinline__ void ld_zpair(const v4i& r, unsigned lo, unsigned hi,
 // (ax, ay, az) in 0..2 -- its byte index ax<<6 | ay<<4 | az<<2 is shifts and ORs of the tap's coordinates, where 9*ax + 3*ay + az cost
 // four quarter-rate multiplies per trilinear sample (make_taps_b).
 constexpr int kPadTab = 48;
-__device__ __forceinline__ LeafCtx stage_leaf_base(const GridDev& g, int* s_nbr, int* s_base, int block, unsigned* s_b4 = nullptr, unsigned* s_b4p = nullptr) {
+__device__ __forceinline__ LeafCtx stage_leaf_base(const GridDev& g, int* s_nbr, int* s_base, int block, unsigned* s_b4 = nullptr, unsigned* s_b4p = nullptr, int leaf = -1) {
 	LeafCtx c;
-	const int pos = (int)launch_pos(g, (unsigned)block);
-	c.leaf = g.sched ? g.sched[pos] : g.first + pos;
+	c.leaf = leaf >= 0 ? leaf : launch_leaf(g, (unsigned)block);
 	c.org = g.origins[c.leaf];
 	if (threadIdx.x < 27) {
 		const int nb = g.nbr27[c.leaf * 27 + threadIdx.x];
@@ -306,15 +305,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 	__shared__ int s_base[27];
 	__shared__ unsigned s_b4[27];
 	__shared__ unsigned s_b4p[kPadTab];
-	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4, s_b4p);
+	// the voxel's own velocity needs the leaf number only: its load is issued before the neighbour table is fetched and staged (one memory
+	// round trip less in front of the first gathers; the kernel is bound by the length of that chain)
 	const int n = threadIdx.x;
-	const int idx = L.leaf * 512 + n;
-	const float px = (float)(L.org.x + (n >> 6)), py = (float)(L.org.y + ((n >> 3) & 7)), pz = (float)(L.org.z + (n & 7));
+	const int leaf = launch_leaf(g, blockIdx.x);
+	const int idx = leaf * 512 + n;
 	const v4i ru = field_rsrc(u, (unsigned)g.n_leaves * 6144u);
 	const unsigned own = (unsigned)idx << 2;
+	const f3 vo = ldv(ru, own);
+	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4, s_b4p, leaf);
+	const float px = (float)(L.org.x + (n >> 6)), py = (float)(L.org.y + ((n >> 3) & 7)), pz = (float)(L.org.z + (n & 7));
 
 	__shared__ float s_tile[kTile * 3];
-	const f3 vo = ldv(ru, own);
 	s_tile[3 * n] = vo.x, s_tile[3 * n + 1] = vo.y, s_tile[3 * n + 2] = vo.z;
 	if (n < 384) {
 		const f3 h = ldv(ru, halo_off(s_b4, n));
@@ -571,15 +573,16 @@ __global__ __launch_bounds__(512) void k_advect_scalars_n(const GridDev g, const
 	__shared__ int s_base[27];
 	__shared__ unsigned s_b4[27];
 	__shared__ unsigned s_b4p[kPadTab];
-	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4, s_b4p);
 	const int n = threadIdx.x;
-	const int idx = L.leaf * 512 + n;
-	const float px = (float)(L.org.x + (n >> 6)), py = (float)(L.org.y + ((n >> 3) & 7)), pz = (float)(L.org.z + (n & 7));
+	const int leaf = launch_leaf(g, blockIdx.x);
+	const int idx = leaf * 512 + n;
 	const unsigned bytes1 = (unsigned)g.n_leaves * 2048u;
 	const v4i ru = field_rsrc(u, bytes1 * 3u);
 	const unsigned own = (unsigned)idx << 2, oob4 = (unsigned)g.oob << 2;
+	const f3 vc = ldv(ru, own);  // (issued before the neighbour table is staged: see k_advect_vector_n)
+	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4, s_b4p, leaf);
+	const float px = (float)(L.org.x + (n >> 6)), py = (float)(L.org.y + ((n >> 3) & 7)), pz = (float)(L.org.z + (n & 7));
 
-	const f3 vc = ldv(ru, own);
 	const float bx = px - scaled_dt * vc.x, by = py - scaled_dt * vc.y, bz = pz - scaled_dt * vc.z;
 	unsigned bo[8], fo[8];
 	float bw[8], fw[8];

@@ -37,6 +37,7 @@ GridDev hns_grid::dev() const {
 	d.nbr27 = (const int*)d_nbr27;
 	d.hash = (const int*)d_hash;
 	d.sched = (const int*)d_sched;
+	d.sched_seg = sched_seg, d.sched_pre = sched_pre;
 	d.blk = (const int*)d_blk;
 	d.hash_mask = topo.hash_mask;
 	d.n_leaves = (int)topo.n_leaves;

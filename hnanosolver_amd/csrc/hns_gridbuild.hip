@@ -268,6 +268,7 @@ int hns_grid_upload_schedule(hns_grid* g) {
 	const int linear = seg;  // (name kept below: the kernels take the segment length)
 	const int pre = (int)std::min<uint64_t>(g->sched_prefix, (uint64_t)n) & ~7;
 	g->d_sched = (seg == 1 && pre == 0) ? nullptr : g->d_sched_mem;
+	g->sched_seg = seg, g->sched_pre = pre;
 	const int* nbr27 = (const int*)g->d_nbr27;
 	const int n_blocks = (n + 255) / 256;
 	int* partner = (int*)g->d_scratch;  // partner[n] | block_heads[n_blocks] | totals[2]

@@ -81,6 +81,8 @@ struct GridDev {
 	const int* nbr27;
 	const int* hash;
 	const int* sched;  // block -> leaf order (XCD-chunked), n_active entries
+	int sched_seg;     // >= 0: the order is the closed form sched_leaf(pos, n_active, sched_seg, sched_pre) (hns_device.hpp) -- one chunk per XCD (0) or
+	int sched_pre;     // plain order (1): a few scalar instructions instead of a dependent load at the head of every workgroup; -1: look `sched` up
 	const int* blk;    // per block, in launch order: {leaf, nbr27[27]} (28 ints)
 	uint32_t hash_mask;
 	int n_leaves;
@@ -99,9 +101,16 @@ __device__ __forceinline__ unsigned launch_pos(const GridDev& g, unsigned b) {
 	return (b >> 3) < rows ? (((rows - 1u - (b >> 3)) << 3) | (b & 7u)) : b;
 }
 
-// the leaf workgroup b works on (kernels with one workgroup per leaf)
+// the leaf workgroup b works on (kernels with one workgroup per leaf). One chunk per XCD (sched_seg 0: every grid up to 40k leaves) is
+// closed form -- block b = 8 i + x is leaf x * (n / 8) + min(x, n % 8) + i of the range -- and costs a few scalar instructions; reading
+// it from the table put a dependent load in front of everything a workgroup does (the advection kernels are bound by the length of
+// that chain: profiles/r04_advect_notes.txt).
 __device__ __forceinline__ int launch_leaf(const GridDev& g, unsigned b) {
 	const int pos = (int)launch_pos(g, b);
+	if (g.sched_seg == 0 && g.sched_pre == 0) {
+		const int base = g.n_active >> 3, rem = g.n_active & 7, x = pos & 7, i = pos >> 3;
+		return g.first + x * base + (x < rem ? x : rem) + i;
+	}
 	return g.sched ? g.sched[pos] : g.first + pos;
 }
 
@@ -133,6 +142,7 @@ struct hns_grid {
 	void* d_sched = nullptr;
 	void* d_blk = nullptr;
 	void* d_pairs = nullptr;    // launch-ordered wave records {leaf0, nbr27, leaf1 or -1, nbr27} (56 ints): z-adjacent pairs and lone leaves
+	int sched_seg = -1, sched_pre = 0;  // parameters of the current launch order (hns_grid_upload_schedule), for GridDev
 	uint64_t chain_boundary = 0;  // leaves at the head of the active range that are a multi-GPU rank's BOUNDARY leaves (hns_dist: the range its chained sweeps run over); correctness, not speed
 	uint64_t sched_prefix = 0;    // leaves at the head of the active range that the launch order deals out to all XCDs first (hns_dist: boundary leaves)
 	void* d_sched_mem = nullptr;  // storage of d_sched (d_sched itself is null under the linear schedule)
