@@ -43,12 +43,10 @@ struct Options {
 	std::atomic<int> divergence_form{0};       // "divergence": 0 auto (by size) | 1 row | 2 coalesced (own leaf fetched in memory order, handed to the row owners through LDS)
 	std::atomic<int> dist_block{1};            // "dist_block": a rank with sweeps_per_exchange >= 2 sweeps its launch ranges two iterations per launch (hns_sorblock.hip over a range)
 	std::atomic<int> dist_spread{1};           // "dist_spread": the owned launch range of a sweeps_per_exchange = 1 rank deals its boundary leaves out to all XCDs (read at hns_dist_create)
-	std::atomic<int> sor_lds_pad{0};           // "sor_lds_pad": extra dynamic LDS bytes per wave of the pair kernel (an occupancy experiment: fewer waves in flight per XCD)
 	std::atomic<int> sor_block_lb{0};          // "sor_block_lb": temporally blocked SOR (hns_sorblock.hip), block edge in leaves: 0 = by size, 1, 2
 	std::atomic<int> sor_block_k{0};           // "sor_block_k": ... iterations per launch: 0 = by shape, 2, 4 (4: one-leaf blocks only)
 	std::atomic<int> sor_block_stagger{8};     // "sor_block_stagger": ... launch-start stagger of the two workgroups of a CU, x 1,024 cycles (0 = off; hns_sorblock.hip)
 	std::atomic<int> sor_block_lean{0};        // "sor_block_lean" = auto | 0 | 1 (stored 0 / 1 / 2): ... its lean form (row state in LDS, three workgroups per CU); auto = by size
-	std::atomic<int> sor_block_lean_stagger{0};  // "sor_block_lean_stagger": ... launch-start stagger of the lean form's three workgroups per CU, x 1,024 cycles
 	std::atomic<int> sor_block_seg{0};         // "sor_block_seg": ... blocks per XCD segment of its launch order (0: one chunk per XCD; read when the block table is built)
 };
 Options& options();

@@ -1049,7 +1049,7 @@ static int launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* di
 		hipLaunchKernelGGL(k_rbgs_pair<true>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, (const int*)nullptr, div, src, dst, dx2, omega, last);
 	} else {
 		// one launch: the record list holds the z-adjacent pairs and, as {leaf, nbr27, -1, ...}, the leaves that found no partner
-		hipLaunchKernelGGL(k_rbgs_pair<false>, dim3((unsigned)g->n_pairs), dim3(64), (size_t)options().sor_lds_pad.load(), st, (const int*)g->d_pairs, (const int*)nullptr, div, src, dst, dx2, omega, last);
+		hipLaunchKernelGGL(k_rbgs_pair<false>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, (const int*)nullptr, div, src, dst, dx2, omega, last);
 	}
 	return HNS_OK;
 }

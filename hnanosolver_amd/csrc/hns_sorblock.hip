@@ -830,7 +830,7 @@ int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const fl
 	if (lb == 1 && k == 2) SB_LAUNCH(1, 2, g->d_blk, g->n_active);
 	else if (lb == 1 && k == 4) SB_LAUNCH(1, 4, g->d_blk, g->n_active);
 	else if (lb == 2 && k == 2 && lean) {
-		const int sl = options().sor_block_lean_stagger.load();
+		const int sl = 0;  // (a launch-start stagger buys the lean form nothing: three workgroups per CU drift apart by themselves; option removed in round 4)
 		if (src_is_zero)
 			hipLaunchKernelGGL((k_rbgs_block<2, 2, true, true>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, sl);
 		else

@@ -153,9 +153,7 @@ const OptionDesc kOptions[] = {
     {"sor_block_k", &Options::sor_block_k, nullptr},
     {"sor_block_seg", &Options::sor_block_seg, nullptr},
     {"sor_block_lean", &Options::sor_block_lean, kWordsAuto01},
-    {"sor_block_lean_stagger", &Options::sor_block_lean_stagger, nullptr},
     {"sor_block_stagger", &Options::sor_block_stagger, nullptr},
-    {"sor_lds_pad", &Options::sor_lds_pad, nullptr},
     {"schedule_segment", &Options::schedule_segment, nullptr},
     {"dist_wire_us", &Options::dist_wire_us, nullptr},
     {"dist_mirror", &Options::dist_mirror, kWordsMirror},

@@ -67,7 +67,7 @@ int hns_trim_memory(void);
  *   "sor_block_lb"  0 = by size | 1 | 2: block edge of the temporally blocked form, in leaves
  *   "sor_block_k"   0 = by shape | 2 | 4: its iterations per launch (4: one-leaf blocks only)
  *   "sor_block_lean" auto | 0 | 1: 16^3-voxel blocks with the rows' p kept in LDS and three workgroups per CU (1) or in registers and two (0);
- *                   auto = 1 (the registers form is a cross-check). "sor_block_lean_stagger" N: launch-start stagger of the lean form (default 0)
+ *                   auto = 1 (the registers form is a cross-check).
  *   "sor_block_seg" N: its blocks per XCD segment of the launch order (0: one chunk per XCD; read when the block table is built)
  *   "sor_block_stagger" N: its launch-start stagger between the two workgroups of a CU, x 1,024 cycles (default 8; 0 = off)
  *   "advect"        auto | generic (64-bit addressed advection kernels)
@@ -78,7 +78,6 @@ int hns_trim_memory(void);
  *   "rev"           1 | 0 (divergence and advect_scalars walk the leaves backwards)
  *   "cook_cache"    1 | 0 (operator calls keep their device buffers with the grid)
  *   "cook_pipeline" 1 | 0 (hns_compute_sim overlaps its transfers with the substep)
- *   "sor_lds_pad"   N: extra LDS bytes per wave of the pair SOR kernel (fewer waves in flight; an experiment)
  *   "dist_wire_us"  N: the loopback transport of hns_dist holds every exchange N microseconds (emulated wire time)
  *   "dist_chain"    1 | 0: with dist_mirror, every kernel of the substep of such a rank delivers its own halo (no exchanges at all
  *                   after the first substep); 0 = only the SOR sweeps do (read when the ranks connect; all ranks must agree)

@@ -17,10 +17,10 @@ for c in sys.argv[1:]:
     for lean, stag in (("0", None), ("1", 0), ("1", 2), ("1", 3), ("1", 4), ("1", 6)):
         H.set_option("sor_block_lean", lean)
         if stag is not None:
-            H.set_option("sor_block_lean_stagger", str(stag))
+            pass  # (option sor_block_lean_stagger was removed in round 4: it bought nothing)
         ms = min(D.time_rbgs(grid, div, p_a, p_b, 1.0 / R, 1.97, 48, 3) for _ in range(3))
         line += f"  {'regs' if lean == '0' else 'lean/' + str(stag)} {1e3 * ms:6.2f}"
-    for k in ("rbgs", "sor_block_lb", "sor_block_k", "sor_block_lean", "sor_block_lean_stagger"):
+    for k in ("rbgs", "sor_block_lb", "sor_block_k", "sor_block_lean"):
         H.set_option(k, None)
     print(line, " us / iteration", flush=True)
     del grid, div, p_a, p_b
