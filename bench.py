@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--share-one-gpu", action="store_true",
                     help="builder's check on a 1-GPU box: all N ranks on cuda:0, host rendezvous over gloo, --transport ipc (RCCL refuses two ranks on one device)")
     ap.add_argument("--cook", action="store_true", help="time the cook-equivalent hns_compute_sim call (upload + grid build + substep + download) instead")
+    ap.add_argument("--no-strong", action="store_true", help="default workload only: skip the second record `strong_scaling` (BASELINE config 5, the 1024^3-extent plume "
+                                                              "as ONE domain over the N ranks)")
     return ap.parse_args()
 
 
@@ -106,7 +108,8 @@ def cook_equivalent(args):
     # keeps the device buffers of the previous cook.
     # feedback: warm, and the caller vouches that its arrays still hold what the previous cook handed back -- what the reference's SOP does
     # with its feedback input (SOP_HNanoSolver.cpp:106): nothing is uploaded, the cook is the substep plus the downloads (hns_compute_sim_resident)
-    for mode in ("cold", "warm", "feedback"):
+    # feedback_checked: the same with the promise CHECKED (a digest of every element at both ends of the cook) instead of vouched
+    for mode in ("cold", "warm", "feedback", "feedback_checked"):
         times = {"release_ms": [], "create_index_grid_ms": [], "compute_sim_ms": [], "total_ms": []}
         h = api.IndexGridHandle()
         for it in range(args.warmup + args.steps):
@@ -116,7 +119,7 @@ def cook_equivalent(args):
             t0 = time.perf_counter()
             api.CreateIndexGrid(d, h, 1.0 / R)
             t1 = time.perf_counter()
-            api.Compute_Sim(d, h, args.iterations, 1.0 / 24.0, 1.0 / R, p, False, feedback=(mode == "feedback" and it > 0) or None)
+            api.Compute_Sim(d, h, args.iterations, 1.0 / 24.0, 1.0 / R, p, False, feedback=(mode.startswith("feedback") and it > 0) or None, checked=mode == "feedback_checked")
             t2 = time.perf_counter()
             times["release_ms"].append(1e3 * (t0 - ta))
             times["create_index_grid_ms"].append(1e3 * (t1 - t0))
@@ -211,18 +214,101 @@ def self_launch(args) -> int:
     (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), let rank 0's JSON line
     through on the inherited stdout and hand back the child's exit code. This parent never touches the GPU (no torch
     import, no hns_* call) and never replaces itself with another program."""
-    import socket
     import subprocess
 
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:  # a free rendezvous port on the loopback interface
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun's own c10d rendezvous on a port IT binds (endpoint localhost:0) -- picking a "free" port here and passing its number on
+    # leaves a window in which another process, or a second bench.py on the same box, takes it
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL and hipIpc need on this pool
     env.setdefault("OMP_NUM_THREADS", "1")
     return subprocess.run(cmd, env=env).returncode
+
+
+def timed_steps(step, steps, warmup, world, on_cpu, before_timed=None):
+    """The contract's timed region: W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+    import torch
+    import torch.distributed as dist
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if before_timed:
+        before_timed()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_cpu else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def ghost_note_of(runner):
+    """after a timed region: do the ghost voxels the timed transport wrote hold their owners' bits? (collective; any failure is reported, not raised)"""
+    try:
+        n_pairs, bad = runner.rank_obj.ghost_check(None)
+        return (f"after the timed substeps the velocity and p ghost voxels of all {n_pairs} (owner, holder, field) pairs are bit-equal to their owners' values"
+                if not bad else f"GHOST VOXELS DIFFER FROM THEIR OWNERS' VALUES after the timed substeps in {len(bad)} of {n_pairs} pairs, first {bad[0]}")
+    except Exception as e:  # noqa: BLE001
+        return f"ghost check did not complete: {type(e).__name__}: {e}"[:300]
+
+
+def strong_scaling_record(args, world, rank, dt):
+    """BASELINE.json configs[4] beside the weak-scaling headline, in the same JSON line: the 1024^3-extent plume (65,944 leaves) as ONE domain split over the N
+    ranks (N = 1: the whole domain on the one GPU -- the curve's first point). Same step, same timing rule, same checks (against the single-GPU run of the
+    whole domain before, ghost voxels against their owners after). `value` = substeps/s of the one domain."""
+    import torch
+
+    from hnanosolver_amd import api, device as D, fields
+
+    origins, R = fields.config_leaves("plume1024")
+    vs = 1.0 / R
+    rec = {"metric": "solver substeps/sec of ONE domain over N GPUs (strong scaling)", "unit": "substeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "scaling": "strong", "config": {"workload": "plume1024: BASELINE.json configs[4], 1024^3-extent sparse plume", "leaves": int(len(origins)),
+                                           "active_voxels": int(len(origins)) * 512, "pressure_iterations": args.iterations}}
+    if world == 1:
+        f = fields.synthetic_fields(origins, R)
+        grid = api.create_grid_from_leaves(origins, vs)
+        sim = D.Sim(grid, ["density"])
+        sim.upload({"vel": f["vel"], "density": f["density"]})
+        stream = D.current_stream()
+        elapsed = timed_steps(lambda: sim.core_substep(args.iterations, dt, vs, stream), args.steps, args.warmup, 1, False)
+        rec["config"]["parallelism"] = "single GPU"
+        sim.close()
+    else:
+        from hnanosolver_amd import dist as HD
+
+        runner = HD.SlabBench(origins, R, rank, world, args.iterations, dt, partition=True, sweeps_per_exchange=args.sweeps_per_exchange, transport=args.transport,
+                              reference_transport="ipc" if args.share_one_gpu else "rccl")
+        if not args.no_verify:
+            try:
+                runner.verify_against_single_gpu()
+            except Exception as e:  # noqa: BLE001
+                runner.verified_note = f"check against the single-GPU run did not complete: {type(e).__name__}: {e}"[:300]
+                runner.rank_obj.upload(*runner._fields)
+        elapsed = timed_steps(runner.step, args.steps, args.warmup, world, args.share_one_gpu)
+        info = runner.info()
+        rec["config"].update({
+            "leaves_on_rank_0": runner.n_owned, "verified": runner.verified_note, "ghosts": ghost_note_of(runner),
+            "halo": {k: info[k] for k in ("boundary_leaves", "interior_leaves", "ghost_leaves", "peers", "halo_peers", "sweeps_per_exchange", "bytes_sent", "messages_sent", "exchanges")},
+            "parallelism": f"one domain in {world} slabs of leaves along axis {'xyz'[runner.rank_obj.partition_axis] if runner.rank_obj.partition_axis >= 0 else 'x (contiguous leaf ranges)'}"
+                           + ", halo transport: " + runner.transport_note + (" -- ALL RANKS SHARE ONE GPU (builder's check, not a scaling figure)" if args.share_one_gpu else "")})
+        runner.rank_obj.close()
+    torch.cuda.synchronize()
+    rec["value"] = args.steps / elapsed
+    rec["ms_per_step"] = 1e3 * elapsed / args.steps
+    return rec
 
 
 def main():
@@ -304,35 +390,8 @@ def main():
         def timing_on():
             runner.timing_on(args.steps)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    timing_on()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_one_gpu else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    ghosts_note = None
-    if world > 1:  # after the timed region: do the ghost voxels the timed transport wrote hold their owners' bits? (collective; any failure is reported, not raised)
-        try:
-            group = None
-            n_pairs, bad = runner.rank_obj.ghost_check(group)
-            ghosts_note = (f"after the timed substeps the velocity and p ghost voxels of all {n_pairs} (owner, holder, field) pairs are bit-equal to their owners' values"
-                           if not bad else f"GHOST VOXELS DIFFER FROM THEIR OWNERS' VALUES after the timed substeps in {len(bad)} of {n_pairs} pairs, first {bad[0]}")
-        except Exception as e:  # noqa: BLE001
-            ghosts_note = f"ghost check did not complete: {type(e).__name__}: {e}"[:300]
+    elapsed = timed_steps(step, args.steps, args.warmup, world, args.share_one_gpu, before_timed=timing_on)
+    ghosts_note = ghost_note_of(runner) if world > 1 else None
     p_ms, launches = pressure_time()  # (launches: red+black iterations inside the bracketed pressure loops)
     sor_form, sor_launches, sor_k = D.rbgs_plan(grid, args.iterations) if world == 1 else ("", args.iterations, 1)
     stages, n_sub = stage_times() if stage_times else ({}, 0)
@@ -363,7 +422,7 @@ def main():
 
         traffic = pmc_of(sor_form) if sor_form else None
         if traffic is None:
-            traffic_source = None if not pmc_kernels else traffic_source
+            traffic_source = None
         kernels = {}
         if n_sub:
             for st, ms in stages.items():
@@ -404,12 +463,12 @@ def main():
                 "pressure_iterations": args.iterations,
                 "substep": "advect_vector + divergence + RB-SOR + gradient subtraction + advect_scalars(S=1)",
                 "algorithmic_bytes_per_voxel_substep": BYTES_PER_VOXEL_SUBSTEP - 600 + 12 * args.iterations,
-                "halo": None if world == 1 else {k: runner.info()[k] for k in ("boundary_leaves", "interior_leaves", "ghost_leaves", "peers", "sweeps_per_exchange",
+                "halo": None if world == 1 else {k: runner.info()[k] for k in ("boundary_leaves", "interior_leaves", "ghost_leaves", "peers", "halo_peers", "sweeps_per_exchange",
                                                                                 "bytes_sent", "messages_sent", "exchanges")},
                 "verified": "single GPU path (tests/ tie it to the oracle)" if world == 1 else runner.verified_note,
                 "ghosts": ghosts_note,
                 "parallelism": "single GPU" if world == 1 else (
-                    (f"one domain in {world} contiguous leaf ranges" if args.partition else f"x-slab leaf partition over {world} ranks")
+                    (f"one domain in {world} slabs of leaves (axis {runner.rank_obj.partition_axis}; -1 = contiguous ranges of the leaf order)" if args.partition else f"x-slab leaf partition over {world} ranks")
                     + ", halo transport: " + runner.transport_note
                     + (" -- ALL RANKS SHARE ONE GPU (builder's check, not a scaling figure)" if args.share_one_gpu else "")),
             },
@@ -447,6 +506,18 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(origins, R, args.iterations)
+    # one driver command, both curves: the default workload also runs BASELINE config 5 as one domain over the same ranks (collective: every rank takes part)
+    strong = None
+    if args.config == "256" and not args.partition and not args.no_strong:
+        if world > 1:
+            runner.rank_obj.close()
+        try:
+            strong = strong_scaling_record(args, world, rank, dt)
+        except Exception as e:  # noqa: BLE001 -- the headline line must come out whatever happens to the second record
+            strong = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if rank == 0:
+        if strong is not None:
+            out["strong_scaling"] = strong
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

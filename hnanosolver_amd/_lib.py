@@ -36,11 +36,13 @@ class hns_field(C.Structure):
 class hns_dist_stats(C.Structure):
     _fields_ = [("world", C.c_int), ("rank", C.c_int), ("peers", C.c_int), ("sweeps_per_exchange", C.c_int),
                 ("boundary_leaves", C.c_uint64), ("interior_leaves", C.c_uint64), ("ghost_leaves", C.c_uint64),
-                ("region_voxels_sent", C.c_uint64 * 4), ("bytes_sent", C.c_uint64 * 4), ("messages_sent", C.c_uint64), ("exchanges", C.c_uint64)]
+                ("region_voxels_sent", C.c_uint64 * 4), ("bytes_sent", C.c_uint64 * 4), ("messages_sent", C.c_uint64), ("exchanges", C.c_uint64),
+                ("halo_peers", C.c_uint64)]
 
 
 HNS_DIST_IPC_BLOB_BYTES = 2048
 HNS_DIST_PLAN_ONLY = 1
+HNS_DIST_LEAF_ORDER = 2
 
 
 class hns_combustion_params(C.Structure):
@@ -126,6 +128,9 @@ SIGNATURES = {
     "hns_dist_connect_ipc": (_i, [_vp, _vp]),
     "hns_dist_owned_leaves": (_u64, [_vp]),
     "hns_dist_first_owned_leaf": (_u64, [_vp]),
+    "hns_dist_owned_leaf_ids": (_i, [_vp, _vp]),
+    "hns_dist_partition_axis": (_i, [_vp]),
+    "hns_dist_one_sided_sweeps": (_i, [_u64, _i]),
     "hns_dist_info": (_i, [_vp, C.POINTER(hns_dist_stats)]),
     "hns_dist_local_leaves": (_i, [_vp, _vp]),
     "hns_dist_peer_rank": (_i, [_vp, _i]),

@@ -272,10 +272,13 @@ def CreateIndexGrid(data: GridIndexedData, handle: IndexGridHandle, voxelSize: f
 
 
 def Compute_Sim(data: GridIndexedData, handle: IndexGridHandle, iteration: int, dt: float, voxelSize: float, params: CombustionParams,
-                hasCollision: bool, stream=None, feedback=None) -> Optional[int]:
+                hasCollision: bool, stream=None, feedback=None, checked: bool = True) -> Optional[int]:
     """feedback (not in the reference's signature): True, or the names of the blocks whose arrays still hold what the previous
     Compute_Sim on this handle handed back (the SOP feeds its output back in as the next frame's input, SOP_HNanoSolver.cpp:106):
-    those blocks are not uploaded again (hns_compute_sim_resident; the promise is checked). Returns the number of uploads skipped."""
+    those blocks are not uploaded again (hns_compute_sim_resident). checked=True (default): the promise is CHECKED -- a digest of every
+    element, one pass over the arrays at each end of the cook; any edit is noticed and that block uploaded. checked=False: VOUCHED --
+    only a 4,096-sample signature is compared; a sparse edit (an emitter added to a few leaves) is NOT detected, so a block the caller
+    sourced into must not be named. Returns the number of uploads skipped."""
     if handle is None or handle.isEmpty():
         # argument checks come first in the reference (HNanoSolver.cu:12-23)
         if voxelSize <= 0.0:
@@ -288,7 +291,7 @@ def Compute_Sim(data: GridIndexedData, handle: IndexGridHandle, iteration: int, 
     fields, n, keep = data._fields()
     p = params._c()
     if feedback:
-        flags = bytes(1 if (feedback is True or fields[i].name.decode() in feedback) else 0 for i in range(n))
+        flags = bytes((2 if checked else 1) if (feedback is True or fields[i].name.decode() in feedback) else 0 for i in range(n))
         skipped = C.c_int(0)
         _raise(lib.hns_compute_sim_resident(handle.ptr, fields, n, flags, C.byref(skipped), int(iteration), float(dt), float(voxelSize), C.byref(p),
                                             int(bool(hasCollision)), _stream(stream)))

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "hns_internal.hpp"
@@ -85,8 +86,8 @@ struct hns_sim {
 	bool cached = false, in_use = false;  // owned by the grid's cook cache / currently lent to an operator call
 	// Device-resident feedback across cooks (hns_compute_sim_resident): a signature of what the last hns_compute_sim on this state handed
 	// back for the velocity and for float field i -- those bytes are still in `vel` / cur[i]. 0 = nothing to vouch for (any upload clears it).
-	uint64_t sig_vel = 0;
-	std::vector<uint64_t> sig_cur;
+	uint64_t sig_vel = 0, dig_vel = 0;  // (sig: sample signature; dig: full digest, 0 = not taken)
+	std::vector<uint64_t> sig_cur, dig_cur;
 	void* arena = nullptr;  // every field above is a slice of this one allocation (see the arena pool below)
 	size_t arena_bytes = 0;
 	int device = -1;
@@ -312,7 +313,7 @@ extern "C" int hns_sim_upload(hns_sim* s, const hns_field* fields, int n_fields,
 			return HNS_ERR_RUNTIME;
 		}
 		if (f.ncomp == 3) {
-			s->sig_vel = 0;
+			s->sig_vel = s->dig_vel = 0;
 			HNS_HIP(hipMemcpyAsync(s->vel, f.host, sizeof(float) * 3 * (size_t)s->n, hipMemcpyHostToDevice, st));
 		} else if (f.ncomp == 1) {
 			const int k = f.name ? s->find(f.name) : -1;
@@ -321,6 +322,7 @@ extern "C" int hns_sim_upload(hns_sim* s, const hns_field* fields, int n_fields,
 				return HNS_ERR_RUNTIME;
 			}
 			if ((size_t)k < s->sig_cur.size()) s->sig_cur[(size_t)k] = 0;
+			if ((size_t)k < s->dig_cur.size()) s->dig_cur[(size_t)k] = 0;
 			HNS_HIP(hipMemcpyAsync(s->cur[k], f.host, sizeof(float) * (size_t)s->n, hipMemcpyHostToDevice, st));
 		} else {
 			return fail(HNS_ERR_INVALID_ARGUMENT, "hns_sim_upload: ncomp must be 1 or 3");
@@ -705,9 +707,14 @@ int make_sim(hns_grid* g, const FieldSplit& fs, SimGuard& guard, void* stream) {
 // run under the upload of fuel and waste, the pressure solve under the upload of every other field (Substep::part_b1),
 // and advect_scalars under the download of the final velocity. Same kernels, same order per buffer; only the overlap
 // differs. Option "cook_pipeline" = 0 falls back to upload-all / run / download-all.
-// What a host array and the device buffer it was downloaded from have in common afterwards: element count and 4,096 evenly spread
-// elements, hashed (FNV-1a over their bits). Never 0. Cheap next to a transfer (16 KB read out of 67 - 201 MB), and what a caller's
-// "this array is what you gave me last cook" promise is checked against before an upload is skipped on the strength of it.
+// What a host array and the device buffer it was downloaded from have in common afterwards. Two strengths (hns_compute_sim_resident):
+//  * the SAMPLE signature: element count and 4,096 evenly spread elements, hashed (FNV-1a over their bits). 16 KB read out of 67 - 201 MB: a tripwire
+//    against handing in a different array, NOT a check of the promise -- an edit that misses the samples (an emitter added to a few leaves) passes.
+//    resident[i] = 1 ("vouched") relies on the caller knowing what it changed, as the reference's SOP does (it adds its sources itself,
+//    SOP_HNanoSolver.cpp:159-179, and must not flag a field it sourced into);
+//  * the FULL digest: every element, 64-bit multiply-xor per 8 bytes over 1 MiB chunks on up to 8 host threads (memory-bound: ~5 ms for the 537 MB of a
+//    256^3 cook; an upload of the same is ~10 ms). resident[i] = 2 ("checked"): the skip is sound, at that price at both ends of the cook.
+// Neither is ever 0.
 static uint64_t host_signature(const float* a, size_t count) {
 	uint64_t h = 1469598103934665603ull ^ (uint64_t)count;
 	const size_t samples = count < 4096 ? count : 4096;
@@ -718,34 +725,82 @@ static uint64_t host_signature(const float* a, size_t count) {
 	}
 	return h ? h : 1;
 }
+static uint64_t host_digest(const float* a, size_t count) {
+	constexpr size_t kChunk = (size_t)1 << 18;  // floats per chunk (1 MiB)
+	const size_t n_chunks = (count + kChunk - 1) / kChunk;
+	std::vector<uint64_t> part(n_chunks, 0);
+	auto work = [&](size_t c0, size_t c1) {
+		for (size_t c = c0; c < c1; ++c) {
+			const size_t lo = c * kChunk, hi = std::min(count, lo + kChunk);
+			uint64_t h0 = 0x9E3779B97F4A7C15ull ^ c, h1 = 0xC2B2AE3D27D4EB4Full + c;
+			size_t i = lo;
+			for (; i + 4 <= hi; i += 4) {  // two independent lanes of 8 bytes each
+				uint64_t w0, w1;
+				memcpy(&w0, a + i, 8);
+				memcpy(&w1, a + i + 2, 8);
+				h0 = (h0 ^ w0) * 0x100000001B3ull, h0 ^= h0 >> 29;
+				h1 = (h1 ^ w1) * 0xFF51AFD7ED558CCDull, h1 ^= h1 >> 31;
+			}
+			for (; i < hi; ++i) {
+				uint32_t b;
+				memcpy(&b, a + i, 4);
+				h0 = (h0 ^ b) * 0x100000001B3ull;
+			}
+			part[c] = h0 ^ (h1 * 0x9FB21C651E98DF25ull);
+		}
+	};
+	const size_t n_threads = std::min<size_t>(8, std::max<size_t>(1, n_chunks / 8));
+	if (n_threads <= 1) work(0, n_chunks);
+	else {
+		std::vector<std::thread> th;
+		for (size_t t = 0; t < n_threads; ++t) th.emplace_back(work, n_chunks * t / n_threads, n_chunks * (t + 1) / n_threads);
+		for (auto& t : th) t.join();
+	}
+	uint64_t h = 1469598103934665603ull ^ (uint64_t)count;
+	for (uint64_t p : part) h = (h ^ p) * 1099511628211ull, h ^= h >> 32;
+	return h ? h : 1;
+}
 
 // `resident` (hns_compute_sim_resident): per field of `fields` (by position), non-zero = the caller vouches that the host array still
 // holds what the previous hns_compute_sim on this grid handed back for the block of that name. The field is then not uploaded -- if
 // the device state lent to this call is the one that produced it and the array's signature still matches; uploaded as usual otherwise.
 static int compute_sim_pipelined(hns_sim* s, FieldSplit& fs, int iterations, float dt, float voxel_size, const hns_combustion_params* params,
-                                 int has_collision, void* stream, const std::vector<const hns_field*>& resident, int* skipped) {
+                                 int has_collision, void* stream, const std::vector<std::pair<const hns_field*, int>>& resident, int* skipped) {
 	Substep step;
 	const size_t count = (size_t)s->n;
 	s->sig_cur.resize(s->names.size(), 0);
+	s->dig_cur.resize(s->names.size(), 0);
+	auto level_of = [&](const hns_field* f) {
+		for (auto& r : resident)
+			if (r.first == f) return r.second;
+		return 0;
+	};
 	auto stays = [&](const hns_field* f) {
-		if (std::find(resident.begin(), resident.end(), f) == resident.end()) return false;
-		uint64_t have = 0;
+		const int level = level_of(f);
+		if (!level) return false;
+		uint64_t have = 0, have_full = 0;
 		size_t n = count;
-		if (f->ncomp == 3) have = s->sig_vel, n = 3 * count;
+		if (f->ncomp == 3) have = s->sig_vel, have_full = s->dig_vel, n = 3 * count;
 		else {
 			const int k = s->find(f->name);
-			if (k >= 0) have = s->sig_cur[(size_t)k];
+			if (k >= 0) have = s->sig_cur[(size_t)k], have_full = s->dig_cur[(size_t)k];
 		}
 		if (!have || have != host_signature(f->host, n)) return false;
+		if (level >= 2 && (!have_full || have_full != host_digest(f->host, n))) return false;  // (no digest taken last cook: nothing to check against -> upload)
 		if (skipped) ++*skipped;
 		return true;
 	};
 	auto upload = [&](hns_field* f, void* on) { return stays(f) ? (int)HNS_OK : hns_sim_upload(s, f, 1, on); };
 	auto sign = [&]() {  // (the downloads have completed: what the host arrays hold now is what vel / cur[] hold)
+		// the full digest is taken for the fields this call was asked to CHECK (the caller that checks this cook checks the next one too)
 		s->sig_vel = host_signature(fs.velocity->host, 3 * count);
+		s->dig_vel = level_of(fs.velocity) >= 2 ? host_digest(fs.velocity->host, 3 * count) : 0;
 		for (hns_field* f : fs.floats) {
 			const int k = s->find(f->name);
-			if (k >= 0) s->sig_cur[(size_t)k] = strcmp(f->name, "collision_sdf") ? host_signature(f->host, count) : 0;  // (the SDF comes back zeroed, the device keeps it)
+			if (k < 0) continue;
+			const bool sdf = !strcmp(f->name, "collision_sdf");  // (the SDF comes back zeroed, the device keeps it)
+			s->sig_cur[(size_t)k] = sdf ? 0 : host_signature(f->host, count);
+			s->dig_cur[(size_t)k] = (!sdf && level_of(f) >= 2) ? host_digest(f->host, count) : 0;
 		}
 	};
 	if (!options().cook_pipeline.load()) {
@@ -828,15 +883,16 @@ extern "C" int hns_compute_sim_resident(hns_grid* g, hns_field* fields, int n_fi
 			return HNS_ERR_RUNTIME;
 		}
 	if (!g->on_device) return fail(HNS_ERR_NO_DEVICE, "hns_compute_sim: grid has no device tables (there is no CPU fallback)");
-	std::vector<const hns_field*> res;
+	std::vector<std::pair<const hns_field*, int>> res;
 	if (resident)
 		for (int i = 0; i < n_fields; ++i)
-			if (resident[i]) res.push_back(&fields[i]);
+			if (resident[i]) res.emplace_back(&fields[i], (int)resident[i]);
 	SimGuard guard;
 	HNS_TRY(make_sim(g, fs, guard, stream));
 	if (int rc = compute_sim_pipelined(guard.s, fs, iterations, dt, voxel_size, params, has_collision, stream, res, uploads_skipped)) {
-		guard.s->sig_vel = 0;  // whatever the buffers hold now, nobody was handed it
+		guard.s->sig_vel = guard.s->dig_vel = 0;  // whatever the buffers hold now, nobody was handed it
 		std::fill(guard.s->sig_cur.begin(), guard.s->sig_cur.end(), 0);
+		std::fill(guard.s->dig_cur.begin(), guard.s->dig_cur.end(), 0);
 		// copies on the transfer stream and kernels on the caller's may still be queued: let them finish before the
 		// guard hands the buffers on (and before the caller reuses its host arrays)
 		if (guard.s->xfer) (void)hipStreamSynchronize(guard.s->xfer);

@@ -365,8 +365,11 @@ struct hns_dist {
 	float voxel_size = 1.0f;
 	int64_t n_global = 0;
 	int nB = 0, nI = 0, nG = 0;
-	std::vector<int64_t> local_global;  // global id of every local leaf, local order [B | I | G]
-	std::vector<int> owned_perm;        // position of local leaf l < nB+nI in the ascending-global-id list of owned leaves
+	std::vector<int64_t> local_global;  // global id (position in the caller's leaf list) of every local leaf, local order [B | I | G]
+	std::vector<int> owned_perm;        // position of local leaf l < nB+nI in the list of owned leaves in PARTITION order (owned_global)
+	std::vector<int64_t> owned_global;  // global ids of the owned leaves in partition order: the order of the host arrays of upload / download
+	bool blocked = false;               // the chained pressure loop of this decomposition takes two iterations per launch (blocked_mirror_rule, decided at create)
+	int part_axis = -1;                 // -1: the partition is contiguous ranges of the caller's leaf order; 0 / 1 / 2: slabs along that axis (partition_order)
 	std::vector<Peer> peers;
 	hns_grid *gB = nullptr, *gI = nullptr, *gO = nullptr, *gA = nullptr;
 	// device state over the local leaves
@@ -446,7 +449,61 @@ static int far_check(const hns_dist* d) {
 
 namespace {
 
-int build_plan(hns_dist* d, const int32_t* origins, int64_t n, int world, int rank) {
+// Round 5: WHICH leaves a rank owns. Rounds 1-4 cut the caller's leaf list (NanoVDB order: hierarchical, x-major) into `world` contiguous ranges.
+// That is a slab decomposition for box domains, but on BASELINE config 5 (the 66k-leaf plume on a 1024^3 extent, 8 ranks) the ranges are
+// chunks of 128^3-voxel NanoVDB nodes and every rank touches SEVEN others: 14 point-to-point messages per exchange, 25+ exchanges per substep.
+// Here the leaves are put in slab order -- by leaf coordinate along ONE axis, the caller's order inside a plane of leaves --, THAT list is
+// cut into `world` equal ranges, and every range is put back into the caller's order: a rank touches the rank before and the rank behind it (plus the owner of the caller's leaf 0, whose element
+// 0 every rank mirrors). The axis is the one whose cuts cross the fewest leaves (the plume: y, its own axis -- 1,240 boundary leaves per rank
+// instead of 1,864, 2 halo peers instead of 7). If the cut along x selects the same leaf sets as the contiguous ranges did (every box domain
+// whose slabs are whole 128-voxel NanoVDB nodes: the weak-scaling slabs of bench.py), the caller's order is kept as it is: part_axis -1.
+// order[i] = position in the caller's list of the i-th leaf in partition order. Every rank derives the same order from the same global list.
+int partition_order(const int32_t* origins, int64_t n, int world, bool leaf_order, std::vector<int64_t>& order) {
+	order.resize((size_t)n);
+	for (int64_t i = 0; i < n; ++i) order[(size_t)i] = i;
+	if (leaf_order || world <= 1 || n == 0) return -1;
+	std::vector<int64_t> best;
+	int64_t best_cost = -1;
+	int best_axis = -1;
+	for (int a = 0; a < 3; ++a) {
+		std::vector<int64_t> o = order;
+		std::stable_sort(o.begin(), o.end(), [&](int64_t x, int64_t y) { return origins[(size_t)x * 3 + (size_t)a] < origins[(size_t)y * 3 + (size_t)a]; });
+		// leaves in the planes a cut touches: what the two ranks at that cut exchange
+		int64_t cost = 0;
+		for (int r = 1; r < world; ++r) {
+			const int64_t c = n * r / world;
+			if (c <= 0 || c >= n) continue;
+			const int32_t lo = origins[(size_t)o[(size_t)c - 1] * 3 + (size_t)a], hi = origins[(size_t)o[(size_t)c] * 3 + (size_t)a];
+			auto plane = [&](int32_t v) {
+				auto cmp_lo = [&](int64_t x, int32_t val) { return origins[(size_t)x * 3 + (size_t)a] < val; };
+				auto cmp_hi = [&](int32_t val, int64_t x) { return val < origins[(size_t)x * 3 + (size_t)a]; };
+				return (int64_t)(std::upper_bound(o.begin(), o.end(), v, cmp_hi) - std::lower_bound(o.begin(), o.end(), v, cmp_lo));
+			};
+			cost += plane(lo) + (hi != lo ? plane(hi) : 0);
+		}
+		if (best_cost < 0 || cost < best_cost) best_cost = cost, best_axis = a, best.swap(o);
+	}
+	// the same leaf sets as the contiguous ranges of the caller's order? Then that order stays (memory layout of a rank = the caller's)
+	bool same = true;
+	if (best_axis != 0) {  // (only the x cut can coincide with NanoVDB order; check it even if another axis is cheaper: equal sets keep rounds 1-4's layout)
+		std::vector<int64_t> o = order;
+		std::stable_sort(o.begin(), o.end(), [&](int64_t x, int64_t y) { return origins[(size_t)x * 3] < origins[(size_t)y * 3]; });
+		for (int r = 0; r < world && same; ++r)
+			for (int64_t i = n * r / world; i < n * (r + 1) / world && same; ++i) same = o[(size_t)i] >= n * r / world && o[(size_t)i] < n * (r + 1) / world;
+	} else {
+		for (int r = 0; r < world && same; ++r)
+			for (int64_t i = n * r / world; i < n * (r + 1) / world && same; ++i) same = best[(size_t)i] >= n * r / world && best[(size_t)i] < n * (r + 1) / world;
+	}
+	if (same) return -1;
+	// the slabs decide WHICH leaves a rank owns; inside a rank they stay in the caller's order (a rank's memory layout then is NanoVDB order restricted to
+	// its slab -- whole 128^3-voxel nodes, compact in 3-D -- where plane-major order put a leaf's neighbours along the cut axis a whole plane of leaves
+	// away: measured on config 5, rank 4 of 8 alone, 13.2 against 12.3 us per iteration of the chained pressure loop)
+	for (int r = 0; r < world; ++r) std::sort(best.begin() + n * r / world, best.begin() + n * (r + 1) / world);
+	order.swap(best);
+	return best_axis;
+}
+
+int build_plan(hns_dist* d, const int32_t* origins, int64_t n, int world, int rank, int64_t g0) {
 	Topology topo;
 	HNS_TRY(topo.prepare(origins, n));
 	HNS_TRY(topo.build_tables());
@@ -455,7 +512,7 @@ int build_plan(hns_dist* d, const int32_t* origins, int64_t n, int world, int ra
 	auto owner = [&](int64_t l) { return (int)(std::upper_bound(bounds.begin(), bounds.end(), l) - bounds.begin()) - 1; };
 	const int64_t o0 = bounds[(size_t)rank], o1 = bounds[(size_t)rank + 1];
 	const int n_owned = (int)(o1 - o0);
-	const int owner0 = n ? owner(0) : rank;
+	const int owner0 = n ? owner(g0) : rank;  // (g0: where the caller's leaf 0 -- whose element 0 advect_scalars reads for out-of-domain taps -- sits in partition order)
 
 	Mask512 reach[27][X_COUNT];
 	const int depth[X_COUNT] = {24, 1, 2 * d->k - 1, 2 * d->k};  // X_ADV: the whole leaf
@@ -502,10 +559,10 @@ int build_plan(hns_dist* d, const int32_t* origins, int64_t n, int world, int ra
 	if (world > 1 && n > 0) {
 		if (owner0 == rank) {
 			for (int q = 0; q < world; ++q)
-				if (q != rank) entry(send_of[(size_t)q], send_keys[(size_t)q], 0).m[X_ADV].fill();
-			is_boundary[0] = 1;
+				if (q != rank) entry(send_of[(size_t)q], send_keys[(size_t)q], g0).m[X_ADV].fill();
+			is_boundary[(size_t)(g0 - o0)] = 1;
 		} else {
-			entry(recv_of[(size_t)owner0], recv_keys[(size_t)owner0], 0).m[X_ADV].fill();
+			entry(recv_of[(size_t)owner0], recv_keys[(size_t)owner0], g0).m[X_ADV].fill();
 		}
 	}
 
@@ -673,9 +730,14 @@ PhaseMirror phase_args(hns_dist* d, int t, const std::vector<std::pair<const flo
 // (hns_sorblock.hip: k_rbgs_block<2, 2, ., true, PhaseMirror>), whose mirror region is the plan's reach-4 region of p. All ranks must
 // take the same path (they count launches alike), so the decision uses only what every rank knows: the smallest owned range must be
 // swept in 16^3 blocks (more than 600 leaves, hns_rbgs_block_shape) and the option must say so.
-bool blocked_mirror(const hns_dist* d) {
-	return d->k == 2 && options().dist_block.load() != 0 && options().sor_block_lb.load() != 1 && d->world > 0 && d->n_global / d->world > 600 && d->n_global <= 2000000;
+// Does a rank of `world` ranks over `n_global` leaves take the chained blocked sweep (two iterations per chained launch) when it runs with
+// sweeps_per_exchange = `k` over the ipc / local transports? From what every rank knows alike (all ranks must count launches alike) and the options
+// as they are NOW: hns_dist_create asks once and stores the answer (hns_dist::blocked), which is what create, connect and the substep use -- an option
+// changed between create and connect no longer leaves a rank on two paths at once.
+bool blocked_mirror_rule(int k, int world, int64_t n_global) {
+	return k == 2 && options().dist_block.load() != 0 && options().sor_block_lb.load() != 1 && world > 0 && n_global / world > 600 && n_global <= 2000000;
 }
+bool blocked_mirror(const hns_dist* d) { return d->blocked; }
 bool mirror_wanted(const hns_dist* d) { return (d->k == 1 || blocked_mirror(d)) && d->world > 1 && options().dist_mirror.load() != 0; }
 
 }  // namespace
@@ -727,7 +789,28 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 		return bail(fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_create: sweeps_per_exchange must be 1..4"));
 	d = new hns_dist;
 	d->world = world, d->rank = rank, d->k = sweeps_per_exchange, d->n_scalars = n_scalars, d->voxel_size = voxel_size, d->n_global = (int64_t)n_leaves;
-	if ((rc = build_plan(d, global_leaf_origins_xyz, (int64_t)n_leaves, world, rank)) != HNS_OK) return bail(rc);
+	d->blocked = blocked_mirror_rule(d->k, world, (int64_t)n_leaves);
+	{
+		// the plan is built over the leaves in PARTITION order (build_plan's "global" ids are positions in that order); what leaves this block are
+		// positions in the caller's list again
+		std::vector<int64_t> order;
+		d->part_axis = partition_order(global_leaf_origins_xyz, (int64_t)n_leaves, world, (flags & HNS_DIST_LEAF_ORDER) != 0, order);
+		std::vector<int32_t> po;
+		const int32_t* plan_origins = global_leaf_origins_xyz;
+		int64_t g0 = 0;
+		if (d->part_axis >= 0) {
+			po.resize((size_t)n_leaves * 3);
+			for (uint64_t i = 0; i < n_leaves; ++i) {
+				for (int a = 0; a < 3; ++a) po[(size_t)i * 3 + (size_t)a] = global_leaf_origins_xyz[(size_t)order[(size_t)i] * 3 + (size_t)a];
+				if (order[(size_t)i] == 0) g0 = (int64_t)i;
+			}
+			plan_origins = po.data();
+		}
+		if ((rc = build_plan(d, plan_origins, (int64_t)n_leaves, world, rank, g0)) != HNS_OK) return bail(rc);
+		for (int64_t& id : d->local_global) id = order[(size_t)id];
+		const int64_t o0 = (int64_t)n_leaves * rank / world, o1 = (int64_t)n_leaves * (rank + 1) / world;
+		d->owned_global.assign(order.begin() + o0, order.begin() + o1);
+	}
 	if (flags & HNS_DIST_PLAN_ONLY) {  // host-side plan for inspection (tests run it through a CPU engine); no device is touched
 		if (err) *err = HNS_OK;
 		return d;
@@ -1091,7 +1174,19 @@ int hns_dist_peer_region(const hns_dist* d, int peer, int type, int is_send, int
 }
 
 uint64_t hns_dist_owned_leaves(const hns_dist* d) { return d ? (uint64_t)(d->nB + d->nI) : 0; }
-uint64_t hns_dist_first_owned_leaf(const hns_dist* d) { return d && d->nB + d->nI ? (uint64_t)(d->n_global * d->rank / d->world) : 0; }
+// the first owned leaf when the owned leaves are a contiguous run of the caller's list (part_axis -1: every partition of rounds 1-4), else ~0
+uint64_t hns_dist_first_owned_leaf(const hns_dist* d) {
+	if (!d || d->nB + d->nI == 0) return 0;
+	return d->part_axis < 0 ? (uint64_t)d->owned_global.front() : ~(uint64_t)0;
+}
+int hns_dist_owned_leaf_ids(const hns_dist* d, int64_t* out_global_ids) {
+	if (!d || !out_global_ids) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_owned_leaf_ids: null argument");
+	std::copy(d->owned_global.begin(), d->owned_global.end(), out_global_ids);
+	return HNS_OK;
+}
+int hns_dist_partition_axis(const hns_dist* d) { return d ? d->part_axis : -1; }
+// sweeps_per_exchange of the chained one-sided substep for a decomposition of this size: 2 where the ranks' owned ranges are swept in 16^3 blocks, else 1
+int hns_dist_one_sided_sweeps(uint64_t n_leaves, int world) { return blocked_mirror_rule(2, world, (int64_t)n_leaves) ? 2 : 1; }
 
 int hns_dist_info(const hns_dist* d, hns_dist_stats* out) {
 	if (!d || !out) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_info: null argument");
@@ -1104,11 +1199,16 @@ int hns_dist_info(const hns_dist* d, hns_dist_stats* out) {
 		for (const Peer& p : d->peers) out->region_voxels_sent[t] += (uint64_t)p.send[t].voxels;
 	}
 	out->messages_sent = d->messages_sent, out->exchanges = d->exchanges;
+	for (const Peer& p : d->peers) {
+		bool halo = false;
+		for (int t = 1; t < X_COUNT; ++t) halo = halo || p.send[t].voxels || p.recv[t].voxels;
+		out->halo_peers += halo ? 1 : 0;
+	}
 	return HNS_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// upload / download: host arrays over the OWNED leaves in ascending global order
+// upload / download: host arrays over the OWNED leaves in partition order (hns_dist_owned_leaf_ids; ascending global ids when part_axis < 0)
 // ---------------------------------------------------------------------------------------------------------------
 
 static int drain(hns_dist* d, hipStream_t st) {

@@ -163,7 +163,7 @@ struct hns_grid {
 	bool sb_built = false;
 	int sb_seg = 0;
 	uint64_t sb_first = 0, sb_count = 0;                  // the launch range the records were built for
-	std::vector<std::pair<void*, size_t>> sb_retired;     // superseded tables: back to the pool only when the grid goes
+	std::vector<std::pair<void*, size_t>> sb_retired;     // superseded tables: back to the pool when the grid goes, or -- beyond four of them -- behind a device synchronise
 	std::mutex build_mutex;              // guards the tables built on first use (tile groups, block records): cooks from several host threads may share a grid
 	std::mutex host_mutex;               // guards the lazy host copy of the device-built tables and sim_cache
 	std::vector<hns_sim*> sim_cache;     // device-resident state kept between operator calls (hns_api.hip: make_sim)

@@ -722,11 +722,21 @@ using namespace hns;
 // inside an asynchronous per-stream entry point, stalling every stream of the device on first use (concurrent cooks). (3) A table that
 // was handed to launches is never returned to the pool while the grid lives (another host thread's launch may still read it): tables
 // superseded by an option or range change are parked until the grid goes (hns_grid_retire_blocks).
+void hns_grid_retire_blocks(hns_grid* g);
+
 int hns_grid_build_blocks(hns_grid* g) {
 	std::lock_guard<std::mutex> lock(g->build_mutex);
 	const int seg = options().sor_block_seg.load();
 	if (g->sb_built && g->sb_seg == seg && g->sb_first == g->first_active && g->sb_count == g->n_active) return HNS_OK;
-	if (g->d_sb_tab) g->sb_retired.emplace_back(g->d_sb_tab, g->sb_bytes);
+	if (g->d_sb_tab) {
+		//  a grid whose launch range or segment option changes every frame would park one table per change until it is destroyed: beyond
+		// four parked tables wait for the device -- a launch that was handed one of them has finished then -- and give them all back to the pool
+		if (g->sb_retired.size() >= 4) {
+			HNS_HIP(hipDeviceSynchronize());
+			hns_grid_retire_blocks(g);
+		}
+		g->sb_retired.emplace_back(g->d_sb_tab, g->sb_bytes);
+	}
 	g->d_sb_tab = nullptr;
 	g->sb_bytes = 0;
 	g->n_sb = 0;

@@ -1,7 +1,8 @@
 """Leaf-partitioned multi-GPU core substep: host-side mirror of the ``hns_dist_*`` entry points of libhns.so.
 
 The reference is single-GPU; the decomposition is new design and lives in ``csrc/hns_dist.hip``: rank r
-owns leaves ``[n*r/world, n*(r+1)/world)`` of the NanoVDB-ordered global leaf list (x-slabs for box-like domains), keeps
+owns the r-th of `world` equal ranges of the global leaf list in slab order (``DistRank.owned_ids``; box domains: x-slabs = contiguous
+ranges of the NanoVDB-ordered list, as in rounds 1-4; the plume of BASELINE config 5: slabs along its own axis, two halo peers per rank), keeps
 one layer of ghost leaves in the local order ``[boundary | interior | ghosts]``, runs every kernel on its boundary leaves
 first and ships exactly the ghost voxels the peers' next kernel can read (512-bit masks per leaf, derived on both sides
 from the global leaf list) over RCCL point-to-point on a communication stream while the interior is being computed.
@@ -34,8 +35,23 @@ def omega_compute(voxel_size: float) -> float:
 
 
 def partition_bounds(n_leaves: int, world: int) -> np.ndarray:
-    """First global leaf of every rank (and n_leaves at the end): the rule hns_dist_create applies."""
+    """First position of every rank (and n_leaves at the end) in the PARTITION order of the leaves: the rule hns_dist_create applies. Positions
+    in the caller's list only when the partition is contiguous ranges of it (DistRank.partition_axis == -1); see owned_ids_of."""
     return np.array([(n_leaves * r) // world for r in range(world + 1)], dtype=np.int64)
+
+
+def owned_ids_of(global_origins: np.ndarray, world: int, rank: int, leaf_order: bool = False) -> np.ndarray:
+    """The leaves (positions in `global_origins`) rank `rank` of `world` owns, in upload / download order: asked of the library (a plan-only handle)."""
+    d = DistRank(global_origins, world, rank, 1.0, 0, 0, plan_only=True, leaf_order=leaf_order)
+    ids = d.owned_ids.copy()
+    d.close()
+    return ids
+
+
+def take_leaves(a: np.ndarray, leaf_ids: np.ndarray) -> np.ndarray:
+    """rows of a per-voxel array (n_leaves * 512 [, c]) that belong to the listed leaves, in that order"""
+    a = np.asarray(a)
+    return np.ascontiguousarray(a.reshape((-1, LEAF_VOXELS) + a.shape[1:])[np.asarray(leaf_ids, dtype=np.int64)].reshape((-1,) + a.shape[1:]))
 
 
 @dataclass
@@ -62,23 +78,34 @@ class DistRank:
     """One rank of the decomposition (``hns_dist``). ``plan_only=True`` builds the host-side plan without a device."""
 
     def __init__(self, global_origins: np.ndarray, world: int, rank: int, voxel_size: float, n_scalars: int = 1, sweeps_per_exchange: int = 0,
-                 plan_only: bool = False):
+                 plan_only: bool = False, leaf_order: bool = False):
         o = np.ascontiguousarray(global_origins, dtype=np.int32).reshape(-1, 3)
         err = C.c_int(0)
         self._ptr = lib.hns_dist_create(o.ctypes.data, o.shape[0], int(world), int(rank), float(voxel_size), int(n_scalars), int(sweeps_per_exchange),
-                                        _lib.HNS_DIST_PLAN_ONLY if plan_only else 0, C.byref(err))
+                                        (_lib.HNS_DIST_PLAN_ONLY if plan_only else 0) | (_lib.HNS_DIST_LEAF_ORDER if leaf_order else 0), C.byref(err))
         if not self._ptr:
             _raise(err.value if err.value < 0 else _lib.HNS_ERR_RUNTIME)
         self.world, self.rank, self.n_scalars, self.voxel_size = int(world), int(rank), int(n_scalars), float(voxel_size)
         self.n_global = o.shape[0]
         self.n_owned = int(lib.hns_dist_owned_leaves(self._ptr))
-        self.first_owned = int(lib.hns_dist_first_owned_leaf(self._ptr))
+        # the owned leaves (positions in `global_origins`) in the order upload / download use. Slabs along `partition_axis` (0 / 1 / 2), or --
+        # partition_axis -1 -- the contiguous range [first_owned, first_owned + n_owned) of the caller's list (hns.h: hns_dist_partition_axis)
+        self.owned_ids = np.zeros(self.n_owned, dtype=np.int64)
+        if self.n_owned:
+            _raise(lib.hns_dist_owned_leaf_ids(self._ptr, self.owned_ids.ctypes.data))
+        self.partition_axis = int(lib.hns_dist_partition_axis(self._ptr))
+        self.first_owned = int(lib.hns_dist_first_owned_leaf(self._ptr)) if self.partition_axis < 0 else -1
+
+    def owned_voxels(self, a: np.ndarray) -> np.ndarray:
+        """rows of a per-voxel global array (n_global * 512 [, c]) that belong to this rank's leaves, in upload / download order"""
+        a = np.asarray(a)
+        return np.ascontiguousarray(a.reshape((self.n_global, LEAF_VOXELS) + a.shape[1:])[self.owned_ids].reshape((-1,) + a.shape[1:]))
 
     # ---- plan ----
     def info(self) -> Dict:
         s = _lib.hns_dist_stats()
         _raise(lib.hns_dist_info(self._ptr, C.byref(s)))
-        return {"world": s.world, "rank": s.rank, "peers": s.peers, "sweeps_per_exchange": s.sweeps_per_exchange, "boundary_leaves": int(s.boundary_leaves),
+        return {"world": s.world, "rank": s.rank, "peers": s.peers, "halo_peers": int(s.halo_peers), "sweeps_per_exchange": s.sweeps_per_exchange, "boundary_leaves": int(s.boundary_leaves),
                 "interior_leaves": int(s.interior_leaves), "ghost_leaves": int(s.ghost_leaves),
                 "region_voxels_sent": dict(zip(REGION_TYPES, [int(x) for x in s.region_voxels_sent])),
                 "bytes_sent": dict(zip(REGION_TYPES, [int(x) for x in s.bytes_sent])), "messages_sent": int(s.messages_sent), "exchanges": int(s.exchanges)}
@@ -175,7 +202,7 @@ class DistRank:
 
     # ---- data ----
     def upload(self, vel: np.ndarray, scalars: Sequence[np.ndarray], stream: int = 0) -> None:
-        """Host arrays over the OWNED leaves in ascending global order."""
+        """Host arrays over the OWNED leaves in the order of `owned_ids`."""
         vel = np.ascontiguousarray(vel, dtype=np.float32)
         sc = [np.ascontiguousarray(s, dtype=np.float32) for s in scalars]
         assert vel.size == self.n_owned * LEAF_VOXELS * 3 and len(sc) == self.n_scalars and all(s.size == self.n_owned * LEAF_VOXELS for s in sc)
@@ -329,16 +356,18 @@ class SlabBench:
         self.iterations, self.dt, self.vs = iterations, dt, 1.0 / R  # same voxel size (and omega) as the single-GPU workload
         self.stream = int(torch.cuda.current_stream().cuda_stream)
         self.transport_note = "no peers" if world == 1 else transport
-        first, count = int(partition_bounds(len(glob), world)[rank]), int(np.diff(partition_bounds(len(glob), world))[rank])
-        own = glob[first:first + count].copy()
-        if not partition:
-            own[:, 0] %= R
-        f = fields.synthetic_fields(own, R)
-        self._fields = (f["vel"], [f["density"]])
 
         def make(k):
             return DistRank(glob, world, rank, self.vs, n_scalars=1, sweeps_per_exchange=k)
 
+        plan = DistRank(glob, world, rank, self.vs, n_scalars=1, plan_only=True)  # (which leaves are this rank's: the library's rule, not restated here)
+        self._owned_ids = plan.owned_ids.copy()
+        plan.close()
+        own = glob[self._owned_ids].copy()
+        if not partition:
+            own[:, 0] %= R
+        f = fields.synthetic_fields(own, R)
+        self._fields = (f["vel"], [f["density"]])
         self._glob, self._world = glob, world
         if world > 1 and connect and transport == "auto":
             self.rank_obj = self._verified_one_sided(make, sweeps_per_exchange, reference_transport)
@@ -348,14 +377,14 @@ class SlabBench:
             if world > 1 and connect:
                 self.rank_obj.connect_ipc() if transport == "ipc" else self.rank_obj.connect_rccl()
         self.rank_obj.upload(*self._fields)
-        self._glob, self._R, self._partition, self._first, self._count, self._world = glob, R, partition, first, count, world
+        self._glob, self._R, self._partition, self._world = glob, R, partition, world
         self.verified_note = "single GPU" if world == 1 else "not checked"
 
     @staticmethod
     def _one_sided_k(n_leaves: int, world: int) -> int:
-        """sweeps_per_exchange of the chained one-sided substep: 2 = the temporally blocked sweep, two iterations per chained launch,
-        where every rank's owned range is swept in 16^3 blocks (more than 600 leaves per rank: hns_dist.hip blocked_mirror); else 1."""
-        return 2 if n_leaves // max(1, world) > 600 else 1
+        """sweeps_per_exchange of the chained one-sided substep: 2 = the temporally blocked sweep, two iterations per chained launch, where the library
+        sweeps every rank's owned range in 16^3 blocks; else 1. The library's own rule (hns_dist_one_sided_sweeps), not a copy of it."""
+        return int(lib.hns_dist_one_sided_sweeps(int(n_leaves), int(world)))
 
     def verify_against_single_gpu(self, substeps: int = 2, max_voxels: int = 600_000_000) -> bool:
         """Every rank computes `substeps` substeps of the WHOLE domain on its own GPU with the single-GPU path (the same on every rank, bit
@@ -392,8 +421,7 @@ class SlabBench:
             for _ in range(substeps):
                 sim.core_substep(self.iterations, self.dt, self.vs, self.stream)
             sim.download(arrays)
-            sl = slice(self._first * LEAF_VOXELS, (self._first + self._count) * LEAF_VOXELS)
-            same = np.array_equal(got["vel"], arrays["vel"][sl]) and np.array_equal(got["scalars"][0], arrays["density"][sl])
+            same = np.array_equal(got["vel"], d.owned_voxels(arrays["vel"])) and np.array_equal(got["scalars"][0], d.owned_voxels(arrays["density"]))
             sim.close()
         except Exception as e:  # noqa: BLE001
             same, why = False, f" [the check failed on a rank: {type(e).__name__}: {e}]"[:200]

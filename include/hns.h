@@ -195,13 +195,21 @@ typedef struct { /* CombustionParams, src/Cuda/Kernels.cuh:6-13 */
 int hns_compute_sim(hns_grid*, hns_field* fields, int n_fields, int iterations, float dt, float voxel_size,
                     const hns_combustion_params* params, int has_collision, void* stream);
 /* The same cook when the caller feeds the previous cook's output straight back in -- what the reference's SOP does with its first
- * input (src/SOP/HNanoSolver/SOP_HNanoSolver.cpp:106: the "feedback" VDBs of frame n are frame n+1's state): resident[i] != 0 vouches
- * that fields[i].host still holds, untouched, what the previous hns_compute_sim(_resident) on this grid handed back for the block of
- * that name. Such a field is not uploaded again: the device buffer it was downloaded from still holds it (the cook cache keeps
- * operator state with the grid, "cook_cache"). The promise is checked, not trusted: a signature of the array (its size and 4,096
- * evenly spread elements) is compared with the one taken when it was handed back, and the field is uploaded as usual when they differ,
- * when the topology changed, or when another operator used the state in between. resident == NULL: hns_compute_sim. *uploads_skipped
- * (may be NULL) receives the number of fields that stayed on the device. Results are bit-identical to hns_compute_sim. */
+ * input (src/SOP/HNanoSolver/SOP_HNanoSolver.cpp:106: the "feedback" VDBs of frame n are frame n+1's state). resident[i] != 0 says that
+ * fields[i].host still holds, untouched, what the previous hns_compute_sim(_resident) on this grid handed back for the block of that name;
+ * such a field is not uploaded again: the device buffer it was downloaded from still holds it (the cook cache keeps operator state with
+ * the grid, "cook_cache"). Two strengths:
+ *   resident[i] = 1  VOUCHED. The caller knows what it changed (the SOP adds its sources itself, SOP_HNanoSolver.cpp:159-179: a block it
+ *                    sourced into must NOT be flagged). The library only trips on gross mistakes: a signature of the array (its size and
+ *                    4,096 evenly spread elements) must match the one taken when it was handed back. A sparse edit that misses the samples
+ *                    is NOT detected and that field would silently stay stale on the device.
+ *   resident[i] = 2  CHECKED. A 64-bit digest of EVERY element (taken when the array was handed back by a call that asked for it, taken
+ *                    again now, on up to 8 host threads) must match as well: any edit is noticed and the field uploaded. Costs one pass
+ *                    over the array at each end of the cook (256^3: ~5 ms for all fields, against ~10 ms for uploading them); the first
+ *                    cook that asks finds no digest to compare with and uploads.
+ * Either way the field is uploaded as usual when the check fails, when the topology changed, or when another operator used the state in
+ * between. resident == NULL: hns_compute_sim. *uploads_skipped (may be NULL) receives the number of fields that stayed on the device.
+ * Results are bit-identical to hns_compute_sim whenever the promise holds. */
 int hns_compute_sim_resident(hns_grid*, hns_field* fields, int n_fields, const unsigned char* resident, int* uploads_skipped, int iterations, float dt,
                              float voxel_size, const hns_combustion_params* params, int has_collision, void* stream);
 /* AdvectIndexGrid: every float field through the single-field BFECC kernel (advect_scalar), no collision. */
@@ -270,7 +278,13 @@ int hns_dev_rbgs_color(hns_grid*, const float* div, float* p, float dx, float om
  * WHICH BUFFER HOLDS THE RESULT IS NOT A FUNCTION OF `iterations`: *result_in_b is 1 when it is p_b, 0 when it is p_a
  * (e.g. blocked form: iterations = 2 -> p_b, 4 -> p_b or p_a, 6 -> p_b or p_a). A caller that wants the result must pass
  * result_in_b and read it (NULL is accepted from callers that only time the solve). The other buffer holds an intermediate
- * iterate. p_a and p_b must not alias. */
+ * iterate. p_a and p_b must not alias.
+ * On a grid with a LAUNCH RANGE (hns_grid_set_active_range / _leaves: a multi-GPU rank's boundary / interior / owned leaves) only the leaves
+ * of the range are written, and the statement above holds for ONE launch: a temporally blocked launch advances the leaves outside the range
+ * inside its tiles instead of reading them as fixed, so its result on the range equals what a WHOLE-grid sweep leaves there -- provided p within
+ * 2K voxels of the range and div within 2K - 1 are current in the leaves outside it (K = iterations per launch, hns_grid_rbgs_plan). A second
+ * launch reads the other buffer, whose out-of-range leaves the first never wrote: the caller must refresh those voxels in BOTH buffers between
+ * launches (hns_dist does: an exchange, or its peers' mirror stores, after every launch). With nothing refreshing them, use one launch per call. */
 int hns_dev_rbgs_iterate(hns_grid*, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int* result_in_b,
                          void* stream);
 /* subtractPressureGradient(_opt) (Kernel.cu:694-829); out3 may alias vel3 (each voxel reads only its own velocity) */
@@ -296,7 +310,7 @@ int hns_dev_unpack_leaves(const float* packed, const int32_t* leaf_ids, uint64_t
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Leaf-partitioned multi-GPU core substep (new: the reference is single-GPU). One hns_dist per rank = per GPU.      */
-/* Rank r owns leaves [n*r/world, n*(r+1)/world) of the global leaf list (NanoVDB order: x-slabs for box domains), */
+/* Rank r owns the r-th of `world` equal ranges of the global leaf list in slab order (hns_dist_partition_axis below), */
 /* keeps one layer of ghost leaves and refreshes exactly the ghost voxels the next kernel can read (hns_dist.hip). */
 /* Owned results are bit-identical to the single-domain hns_sim_core_substep -- as long as every tap of an advection   */
 /* back-trace that leaves the 27-leaf neighbourhood of its voxel's leaf (|u| dt / dx above ~8 voxels) still lands in   */
@@ -316,12 +330,15 @@ typedef struct {
 	uint64_t region_voxels_sent[4]; /* voxels this rank sends per exchange of that type (a property of the plan)   */
 	uint64_t bytes_sent[4];         /* payload bytes this rank sent during the last substep                          */
 	uint64_t messages_sent, exchanges; /* point-to-point messages / exchange rounds of the last substep              */
+	uint64_t halo_peers; /* peers this rank exchanges div / p / reach-1 halo voxels with (slab partition: the rank before and the rank behind it);
+	                        `peers` also counts ranks it only shares the element-0 mirror of the caller's leaf 0 with (its owner: every rank) */
 } hns_dist_stats;
 
 /* sweeps_per_exchange (1..4, 0 = default 4): the pressure loop refreshes the ghosts of p after every k-th fused sweep and
  * sweeps the ghost leaves locally in between. n_scalars float fields are advected (the metric's core substep uses 1). */
 #define HNS_DIST_DEFAULT 0u
 #define HNS_DIST_PLAN_ONLY 1u /* build the partition plan on the host only (inspection / CPU tests); compute calls then fail */
+#define HNS_DIST_LEAF_ORDER 2u /* rank r owns leaves [n*r/world, n*(r+1)/world) of the caller's list whatever the domain (the rule of rounds 1-4) */
 hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_leaves, int world, int rank, float voxel_size, int n_scalars,
                           int sweeps_per_exchange, unsigned flags, int* err);
 void hns_dist_destroy(hns_dist*);
@@ -347,7 +364,18 @@ int hns_dist_connect_loopback(hns_dist*);
  * multi-rank path issues): what a single-GPU box can check of the RCCL path. Leaves what the copy-based loopback leaves. */
 int hns_dist_connect_loopback_rccl(hns_dist*);
 uint64_t hns_dist_owned_leaves(const hns_dist*);
-uint64_t hns_dist_first_owned_leaf(const hns_dist*); /* global id of the first owned leaf; owned leaves are contiguous */
+/* Which leaves a rank owns (round 5): the leaves in SLAB order -- by leaf coordinate along the axis whose cuts cross the fewest leaves, the
+ * caller's order inside a plane -- cut into `world` equal ranges, so that a rank exchanges halos with the rank before and the rank behind
+ * it only (BASELINE config 5 in 8 ranks: 2 halo peers instead of 7). Where the x cut selects the same leaf sets as contiguous ranges of the
+ * caller's list (box domains made of whole 128-voxel NanoVDB nodes per rank) the caller's order is kept: hns_dist_partition_axis = -1 and
+ * hns_dist_first_owned_leaf = the first leaf of the contiguous run. Otherwise hns_dist_partition_axis = 0 / 1 / 2, hns_dist_first_owned_leaf
+ * = ~0, and hns_dist_owned_leaf_ids lists the owned leaves (positions in the caller's list) in the order hns_dist_upload / _download expect. */
+uint64_t hns_dist_first_owned_leaf(const hns_dist*);
+int hns_dist_owned_leaf_ids(const hns_dist*, int64_t* out_global_ids); /* hns_dist_owned_leaves entries */
+int hns_dist_partition_axis(const hns_dist*);
+/* sweeps_per_exchange to create the ranks with for the chained one-sided substep (ipc / local transports) of `world` ranks over n_leaves leaves: 2 = the
+ * temporally blocked chained sweep, two iterations per launch, where every rank's range is large enough for 16^3 blocks under the current options; else 1 */
+int hns_dist_one_sided_sweeps(uint64_t n_leaves, int world);
 int hns_dist_info(const hns_dist*, hns_dist_stats* out);
 /* The plan (also on PLAN_ONLY handles): global id of every local leaf in local order [boundary | interior | ghosts]; the
  * rank of peer i (-1 beyond the last); and per peer, halo region type (0..3 as in hns_dist_stats) and direction the
@@ -355,7 +383,7 @@ int hns_dist_info(const hns_dist*, hns_dist_stats* out);
 int hns_dist_local_leaves(const hns_dist*, int64_t* out_global_ids);
 int hns_dist_peer_rank(const hns_dist*, int peer);
 int hns_dist_peer_region(const hns_dist*, int peer, int type, int is_send, int32_t* leaves, unsigned char* masks, uint64_t* n_leaves, uint64_t* n_voxels);
-/* Host arrays over the OWNED leaves in ascending global order (vel3: 512*3 floats per leaf, each scalar 512 per leaf).
+/* Host arrays over the OWNED leaves in the order of hns_dist_owned_leaf_ids (vel3: 512*3 floats per leaf, each scalar 512 per leaf).
  * Collective in effect: every rank uploads before the next substep (the first exchange then carries the new fields).
  * Synchronous. download: any pointer may be NULL; `pressure` receives the last solve's p. */
 int hns_dist_upload(hns_dist*, const float* vel3, const float* const* scalars, void* stream);

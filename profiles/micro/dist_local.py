@@ -19,7 +19,7 @@ glob = origins if partition else HD.slab_domain(origins, R, world)
 ranks = [HD.DistRank(glob, world, r, vs, n_scalars=1, sweeps_per_exchange=k) for r in range(world)]
 HD.DistRank.connect_local(ranks)
 for d in ranks:
-    own = glob[d.first_owned:d.first_owned + d.n_owned].copy()
+    own = glob[d.owned_ids].copy()
     if not partition:
         own[:, 0] %= R
     g = fields.synthetic_fields(own, R)

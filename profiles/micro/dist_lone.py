@@ -23,7 +23,7 @@ vs, iters, dt, n = 1.0 / R, 50, 1.0 / 24.0, 10
 glob = origins if partition else HD.slab_domain(origins, R, world)
 d = HD.DistRank(glob, world, rank, vs, n_scalars=1, sweeps_per_exchange=k)
 d.connect_loopback()
-own = glob[d.first_owned:d.first_owned + d.n_owned].copy()
+own = glob[d.owned_ids].copy()
 if not partition:
     own[:, 0] %= R
 g = fields.synthetic_fields(own, R)

@@ -4,6 +4,7 @@ hns_dist (every rank in this process, a message = a device copy out of the peer'
 unpack kernels, communication stream and events exactly as with RCCL).
 
   argv: config (256 | 128 | plume1024 ...)  world  [sweeps_per_exchange]   [--partition: split ONE config domain]
+        [--leaf-order: contiguous ranges of the leaf list, the partition of rounds 1-4]  [--rank=N: the rank measured alone]
 
 Weak scaling (default): `world` slabs of the config stacked along x. All ranks share the device, so the device time of a
 lockstep substep is compared with world x the plain single-GPU substep of one slab: their ratio is the per-rank overhead
@@ -23,6 +24,8 @@ config = args[0] if args else "256"
 world = int(args[1]) if len(args) > 1 else 2
 k = int(args[2]) if len(args) > 2 else 0
 partition = "--partition" in sys.argv
+leaf_order = "--leaf-order" in sys.argv
+pick = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--rank=")]
 iters, dt = 50, 1.0 / 24.0
 origins, R = fields.config_leaves(config)
 vs = 1.0 / R
@@ -48,19 +51,19 @@ single = timed(lambda: sim.core_substep(iters, dt, vs, st))
 sim.close()
 
 glob = origins if partition else HD.slab_domain(origins, R, world)
-ranks = [HD.DistRank(glob, world, r, vs, n_scalars=1, sweeps_per_exchange=k) for r in range(world)]
+ranks = [HD.DistRank(glob, world, r, vs, n_scalars=1, sweeps_per_exchange=k, leaf_order=leaf_order) for r in range(world)]
 HD.DistRank.connect_local(ranks)
 for d in ranks:
-    own = glob[d.first_owned:d.first_owned + d.n_owned].copy()
+    own = glob[d.owned_ids].copy()
     if not partition:
         own[:, 0] %= R
     g = fields.synthetic_fields(own, R)
     d.upload(g["vel"], [g["density"]])
 # one rank alone, its messages looped back to itself (wrong data, right sizes): the production structure of one GPU's work
-lone_rank = 0 if world < 3 else world // 2  # a rank with neighbours on both sides where there is one
-lone = HD.DistRank(glob, world, lone_rank, vs, n_scalars=1, sweeps_per_exchange=k)
+lone_rank = pick[0] if pick else (0 if world < 3 else world // 2)  # a rank with neighbours on both sides where there is one
+lone = HD.DistRank(glob, world, lone_rank, vs, n_scalars=1, sweeps_per_exchange=k, leaf_order=leaf_order)
 lone.connect_loopback()
-own = glob[lone.first_owned:lone.first_owned + lone.n_owned].copy()
+own = glob[lone.owned_ids].copy()
 if not partition:
     own[:, 0] %= R
 g = fields.synthetic_fields(own, R)
@@ -90,10 +93,10 @@ torch.cuda.synchronize()
 info = [d.info() for d in ranks]
 work = single if partition else world * single
 print(json.dumps({
-    "config": config, "world": world, "partition": partition, "sweeps_per_exchange": info[0]["sweeps_per_exchange"],
+    "config": config, "world": world, "partition": partition, "partition_axis": ranks[0].partition_axis, "sweeps_per_exchange": info[0]["sweeps_per_exchange"],
     "single_gpu_substep_ms": round(single, 3), "all_ranks_lockstep_ms": round(lock, 3), "same_work_on_one_grid_ms": round(work, 3),
     "lockstep_overhead": round(lock / work - 1.0, 4), "lockstep_host_enqueue_ms_per_rank_per_substep": round(enqueue, 3),
-    "one_rank_loopback": {"rank": lone_rank, "owned_leaves": alone_info["boundary_leaves"] + alone_info["interior_leaves"], "substep_ms": round(alone, 3), "pressure_us_per_iteration": round(alone_us_per_iteration, 2),
+    "one_rank_loopback": {"rank": lone_rank, "peers": alone_info["peers"], "halo_peers": alone_info["halo_peers"], "boundary_leaves": alone_info["boundary_leaves"], "ghost_leaves": alone_info["ghost_leaves"], "owned_leaves": alone_info["boundary_leaves"] + alone_info["interior_leaves"], "substep_ms": round(alone, 3), "pressure_us_per_iteration": round(alone_us_per_iteration, 2),
                           "host_enqueue_ms": round(alone_enqueue, 3),
                           "overhead_vs_single_gpu_per_leaf": round((alone / (alone_info["boundary_leaves"] + alone_info["interior_leaves"])) / (single / len(origins) * (world if partition else 1)) - 1.0, 4)},
     "rank0": {x: info[0][x] for x in ("boundary_leaves", "interior_leaves", "ghost_leaves", "peers", "exchanges", "messages_sent", "bytes_sent")},

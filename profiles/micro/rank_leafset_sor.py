@@ -14,7 +14,7 @@ ranks = [int(a) for a in sys.argv[3:]] or list(range(world))
 origins, R = fields.config_leaves(config)
 for rank in ranks:
     d = HD.DistRank(origins, world, rank, 1.0 / R, n_scalars=1, sweeps_per_exchange=1)
-    own = origins[d.first_owned:d.first_owned + d.n_owned].copy()
+    own = origins[d.owned_ids].copy()
     del d
     own = np.ascontiguousarray(own[fields.nanovdb_order(own)])
     grid = api.create_grid_from_leaves(own, 1.0 / R)

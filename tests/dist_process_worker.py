@@ -48,12 +48,10 @@ def main():
     try:
         origins, R = case_leaves(case)
         names = ["density", "temperature"]
-        b = HD.partition_bounds(len(origins), world)
         full = fields.synthetic_fields(origins, R)
-        sl = slice(b[rank] * 512, b[rank + 1] * 512)
         d = HD.DistRank(origins, world, rank, 1.0 / R, n_scalars=len(names), sweeps_per_exchange=k)
         d.connect_ipc()
-        d.upload(full["vel"][sl], [full[n][sl] for n in names])
+        d.upload(d.owned_voxels(full["vel"]), [d.owned_voxels(full[n]) for n in names])
         stream = int(torch.cuda.current_stream().cuda_stream)
         dist.barrier()
         for _ in range(substeps):

@@ -45,18 +45,19 @@ class ReferenceRank:
         self.ranges = {"B": (0, self.nB), "I": (self.nB, self.nB + self.nI), "A": (0, len(self.local_global))}
 
     def load_owned(self, vel, scalars):
-        """owned leaves in ascending global order -> local order [B | I]"""
-        first = int(self.local_global[: self.nB + self.nI].min()) if self.nB + self.nI else 0
+        """owned leaves in upload order (DistRank.owned_ids) -> local order [B | I]"""
+        where = {int(g): i for i, g in enumerate(self.plan.owned_ids.tolist())}
         for l in range(self.nB + self.nI):
-            src = int(self.local_global[l]) - first
+            src = where[int(self.local_global[l])]
             self.u[l * 512:(l + 1) * 512] = vel[src * 512:(src + 1) * 512]
             for s, a in zip(self.phi, scalars):
                 s[l * 512:(l + 1) * 512] = a[src * 512:(src + 1) * 512]
 
     def owned(self, a):
-        """local [B | I] -> ascending global order"""
+        """local [B | I] -> download order (DistRank.owned_ids)"""
         n = self.nB + self.nI
-        order = np.argsort(self.local_global[:n], kind="stable")
+        local_of = {int(g): l for l, g in enumerate(self.local_global[:n].tolist())}
+        order = [local_of[int(g)] for g in self.plan.owned_ids.tolist()]
         return np.concatenate([a[l * 512:(l + 1) * 512] for l in order]) if n else a[:0]
 
     def _put(self, dst, full, rng):

@@ -32,28 +32,51 @@ def brute_neighbors(o):
     return nbr
 
 
+@pytest.mark.parametrize("leaf_order", [False, True])
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 @pytest.mark.parametrize("k", [1, 2, 4])
-def test_plan_properties(world, k):
+def test_plan_properties(world, k, leaf_order):
+    """both partitions: slabs along the cheapest axis (round 5) and contiguous ranges of the caller's list (HNS_DIST_LEAF_ORDER)"""
     o = random_leaves()
     n = len(o)
     nbr = brute_neighbors(o)
     bounds = HD.partition_bounds(n, world)
-    owner = np.searchsorted(bounds, np.arange(n), side="right") - 1
-    ranks = [HD.DistRank(o, world, r, 1.0 / 64, 2, k, plan_only=True) for r in range(world)]
+    ranks = [HD.DistRank(o, world, r, 1.0 / 64, 2, k, plan_only=True, leaf_order=leaf_order) for r in range(world)]
+    # the partition: every leaf owned once, equal shares, the same axis on every rank; slabs: sorted along that axis, the caller's order inside a plane
+    part = np.concatenate([d.owned_ids for d in ranks])
+    assert sorted(part.tolist()) == list(range(n)) and [d.n_owned for d in ranks] == np.diff(bounds).tolist()
+    axis = ranks[0].partition_axis
+    assert all(d.partition_axis == axis for d in ranks)
+    if leaf_order or world == 1:
+        assert axis == -1
+    if axis < 0:
+        assert part.tolist() == list(range(n))
+    else:  # slabs: rank r's leaves lie before rank r+1's along the axis (a plane two ranks share is split by the caller's order); inside a rank: the caller's order
+        for r, d in enumerate(ranks):
+            assert (np.diff(d.owned_ids) > 0).all()
+            if r + 1 < world and d.n_owned and ranks[r + 1].n_owned:
+                a, b2 = o[d.owned_ids, axis], o[ranks[r + 1].owned_ids, axis]
+                assert a.max() <= b2.min()
+                if a.max() == b2.min():
+                    assert d.owned_ids[a == a.max()].max() < ranks[r + 1].owned_ids[b2 == b2.min()].min()
+    owner = np.empty(n, dtype=np.int64)
+    ppos = np.empty(n, dtype=np.int64)  # position in partition order
+    for r, d in enumerate(ranks):
+        owner[d.owned_ids] = r
+    ppos[part] = np.arange(n)
     plans = [(d.info(), d.local_leaves(), d.peers()) for d in ranks]
     depth = [99, 1, 2 * k - 1, 2 * k]
     vox = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij"), -1).reshape(-1, 3)  # x<<6|y<<3|z order
     for r, (info, loc, peers) in enumerate(plans):
         nB, nI, nG = info["boundary_leaves"], info["interior_leaves"], info["ghost_leaves"]
-        owned = np.arange(bounds[r], bounds[r + 1])
-        assert ranks[r].n_owned == len(owned) and (len(owned) == 0 or ranks[r].first_owned == owned[0])
-        assert sorted(loc[: nB + nI].tolist()) == owned.tolist()
+        owned = ranks[r].owned_ids
+        assert ranks[r].first_owned == (-1 if axis >= 0 else (int(owned[0]) if len(owned) else 0))
+        assert sorted(loc[: nB + nI].tolist()) == sorted(owned.tolist())
         # boundary = owned leaves another rank mirrors (+ global leaf 0 on its owner, mirrored everywhere)
         nb_owner = np.where(nbr[owned] >= 0, owner[np.maximum(nbr[owned], 0)], r)
         is_b = (nb_owner != r).any(axis=1)
         if world > 1 and r == owner[0]:
-            is_b[0] = True
+            is_b[owned == 0] = True
         assert loc[:nB].tolist() == owned[is_b].tolist() and loc[nB:nB + nI].tolist() == owned[~is_b].tolist()
         ghosts = set(nbr[owned].reshape(-1).tolist()) - set(owned.tolist()) - {-1}
         if world > 1 and r != owner[0]:
@@ -61,8 +84,8 @@ def test_plan_properties(world, k):
         assert set(loc[nB + nI:].tolist()) == ghosts and len(loc) == nB + nI + nG
         assert [p.rank for p in peers] == sorted(p.rank for p in peers)
         pos = nB + nI
-        for p in peers:  # ghosts grouped by owner, ascending global id inside a group
-            mine = sorted(g for g in ghosts if owner[g] == p.rank)
+        for p in peers:  # ghosts grouped by owner, in partition order inside a group
+            mine = sorted((g for g in ghosts if owner[g] == p.rank), key=lambda g: ppos[g])
             assert loc[pos:pos + len(mine)].tolist() == mine
             pos += len(mine)
             # what I send to p is exactly what p expects from me: same leaves (global ids), same masks, same order
@@ -116,9 +139,8 @@ def _worker(rank, world, port, name, iters, k, out_dir):
         origins, R = _case(name)
         f = fields.synthetic_fields(origins, R)
         rr = ReferenceRank(origins, world, rank, 1.0 / R, 2, k, poison=7.0)  # ghosts start WRONG: the first exchange must repair them
-        b = HD.partition_bounds(len(origins), world)
-        sl = slice(b[rank] * 512, b[rank + 1] * 512)
-        rr.load_owned(f["vel"][sl], [f["density"][sl], f["temperature"][sl]])
+        ids = rr.plan.owned_ids
+        rr.load_owned(HD.take_leaves(f["vel"], ids), [HD.take_leaves(f["density"], ids), HD.take_leaves(f["temperature"], ids)])
         for _ in range(2):
             rr.core_substep(iters, 1.0 / 24.0)
         rr.complete()  # the scalars posted for the NEXT substep: drain them before any rank hangs up
@@ -159,13 +181,12 @@ def test_partitioned_substep_is_bit_identical_to_single_domain(tmp_path, name, w
         p = G.rbgs_iterations(div, float(np.float32(vs)), omega, iters)
         u = G.subtract_pressure_gradient(adv, p, inv_dx)
         phi = G.advect_scalars(u, phi, dt, inv_dx)
-    b = HD.partition_bounds(len(origins), world)
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
-        sl = slice(b[r] * 512, b[r + 1] * 512)
-        assert np.array_equal(z["u"], u[sl]), f"rank {r} velocity"
-        assert np.array_equal(z["p"], p[sl]), f"rank {r} pressure"
-        assert np.array_equal(z["phi0"], phi[0][sl]) and np.array_equal(z["phi1"], phi[1][sl]), f"rank {r} scalars"
+        ids = HD.owned_ids_of(origins, world, r)
+        assert np.array_equal(z["u"], HD.take_leaves(u, ids)), f"rank {r} velocity"
+        assert np.array_equal(z["p"], HD.take_leaves(p, ids)), f"rank {r} pressure"
+        assert np.array_equal(z["phi0"], HD.take_leaves(phi[0], ids)) and np.array_equal(z["phi1"], HD.take_leaves(phi[1], ids)), f"rank {r} scalars"
         assert z["bytes_sent"] > 0
 
 
@@ -202,9 +223,8 @@ def _sim_worker(rank, world, port, name, iters, k, coll, fs, out_dir):
     try:
         origins, R, f = _sim_inputs(name)
         rr = ReferenceRank(origins, world, rank, 1.0 / R, len(SIM_NAMES), k, poison=7.0)
-        b = HD.partition_bounds(len(origins), world)
-        sl = slice(b[rank] * 512, b[rank + 1] * 512)
-        rr.load_owned(f["vel"][sl], [f[n][sl] for n in SIM_NAMES])
+        ids = rr.plan.owned_ids
+        rr.load_owned(HD.take_leaves(f["vel"], ids), [HD.take_leaves(f[n], ids) for n in SIM_NAMES])
         for _ in range(2):
             rr.sim_substep(SIM_NAMES, iters, 1.0 / 24.0, _sim_params(fs), coll)
         rr.complete()
@@ -233,13 +253,12 @@ def test_partitioned_compute_sim_walk_is_bit_identical_to_single_domain(tmp_path
     for _ in range(2):
         assert G.compute_sim(u, phi, iters, 1.0 / 24.0, 1.0 / R, _sim_params(fs), coll) == 0
         phi["collision_sdf"][:] = sdf0  # the reference's driver hands the SDF back zeroed (HNanoSolver.cu:364-369); the device-resident state keeps it
-    b = HD.partition_bounds(len(origins), world)
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
-        sl = slice(b[r] * 512, b[r + 1] * 512)
-        assert np.array_equal(z["u"], u[sl]), f"rank {r} velocity"
+        ids = HD.owned_ids_of(origins, world, r)
+        assert np.array_equal(z["u"], HD.take_leaves(u, ids)), f"rank {r} velocity"
         for n in SIM_NAMES:
-            assert np.array_equal(z[n], phi[n][sl]), f"rank {r} {n}"
+            assert np.array_equal(z[n], HD.take_leaves(phi[n], ids)), f"rank {r} {n}"
 
 
 def test_ghost_digest_comparison_names_the_pair_that_differs():

@@ -32,10 +32,9 @@ def run_local(origins, R, world, k, names, iters, substeps, dt=1.0 / 24.0):
     f = fields.synthetic_fields(origins, R)
     ranks = [HD.DistRank(origins, world, r, 1.0 / R, n_scalars=len(names), sweeps_per_exchange=k) for r in range(world)]
     HD.DistRank.connect_local(ranks)
-    b = HD.partition_bounds(len(origins), world)
+    b = None  # (which leaves a rank owns is the rank's own knowledge: DistRank.owned_ids / owned_voxels)
     for r, d in enumerate(ranks):
-        sl = slice(b[r] * 512, b[r + 1] * 512)
-        d.upload(f["vel"][sl], [f[n][sl] for n in names])
+        d.upload(d.owned_voxels(f["vel"]), [d.owned_voxels(f[n]) for n in names])
     stream = int(torch.cuda.current_stream().cuda_stream)
     for _ in range(substeps):
         HD.DistRank.local_core_substep(ranks, iters, dt, stream)
@@ -50,10 +49,9 @@ def check(ranks, b, want, names):
     assert not bad and (n_pairs > 0 or len(ranks) == 1), (n_pairs, bad[:3])
     for r, d in enumerate(ranks):
         got = d.download()
-        sl = slice(b[r] * 512, b[r + 1] * 512)
-        assert np.array_equal(got["vel"], want["vel"][sl]), f"rank {r} velocity"
+        assert np.array_equal(got["vel"], d.owned_voxels(want["vel"])), f"rank {r} velocity"
         for n, a in zip(names, got["scalars"]):
-            assert np.array_equal(a, want[n][sl]), f"rank {r} {n}"
+            assert np.array_equal(a, d.owned_voxels(want[n])), f"rank {r} {n}"
 
 
 def scattered_leaves():
@@ -169,8 +167,7 @@ def test_new_fields_between_substeps_and_many_substeps():
 
     f = fields.synthetic_fields(origins, R)
     for r, d in enumerate(ranks):
-        sl = slice(b[r] * 512, b[r + 1] * 512)
-        d.upload(f["vel"][sl], [f["density"][sl]])
+        d.upload(d.owned_voxels(f["vel"]), [d.owned_voxels(f["density"])])
     stream = int(torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
         HD.DistRank.local_core_substep(ranks, iters, 1.0 / 24.0, stream)
@@ -226,9 +223,8 @@ def test_loopback_transport_two_stream_structure_terminates_and_repeats():
 def _loopback_run(origins, R, world, rank, k, rccl, substeps=2, iters=9):
     import torch
 
-    b = HD.partition_bounds(len(origins), world)
-    f = fields.synthetic_fields(origins[b[rank]:b[rank + 1]], R)
     d = HD.DistRank(origins, world, rank, 1.0 / R, n_scalars=1, sweeps_per_exchange=k)
+    f = fields.synthetic_fields(origins[d.owned_ids], R)
     d.connect_loopback(rccl=rccl)
     d.upload(f["vel"], [f["density"]])
     stream = int(torch.cuda.current_stream().cuda_stream)
@@ -306,12 +302,11 @@ def test_one_process_per_rank_over_mapped_peer_memory(case, world, k, iters, tmp
     names, substeps = ["density", "temperature"], 2
     _, want = single_grid(origins, R, names, iters, substeps)
     got = _run_processes(world, case, k, iters, substeps, tmp_path)
-    b = HD.partition_bounds(len(origins), world)
     for r, g in enumerate(got):
-        sl = slice(b[r] * 512, b[r + 1] * 512)
-        assert np.array_equal(g["vel"], want["vel"][sl]), f"rank {r} velocity"
+        ids = HD.owned_ids_of(origins, world, r)
+        assert np.array_equal(g["vel"], HD.take_leaves(want["vel"], ids)), f"rank {r} velocity"
         for n in names:
-            assert np.array_equal(g[n], want[n][sl]), f"rank {r} {n}"
+            assert np.array_equal(g[n], HD.take_leaves(want[n], ids)), f"rank {r} {n}"
         assert int(g["messages"]) > 0 or k == 1  # (k = 1: after the first substep every kernel delivers its own halo, no messages)
 
 
@@ -373,7 +368,7 @@ def test_unconnected_ranks_refuse_to_step():
 
     origins = fields.dense_leaves(16)
     d = HD.DistRank(origins, 2, 0, 1.0 / 16)
-    f = fields.synthetic_fields(origins[: d.n_owned], 16)
+    f = fields.synthetic_fields(origins[d.owned_ids], 16)
     d.upload(f["vel"], [f["density"]])
     with pytest.raises(H.HNSError):
         d.core_substep(3, 1.0 / 24.0)
@@ -405,14 +400,12 @@ def test_back_trace_beyond_the_ghost_layer_is_reported():
     origins = fields.dense_leaves(R)
     ranks = [HD.DistRank(origins, world, r, 1.0 / R, n_scalars=1, sweeps_per_exchange=4) for r in range(world)]
     HD.DistRank.connect_local(ranks)
-    b = HD.partition_bounds(len(origins), world)
     stream = int(torch.cuda.current_stream().cuda_stream)
 
     def upload(amplitude):
         f = fields.synthetic_fields(origins, R, amplitude_voxels=amplitude)
         for r, d in enumerate(ranks):
-            sl = slice(b[r] * 512, b[r + 1] * 512)
-            d.upload(f["vel"][sl], [f[n][sl] for n in names])
+            d.upload(d.owned_voxels(f["vel"]), [d.owned_voxels(f[n]) for n in names])
 
     upload(400.0)
     HD.DistRank.local_core_substep(ranks, iters, 1.0 / 24.0, stream)
@@ -472,10 +465,9 @@ def test_partitioned_compute_sim_matches_single_grid(name, world, k, coll, facto
 
     ranks = [HD.DistRank(origins, world, r, 1.0 / R, n_scalars=len(SIM_NAMES), sweeps_per_exchange=k) for r in range(world)]
     HD.DistRank.connect_local(ranks)
-    b = HD.partition_bounds(len(origins), world)
+    b = None
     for r, d in enumerate(ranks):
-        sl = slice(b[r] * 512, b[r + 1] * 512)
-        d.upload(f["vel"][sl], [f[n][sl] for n in SIM_NAMES])
+        d.upload(d.owned_voxels(f["vel"]), [d.owned_voxels(f[n]) for n in SIM_NAMES])
     stream = int(torch.cuda.current_stream().cuda_stream)
     for _ in range(substeps):
         HD.DistRank.local_sim_substep(ranks, SIM_NAMES, iters, dt, params, coll, stream)

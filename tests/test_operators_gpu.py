@@ -515,7 +515,7 @@ def test_feedback_cooks_keep_fields_on_the_device(collision):
     params = api.CombustionParams(factorScale=1.0, vorticityScale=0.3)
     names = ["density", "temperature", "fuel", "waste", "flame", "vel"]
 
-    def cooks(feedback, n=4, poke=None, project_before=None):
+    def cooks(feedback, n=4, poke=None, project_before=None, checked=True, poke_at=0):
         d = build_data(origins, R, with_sdf=collision)
         sdf = d.pValues("collision_sdf").copy() if collision else None
         h = api.IndexGridHandle()
@@ -525,30 +525,42 @@ def test_feedback_cooks_keep_fields_on_the_device(collision):
             if collision:
                 d.pValues("collision_sdf")[:] = sdf  # the SOP reads the collider every cook; Compute hands it back zeroed
             if poke == c:
-                d.pValues("density")[0] += 1.0  # element 0 is one of the signature's samples
+                d.pValues("density")[poke_at] += 1.0  # element 0 is one of the signature's samples, element 1 is not
             if project_before == c:
                 api.ProjectNonDivergent(d, 3, vs, handle=h)
-            skipped.append(api.Compute_Sim(d, h, iters, dt, vs, params, collision, feedback=feedback if c else None))
+            skipped.append(api.Compute_Sim(d, h, iters, dt, vs, params, collision, feedback=feedback if c else None, checked=checked))
         out = snapshot(d)
         h.reset()
         return out, skipped
 
     want, _ = cooks(None)
-    got, skipped = cooks(True)
-    assert skipped == [None, 6, 6, 6], skipped  # velocity + five float blocks stay on the device (the SDF goes up every cook)
+    got, skipped = cooks(True, checked=False)
+    assert skipped == [None, 6, 6, 6], skipped  # vouched: velocity + five float blocks stay on the device (the SDF goes up every cook)
     for n in names:
         assert np.array_equal(got[n], want[n]), n
-    got, skipped = cooks(["density", "vel", "fuel"])
+    got, skipped = cooks(True)
+    assert skipped == [None, 0, 6, 6], skipped  # checked: the first asking cook finds no digest to compare with and uploads; from then on as above
+    for n in names:
+        assert np.array_equal(got[n], want[n]), n
+    # a sparse edit that misses the 4,096 samples. CHECKED notices it (same bits as plain cooks); VOUCHED does not -- that is its contract
+    want, _ = cooks(None, poke=2, poke_at=1)
+    got, skipped = cooks(True, poke=2, poke_at=1)
+    assert skipped == [None, 0, 5, 6], skipped
+    for n in names:
+        assert np.array_equal(got[n], want[n]), n
+    _, skipped = cooks(True, poke=2, poke_at=1, checked=False)
+    assert skipped == [None, 6, 6, 6], skipped
+    got, skipped = cooks(["density", "vel", "fuel"], checked=False)
     assert skipped == [None, 3, 3, 3], skipped
     for n in names:
         assert np.array_equal(got[n], want[n]), n
     want, _ = cooks(None, poke=2)
-    got, skipped = cooks(True, poke=2)
-    assert skipped == [None, 6, 5, 6], skipped  # the changed array is noticed and uploaded
+    got, skipped = cooks(True, poke=2, checked=False)
+    assert skipped == [None, 6, 5, 6], skipped  # the changed array is noticed (element 0 is a sample) and uploaded
     for n in names:
         assert np.array_equal(got[n], want[n]), n
     want, _ = cooks(None, project_before=2)
-    got, skipped = cooks(True, project_before=2)
+    got, skipped = cooks(True, project_before=2, checked=False)
     assert skipped == [None, 6, 5, 6], skipped  # ProjectNonDivergent uploaded a velocity of its own into the shared state
     for n in names:
         assert np.array_equal(got[n], want[n]), n
