@@ -712,8 +712,8 @@ int make_sim(hns_grid* g, const FieldSplit& fs, SimGuard& guard, void* stream) {
 //    against handing in a different array, NOT a check of the promise -- an edit that misses the samples (an emitter added to a few leaves) passes.
 //    resident[i] = 1 ("vouched") relies on the caller knowing what it changed, as the reference's SOP does (it adds its sources itself,
 //    SOP_HNanoSolver.cpp:159-179, and must not flag a field it sourced into);
-//  * the FULL digest: every element, 64-bit multiply-xor per 8 bytes over 1 MiB chunks on up to 8 host threads (memory-bound: ~5 ms for the 537 MB of a
-//    256^3 cook; an upload of the same is ~10 ms). resident[i] = 2 ("checked"): the skip is sound, at that price at both ends of the cook.
+//  * the FULL digest: every element, 64-bit multiply-xor per 8 bytes over 1 MiB chunks on up to 8 host threads (measured: ~5.5 ms per pass over the 537 MB of a
+//    256^3 cook). resident[i] = 2 ("checked"): the skip is sound, at that price at both ends of the cook -- 23.1 ms per cook against 19.8 plain and 11.8 vouched.
 // Neither is ever 0.
 static uint64_t host_signature(const float* a, size_t count) {
 	uint64_t h = 1469598103934665603ull ^ (uint64_t)count;

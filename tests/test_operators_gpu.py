@@ -515,7 +515,7 @@ def test_feedback_cooks_keep_fields_on_the_device(collision):
     params = api.CombustionParams(factorScale=1.0, vorticityScale=0.3)
     names = ["density", "temperature", "fuel", "waste", "flame", "vel"]
 
-    def cooks(feedback, n=4, poke=None, project_before=None, checked=True, poke_at=0):
+    def cooks(feedback, n=4, poke=None, project_before=None, checked=False, poke_at=0):
         d = build_data(origins, R, with_sdf=collision)
         sdf = d.pValues("collision_sdf").copy() if collision else None
         h = api.IndexGridHandle()
@@ -538,18 +538,19 @@ def test_feedback_cooks_keep_fields_on_the_device(collision):
     assert skipped == [None, 6, 6, 6], skipped  # vouched: velocity + five float blocks stay on the device (the SDF goes up every cook)
     for n in names:
         assert np.array_equal(got[n], want[n]), n
-    got, skipped = cooks(True)
+    got, skipped = cooks(True, checked=True)
     assert skipped == [None, 0, 6, 6], skipped  # checked: the first asking cook finds no digest to compare with and uploads; from then on as above
     for n in names:
         assert np.array_equal(got[n], want[n]), n
     # a sparse edit that misses the 4,096 samples. CHECKED notices it (same bits as plain cooks); VOUCHED does not -- that is its contract
     want, _ = cooks(None, poke=2, poke_at=1)
-    got, skipped = cooks(True, poke=2, poke_at=1)
+    got, skipped = cooks(True, poke=2, poke_at=1, checked=True)
     assert skipped == [None, 0, 5, 6], skipped
     for n in names:
         assert np.array_equal(got[n], want[n]), n
     _, skipped = cooks(True, poke=2, poke_at=1, checked=False)
     assert skipped == [None, 6, 6, 6], skipped
+    want, _ = cooks(None)
     got, skipped = cooks(["density", "vel", "fuel"], checked=False)
     assert skipped == [None, 3, 3, 3], skipped
     for n in names:
