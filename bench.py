@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--share-one-gpu", action="store_true",
                     help="builder's check on a 1-GPU box: all N ranks on cuda:0, host rendezvous over gloo, --transport ipc (RCCL refuses two ranks on one device)")
     ap.add_argument("--cook", action="store_true", help="time the cook-equivalent hns_compute_sim call (upload + grid build + substep + download) instead")
+    ap.add_argument("--full", action="store_true", help="time the FULL Compute_Sim substep instead (HNanoSolver.cu:150-356 on device-resident fields: five advected scalars, "
+                                                        "combustion, buoyancy; SURVEY 8d's 812 B/voxel row) and print its own JSON line; single GPU")
     ap.add_argument("--no-strong", action="store_true", help="default workload only: skip the second record `strong_scaling` (BASELINE config 5, the 1024^3-extent plume "
                                                               "as ONE domain over the N ranks)")
     return ap.parse_args()
@@ -311,6 +313,92 @@ def strong_scaling_record(args, world, rank, dt):
     return rec
 
 
+FULL_BYTES_PER_VOXEL = 812  # core 688 + vorticity 24 + combustion 40 + buoyancy 28 + four more advected scalars 4 x 8
+FULL_STAGE_BYTES = {"advect_vector": 24, "divergence": 16, "combustion_oxygen": 40, "temperature_buoyancy": 28, "pressure": BYTES_PER_VOXEL_ITER, "gradient": 28,
+                    "advect_scalars_S5": 12 + 8 * 5}
+
+
+def full_substep(args):
+    """The whole Compute_Sim substep a SOP cook runs (reference HNanoSolver.cu:150-356; SURVEY 8d's last row): advect_vector, [vorticity confinement:
+    an exact copy at the default factor_scale 0.5, skipped], divergence, combustion, buoyancy, 50 RB-SOR iterations, gradient subtraction, advect_scalars
+    over the five float fields -- on device-resident fields, K timed substeps between synchronisations. `kernels`: each stage's kernel launched on its own
+    after the timed region on the same arrays, bracketed by events on the launch stream (a stage alone finds its inputs warmer or colder in the Infinity
+    Cache than inside the substep; the rocprofv3 kernel statistics of this command, profiles/r05_full256_kernel_stats.csv, are the in-substep figures)."""
+    import torch
+
+    from hnanosolver_amd import api, device as D, fields
+
+    origins, R = fields.config_leaves(args.config)
+    vs, dt = 1.0 / R, 1.0 / 24.0
+    n_vox = len(origins) * 512
+    names = ["density", "temperature", "fuel", "waste", "flame"]
+    f = fields.synthetic_fields(origins, R)
+    grid = api.create_grid_from_leaves(origins, vs)
+    sim = D.Sim(grid, names)
+    sim.upload({"vel": f["vel"], **{n: f[n] for n in names}})
+    prm = api.CombustionParams(vorticityScale=0.0)  # SOP defaults, vorticityScale = 0 as SURVEY 8d prescribes for metric runs (factor_scale 0.5: a no-op either way)
+    stream = D.current_stream()
+
+    def step():
+        sim.substep(args.iterations, dt, vs, prm, False, stream)
+
+    sim.timing(args.steps)
+    elapsed = timed_steps(step, args.steps, args.warmup, 1, False)
+    p_ms, p_iters = sim.pressure_time()
+    ms = 1e3 * elapsed / args.steps
+    sor_form, sor_launches, _ = D.rbgs_plan(grid, args.iterations)
+
+    # every stage's kernel alone, on arrays of the same size
+    dev = "cuda"
+    u = torch.from_numpy(f["vel"]).to(dev)
+    u2, u3 = torch.empty_like(u), torch.empty_like(u)
+    sc = [torch.from_numpy(f[n]).to(dev) for n in names]
+    sc2 = [torch.empty_like(t) for t in sc]
+    div = torch.zeros(n_vox, device=dev)
+    p_a, p_b = torch.zeros(n_vox, device=dev), torch.zeros(n_vox, device=dev)
+    inv_dx = 1.0 / vs
+
+    def alone(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    stage_ms = {
+        "advect_vector": alone(lambda: D.advect_vector(grid, u, u2, dt, inv_dx)),
+        "divergence": alone(lambda: D.divergence(grid, u2, div, inv_dx)),
+        "combustion_oxygen": alone(lambda: D.combustion_oxygen(sc[2], sc[3], sc[1], div, sc[4], sc2[2], sc2[3], sc2[1], sc2[4], prm.temperatureRelease, prm.expansionRate)),
+        "temperature_buoyancy": alone(lambda: D.temperature_buoyancy(u2, sc2[1], u2, dt, prm.ambientTemp, prm.buoyancyStrength)),
+        "pressure": p_ms / max(1, args.steps),  # (inside the timed substeps: events around the pressure loops)
+        "gradient": alone(lambda: D.subtract_pressure_gradient(grid, u2, p_a, u3, inv_dx)),
+        "advect_scalars_S5": alone(lambda: D.advect_scalars(grid, u3, sc, sc2, dt, inv_dx)),
+    }
+    kernels = {}
+    for st, t_ms in stage_ms.items():
+        alg = FULL_STAGE_BYTES[st] * n_vox * (args.iterations if st == "pressure" else 1)
+        gbs = alg / (t_ms * 1e-3) / 1e9 if t_ms > 0 else None
+        kernels[st] = {"ms_per_substep": t_ms, "algorithmic_bytes": alg, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS if gbs else None,
+                       "share_of_substep": t_ms / ms, "timed": "inside the substeps" if st == "pressure" else "alone, after the timed region"}
+    sub_bytes = (FULL_BYTES_PER_VOXEL - 600 + 12 * args.iterations - 24) * n_vox  # (the vorticity pass, 24 B/voxel, is an exact copy at factor_scale < 1 and skipped)
+    gbs = sub_bytes / (ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "full Compute_Sim substeps/sec (advect + vorticity + combustion + buoyancy + 50 red-black SOR iterations + project + advect of 5 scalars) at N active voxels",
+        "value": args.steps / elapsed, "unit": "substeps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}^3 dense-active grid" if args.config.isdigit() else args.config, "active_voxels_per_gpu": n_vox, "pressure_iterations": args.iterations,
+                   "substep": "Compute_Sim order (HNanoSolver.cu:150-356), S = 5 advected scalars, combustion, buoyancy; vorticity confinement at factor_scale 0.5 is an exact copy and skipped",
+                   "algorithmic_bytes_per_voxel_substep": FULL_BYTES_PER_VOXEL - 600 + 12 * args.iterations - 24, "sor_form": sor_form},
+        "roofline": {"kernel": "whole substep", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_substep": sub_bytes, "pressure_ms_per_iteration": p_ms / max(1, p_iters), "kernel_launches_per_solve": sor_launches, "kernels": kernels},
+    }))
+    sim.close()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -343,6 +431,11 @@ def main():
 
     if args.cook:
         cook_equivalent(args)
+        return
+    if args.full:
+        if world != 1:
+            raise SystemExit("bench.py --full is the single-GPU Compute_Sim substep")
+        full_substep(args)
         return
     origins, R = fields.config_leaves(args.config)
     vs, dt = 1.0 / R, 1.0 / 24.0

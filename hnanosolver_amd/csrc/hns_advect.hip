@@ -167,91 +167,6 @@ __device__ __forceinline__ TapsB make_taps_b(const GridDev& g, const int* s_nbr,
 	return T;
 }
 
-// ---- round 5: the z-column table ------------------------------------------------------------------------------------------
-// make_taps_b spends 58 vector instructions and 8 LDS reads on the eight offsets of a sample (profiles/r05_advect_isa.txt); per axis it derives
-// "which of the three leaves" and "where in the leaf" for the cell and for cell + 1 and combines them per corner. Along z both parts come out of ONE
-// table here: entry (ax, ay, dz) -- neighbour leaf column (ax, ay) of the 3 x 3, cell dz = 0..22 of its 24 voxels along z -- holds the byte offsets
-// of the voxels z = dz and z = dz + 1 of that column's row (x, y) = (0, 0): leaf base and in-leaf z already added, the step into the next leaf at
-// dz & 7 == 7 already taken. A sample then reads four 8-byte entries (one per (x, y) corner) instead of eight 4-byte leaf bases and adds the in-leaf
-// (x, y) part: 40 instructions and 4 LDS reads. SCALE = 3: offsets into a Vec3f field (k_advect_vector_n: no `* 3` per tap either); 1: float fields.
-// Built per workgroup by 9 x 23 threads straight from nbr27 (beside the staging of the other tables: no barrier of its own).
-constexpr int kZTabEntries = 16 * 32;  // entry ((ax * 4 + ay) * 32 + dz): its byte address is bit fields of the cell coordinates
-template <int SCALE>
-__device__ __forceinline__ void stage_ztab(const GridDev& g, int leaf, uint2* s_ztab) {
-	const int t = threadIdx.x;
-	if (t < 9 * 23) {
-		const int a = t / 23, dz = t - a * 23, ax = a / 3, ay = a - ax * 3;
-		const int nb0 = g.nbr27[leaf * 27 + a * 3 + (dz >> 3)], nb1 = g.nbr27[leaf * 27 + a * 3 + ((dz + 1) >> 3)];
-		uint2 e;
-		e.x = (nb0 < 0 ? kOutside : (unsigned)nb0 * 2048u + (unsigned)((dz & 7) << 2)) * (unsigned)SCALE;
-		e.y = (nb1 < 0 ? kOutside : (unsigned)nb1 * 2048u + (unsigned)(((dz + 1) & 7) << 2)) * (unsigned)SCALE;
-		s_ztab[(ax * 4 + ay) * 32 + dz] = e;
-	}
-}
-
-// Floor + the eight corner offsets (as make_taps_b), through the z-column table. T.o: byte offsets into a field of SCALE floats per voxel; an absent
-// leaf gives kOutside * SCALE (+ the in-leaf part): beyond every field the 32-bit kernels accept.
-template <int SCALE>
-__device__ __forceinline__ TapsB make_taps_z(const GridDev& g, const int* s_nbr, const uint2* s_ztab, const int4 org, float x, float y, float z) {
-	TapsB T;
-	const float flx = floorf(x), fly = floorf(y), flz = floorf(z);  // Floor (Stencils.hpp:25-43); x - float(int(floor x)) = x - floor x exactly
-	const int i = (int)flx, j = (int)fly, k = (int)flz;
-	T.fx = x - flx;
-	T.fy = y - fly;
-	T.fz = z - flz;
-	const unsigned dx = (unsigned)(i - (org.x - 8)), dy = (unsigned)(j - (org.y - 8)), dz = (unsigned)(k - (org.z - 8));
-	if (max(dx, max(dy, dz)) < 23u) {
-		const unsigned ex = dx + 1u, ey = dy + 1u;
-		// table byte address: (d >> 3) << {10, 8} for x, y, dz << 3; in-leaf byte offset (d & 7) * {256, 32} * SCALE
-		const unsigned X[2] = {(dx & 24u) << 7, (ex & 24u) << 7}, Y[2] = {(dy & 24u) << 5, (ey & 24u) << 5}, Z = dz << 3;
-		const unsigned lx[2] = {(dx & 7u) * (256u * SCALE), (ex & 7u) * (256u * SCALE)}, ly[2] = {(dy & 7u) * (32u * SCALE), (ey & 7u) * (32u * SCALE)};
-		const char* tab = reinterpret_cast<const char*>(s_ztab);
-#pragma unroll
-		for (int dij = 0; dij < 4; ++dij) {
-			const uint2 e = *reinterpret_cast<const uint2*>(tab + (X[dij >> 1] | Y[dij & 1] | Z));
-			const unsigned l = lx[dij >> 1] + ly[dij & 1];
-			T.o[2 * dij] = e.x + l;
-			T.o[2 * dij + 1] = e.y + l;
-		}
-	} else {
-		int any = 0;
-#pragma unroll
-		for (int c = 0; c < 8; ++c) {  // unrolled: a rolled loop would index T.o dynamically and push the whole array into LDS
-			const int t = tap_index(g, s_nbr, org, i + (c >> 2), j + ((c >> 1) & 1), k + (c & 1));
-			any |= t;
-			T.o[c] = (t < 0 ? kOutside : (unsigned)t << 2) * (unsigned)SCALE;
-		}
-		if (any < 0 && g.far_flag) *g.far_flag = 1;  // a multi-GPU rank: a far tap whose leaf is not here may exist on another rank (see make_taps)
-	}
-	return T;
-}
-
-// the same sample as tri_v_b with offsets that already are Vec3f byte offsets
-__device__ __forceinline__ f3 tri_v_z(const v4i& ru, const TapsB& T);
-
-// ---- round 5: the clamp neighbours out of a padded box ----------------------------------------------------------------------
-// The six face neighbours of a voxel came out of a tile [512 own | 6 x 64 face layers] whose entry numbers cost four instructions per neighbour
-// (tile_nbr: inside the leaf or on a face?). In a 10 x 10 x 10 box -- the leaf with one layer around it, edges and corners unused -- they are the
-// constant offsets +-1, +-10, +-100 from the voxel's own entry: immediates of the LDS reads. Component planes of kBox floats (SoA).
-constexpr int kBox = 1000;
-__device__ __forceinline__ int box_own(int n) { return 111 + (n >> 6) * 100 + ((n >> 3) & 7) * 10 + (n & 7); }
-// box entry of halo value h in [0, 384) (hns_device.hpp: halo_entry -- face f = h >> 6 in the order -x,+x,-y,+y,-z,+z, (a, b) = the two other coordinates)
-__device__ __forceinline__ int box_halo(int h) {
-	const int f = h >> 6, a = (h >> 3) & 7, b = h & 7;
-	const int c = (f & 1) ? 9 : 0;
-	return f < 2 ? c * 100 + (a + 1) * 10 + (b + 1) : (f < 4 ? (a + 1) * 100 + c * 10 + (b + 1) : (a + 1) * 100 + (b + 1) * 10 + c);
-}
-__device__ __forceinline__ float min3f(float a, float b, float c) {
-	float r;
-	asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-	return r;
-}
-__device__ __forceinline__ float max3f(float a, float b, float c) {
-	float r;
-	asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-	return r;
-}
-
 // value or 0 outside the domain (IndexSampler<T,0>, Stencils.hpp:81-89), without a branch
 __device__ __forceinline__ float ldz(const float* __restrict__ f, int idx) {
 	const float v = f[idx < 0 ? 0 : idx];
@@ -311,20 +226,6 @@ __device__ __forceinline__ f3 tri_v_b(const v4i& ru, const TapsB& T) {
 #pragma unroll
 	for (int q = 0; q < 8; ++q) {
 		const v3f v = hns_buffer_load_v3f32(ru, (int)(T.o[q] + (T.o[q] << 1)), 0, 0);
-		c[q].xy = v2f32{v.x, v.y};
-		c[q].z = v.z;
-	}
-	const V3 z0 = lerp_v3(c[0], c[1], T.fz), z1 = lerp_v3(c[2], c[3], T.fz), z2 = lerp_v3(c[4], c[5], T.fz), z3 = lerp_v3(c[6], c[7], T.fz);
-	const V3 y0 = lerp_v3(z0, z1, T.fy), y1 = lerp_v3(z2, z3, T.fy);
-	const V3 r = lerp_v3(y0, y1, T.fx);
-	return f3{r.xy.x, r.xy.y, r.z};
-}
-
-__device__ __forceinline__ f3 tri_v_z(const v4i& ru, const TapsB& T) {
-	V3 c[8];
-#pragma unroll
-	for (int q = 0; q < 8; ++q) {
-		const v3f v = hns_buffer_load_v3f32(ru, (int)T.o[q], 0, 0);
 		c[q].xy = v2f32{v.x, v.y};
 		c[q].z = v.z;
 	}
@@ -401,9 +302,10 @@ __device__ __forceinline__ unsigned halo_off(const unsigned* s_b4, int h) {
 // 32-bit addressed form (no collision field): same loads and arithmetic as the generic kernel below
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_advect_vector_n(const GridDev g, const float* __restrict__ u, float* __restrict__ out, const float scaled_dt) {
 	__shared__ int s_nbr[27];
+	__shared__ int s_base[27];
 	__shared__ unsigned s_b4[27];
-	__shared__ uint2 s_ztab[kZTabEntries];
-	// the voxel's own velocity needs the leaf number only: its load is issued before the neighbour tables are fetched and staged (one memory
+	__shared__ unsigned s_b4p[kPadTab];
+	// the voxel's own velocity needs the leaf number only: its load is issued before the neighbour table is fetched and staged (one memory
 	// round trip less in front of the first gathers; the kernel is bound by the length of that chain)
 	const int n = threadIdx.x;
 	const int leaf = launch_leaf(g, blockIdx.x);
@@ -411,30 +313,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 	const v4i ru = field_rsrc(u, (unsigned)g.n_leaves * 6144u);
 	const unsigned own = (unsigned)idx << 2;
 	const f3 vo = ldv(ru, own);
-	const int4 org = g.origins[leaf];
-	if (n < 27) {
-		const int nb = g.nbr27[leaf * 27 + n];
-		s_nbr[n] = nb;
-		s_b4[n] = nb < 0 ? kOutside : (unsigned)nb * 2048u;
-	}
-	stage_ztab<3>(g, leaf, s_ztab);
-	__syncthreads();
-	const float px = (float)(org.x + (n >> 6)), py = (float)(org.y + ((n >> 3) & 7)), pz = (float)(org.z + (n & 7));
+	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4, s_b4p, leaf);
+	const float px = (float)(L.org.x + (n >> 6)), py = (float)(L.org.y + ((n >> 3) & 7)), pz = (float)(L.org.z + (n & 7));
 
-	__shared__ float s_box[3 * kBox];
-	const int eo = box_own(n);
-	s_box[eo] = vo.x, s_box[kBox + eo] = vo.y, s_box[2 * kBox + eo] = vo.z;
+	__shared__ float s_tile[kTile * 3];
+	s_tile[3 * n] = vo.x, s_tile[3 * n + 1] = vo.y, s_tile[3 * n + 2] = vo.z;
 	if (n < 384) {
 		const f3 h = ldv(ru, halo_off(s_b4, n));
-		const int eh = box_halo(n);
-		s_box[eh] = h.x, s_box[kBox + eh] = h.y, s_box[2 * kBox + eh] = h.z;
+		s_tile[3 * (512 + n)] = h.x, s_tile[3 * (512 + n) + 1] = h.y, s_tile[3 * (512 + n) + 2] = h.z;
 	}
 	float sx = px - scaled_dt * vo.x, sy = py - scaled_dt * vo.y, sz = pz - scaled_dt * vo.z;  // backPos (Kernel.cu:374)
 	f3 vf = {0.0f, 0.0f, 0.0f}, vb = {0.0f, 0.0f, 0.0f};
 #pragma unroll 1
 	for (int pass = 0; pass < 2; ++pass) {
-		const TapsB T = make_taps_z<3>(g, s_nbr, s_ztab, org, sx, sy, sz);
-		const f3 v = tri_v_z(ru, T);
+		const TapsB T = make_taps_b(g, s_nbr, s_b4p, L.org, sx, sy, sz);
+		const f3 v = tri_v_b(ru, T);
 		if (pass == 0) {
 			vf = v;
 			sx = sx + scaled_dt * v.x, sy = sy + scaled_dt * v.y, sz = sz + scaled_dt * v.z;  // Kernel.cu:387
@@ -443,19 +336,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 		}
 	}
 	f3 vc = {vf.x + 0.5f * (vo.x - vb.x), vf.y + 0.5f * (vo.y - vb.y), vf.z + 0.5f * (vo.z - vb.z)};
-	__syncthreads();  // box complete (the gathers above had the memory system to themselves)
-	// min / max over {centre, -x, +x, -y, +y, -z, +z, forward sample} (Kernel.cu:403-430): min and max are exact, so grouping them in threes gives the
-	// bits of the reference's chain of fminf / fmaxf
-	float c[3], fwd[3] = {vf.x, vf.y, vf.z}, own3[3] = {vo.x, vo.y, vo.z}, corr[3] = {vc.x, vc.y, vc.z};
+	__syncthreads();  // tile complete (the gathers above had the memory system to themselves)
+	const int e[6] = {tile_nbr<0, -1>(n), tile_nbr<0, 1>(n), tile_nbr<1, -1>(n), tile_nbr<1, 1>(n), tile_nbr<2, -1>(n), tile_nbr<2, 1>(n)};
+	f3 mn = vo, mx = vo;
 #pragma unroll
-	for (int k = 0; k < 3; ++k) {
-		const float* B = s_box + k * kBox + eo;
-		const float xm = B[-100], xp = B[100], ym = B[-10], yp = B[10], zm = B[-1], zp = B[1];
-		const float mn = fminf(min3f(min3f(own3[k], xm, xp), ym, yp), min3f(zm, zp, fwd[k]));
-		const float mx = fmaxf(max3f(max3f(own3[k], xm, xp), ym, yp), max3f(zm, zp, fwd[k]));
-		c[k] = fmaxf(mn, fminf(corr[k], mx));
+	for (int d = 0; d < 6; ++d) {
+		const f3 nv = {s_tile[3 * e[d]], s_tile[3 * e[d] + 1], s_tile[3 * e[d] + 2]};
+		mn.x = fminf(mn.x, nv.x);
+		mx.x = fmaxf(mx.x, nv.x);
+		mn.y = fminf(mn.y, nv.y);
+		mx.y = fmaxf(mx.y, nv.y);
+		mn.z = fminf(mn.z, nv.z);
+		mx.z = fmaxf(mx.z, nv.z);
 	}
-	st3(out, idx, f3{c[0], c[1], c[2]});
+	mn.x = fminf(mn.x, vf.x);
+	mx.x = fmaxf(mx.x, vf.x);
+	mn.y = fminf(mn.y, vf.y);
+	mx.y = fmaxf(mx.y, vf.y);
+	mn.z = fminf(mn.z, vf.z);
+	mx.z = fmaxf(mx.z, vf.z);
+	vc.x = fmaxf(mn.x, fminf(vc.x, mx.x));
+	vc.y = fmaxf(mn.y, fminf(vc.y, mx.y));
+	vc.z = fmaxf(mn.z, fminf(vc.z, mx.z));
+	st3(out, idx, vc);
 }
 
 template <bool COLL>
