@@ -12,32 +12,25 @@ namespace hns {
 // ---------------------------------------------------------------------------------------------------------------
 
 // combustion_oxygen (reference Kernel.cu:923-966)
-__global__ __launch_bounds__(256) void k_combustion_oxygen(const float* __restrict__ fuelData, const float* __restrict__ wasteData,
-                                                           const float* __restrict__ temperatureData, float* __restrict__ divergenceData,
-                                                           const float* __restrict__ flameData, float* __restrict__ outFuel,
-                                                           float* __restrict__ outWaste, float* __restrict__ outTemperature,
-                                                           float* __restrict__ outFlame, const float temp_gain, const float expansion,
-                                                           const uint64_t n, const int update_div) {
-	for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (uint64_t)gridDim.x * blockDim.x) {
-		float fuel = fuelData[idx];
-		const float waste = wasteData[idx];
-		const float temperature = temperatureData[idx];
-		const float flame = flameData[idx];
-		if (fuel < 0.001f) fuel = 0.0f;
-		const float oxygen = 1.0f - fuel - waste;
-		if (oxygen < 0.0f) {
-			outFuel[idx] = fuel;
-			outWaste[idx] = waste;
-			outTemperature[idx] = temperature;
-			outFlame[idx] = flame;
+__global__ __launch_bounds__(256) void k_combustion_oxygen(const float* __restrict__ fuel_in, const float* __restrict__ waste_in, const float* __restrict__ temp_in,
+                                                           float* __restrict__ div, const float* __restrict__ flame_in, float* __restrict__ fuel_out,
+                                                           float* __restrict__ waste_out, float* __restrict__ temp_out, float* __restrict__ flame_out,
+                                                           const float temp_gain, const float expansion, const uint64_t n, const int update_div) {
+	for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
+		float f = fuel_in[v];
+		const float w = waste_in[v], tmp = temp_in[v], fl = flame_in[v];
+		if (f < 0.001f) f = 0.0f;       // Kernel.cu:936-938
+		const float oxy = 1.0f - f - w;  // :941
+		if (oxy < 0.0f) {                // :942-949: no oxygen left, the voxel passes through
+			fuel_out[v] = f, waste_out[v] = w, temp_out[v] = tmp, flame_out[v] = fl;
 			continue;
 		}
-		const float burn = fminf(oxygen, fuel);
-		outFuel[idx] = fuel - burn;
-		outWaste[idx] = waste + burn * 2.0f;
-		outTemperature[idx] = temperature + burn * temp_gain;
-		if (update_div) divergenceData[idx] += burn * expansion;
-		outFlame[idx] = fmaxf(flame, fminf(1.0f, burn * 10.0f));
+		const float burn = fminf(oxy, f);  // :952
+		fuel_out[v] = f - burn;
+		waste_out[v] = w + burn * 2.0f;
+		temp_out[v] = tmp + burn * temp_gain;
+		if (update_div) div[v] += burn * expansion;
+		flame_out[v] = fmaxf(fl, fminf(1.0f, burn * 10.0f));
 	}
 }
 

@@ -363,6 +363,32 @@ def test_bench_py_launches_its_own_ranks():
     assert "bit-equal to their owners' values" in j["config"]["ghosts"], j["config"]["ghosts"]
 
 
+def test_bench_py_default_line_carries_the_strong_scaling_record():
+    """`python bench.py --gpus 2` with the default workload (what the driver runs for its scaling curve): ONE JSON line with the 256^3 weak-scaling headline
+    and, as `strong_scaling`, BASELINE config 5 -- the 1024^3-extent plume as one domain over the same ranks, slab partition -- both verified against the
+    single-GPU run and with their ghost voxels checked. Both ranks on the one GPU here (--share-one-gpu)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-one-gpu", "--steps", "2", "--warmup", "1", "--iterations", "6"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["workload"].startswith("256^3") and j["value"] > 0
+    s = j["strong_scaling"]
+    assert "error" not in s, s
+    assert s["n_gpus"] == 2 and s["scaling"] == "strong" and s["value"] > 0 and s["config"]["leaves"] == 65944
+    assert "bit-identical to the single-GPU run of the whole domain" in s["config"]["verified"], s["config"]["verified"]
+    assert "bit-equal to their owners' values" in s["config"]["ghosts"], s["config"]["ghosts"]
+    assert s["config"]["halo"]["halo_peers"] == 1 and "slabs of leaves along axis y" in s["config"]["parallelism"]
+
+
 def test_unconnected_ranks_refuse_to_step():
     import hnanosolver_amd as H
 
