@@ -323,7 +323,7 @@ def full_substep(args):
     an exact copy at the default factor_scale 0.5, skipped], divergence, combustion, buoyancy, 50 RB-SOR iterations, gradient subtraction, advect_scalars
     over the five float fields -- on device-resident fields, K timed substeps between synchronisations. `kernels`: each stage's kernel launched on its own
     after the timed region on the same arrays, bracketed by events on the launch stream (a stage alone finds its inputs warmer or colder in the Infinity
-    Cache than inside the substep; the rocprofv3 kernel statistics of this command, profiles/r05_full256_kernel_stats.csv, are the in-substep figures)."""
+    Cache than inside the substep; the rocprofv3 kernel statistics of this command, profiles/r05_final_full256_kernel_stats.csv, are the in-substep figures)."""
     import torch
 
     from hnanosolver_amd import api, device as D, fields

@@ -277,9 +277,9 @@ def Compute_Sim(data: GridIndexedData, handle: IndexGridHandle, iteration: int, 
     Compute_Sim on this handle handed back (the SOP feeds its output back in as the next frame's input, SOP_HNanoSolver.cpp:106):
     those blocks are not uploaded again (hns_compute_sim_resident). checked=False (default): VOUCHED -- the caller knows what it changed; only a
     4,096-sample signature is compared, a sparse edit (an emitter added to a few leaves) is NOT detected, so a block the caller sourced
-    into must not be named. checked=True: CHECKED -- a digest of every element, one pass over the arrays at each end of the cook; any edit is
-    noticed and that block uploaded. Sound, and at 256^3 dearer than not using feedback at all (23.1 ms against 19.8 for the plain warm cook and
-    11.8 vouched, profiles/r05_cook256.json): the uploads it saves run under the substep anyway. Returns the number of uploads skipped."""
+    into must not be named. checked=True: CHECKED -- a digest of every element (taken on the device when a block is handed back, on host threads when
+    it comes in again); any edit is noticed and that block uploaded. Sound; 14.8 ms per cook at 256^3 against 19.8 for the plain warm cook and 11.9
+    vouched (profiles/r05_final_cook256.json). Returns the number of uploads skipped."""
     if handle is None or handle.isEmpty():
         # argument checks come first in the reference (HNanoSolver.cu:12-23)
         if voxelSize <= 0.0:

@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "hns_device.hpp"
+#include "hns_digest.hpp"
 
 namespace hns {
 
@@ -168,6 +169,34 @@ int hns_dev_combustion_oxygen(const float* fuel, const float* waste, const float
 }
 
 // the two halves of combustion_oxygen for the cook pipeline (see k_combustion_div)
+// ---- field digest (hns_compute_sim_resident, CHECKED fields; hns_digest.hpp) ----
+// sum over the 16-byte pieces of a field of hns_digest_piece(piece number, its two 8-byte words), mod 2^64: order-independent, so the device takes it of the
+// buffer a host array was downloaded from in one pass at memory speed, and the host takes the same number of the array on as many threads as it likes
+__global__ __launch_bounds__(256) void k_field_digest(const uint4* __restrict__ a, const uint64_t n_pieces, const float* __restrict__ tail, const int n_tail, unsigned long long* __restrict__ out) {
+	unsigned long long sum = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pieces; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint4 v = a[i];
+		sum += hns_digest_piece(i, (uint64_t)v.x | (uint64_t)v.y << 32, (uint64_t)v.z | (uint64_t)v.w << 32);
+	}
+	if (n_tail && blockIdx.x == 0 && threadIdx.x == 0) {  // (a field whose length is not a multiple of four floats: zero-padded last piece)
+		uint32_t w[4] = {0, 0, 0, 0};
+		for (int k = 0; k < n_tail; ++k) w[k] = __float_as_uint(tail[k]);
+		sum += hns_digest_piece(n_pieces, (uint64_t)w[0] | (uint64_t)w[1] << 32, (uint64_t)w[2] | (uint64_t)w[3] << 32);
+	}
+	for (int d = 32; d; d >>= 1) sum += __shfl_down(sum, d, 64);
+	__shared__ unsigned long long s_part[4];
+	if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
+	__syncthreads();
+	if (threadIdx.x == 0) atomicAdd(out, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+
+int hns_field_digest(const float* field, uint64_t count, unsigned long long* d_out, void* stream) {
+	const uint64_t n_pieces = count / 4;
+	const unsigned blocks = (unsigned)std::min<uint64_t>(2048, std::max<uint64_t>(1, (n_pieces + 255) / 256));
+	hipLaunchKernelGGL(k_field_digest, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4*>(field), n_pieces, field + 4 * n_pieces, (int)(count & 3), d_out);
+	return launch_status("hns_field_digest");
+}
+
 int hns_combustion_div(const float* fuel, const float* waste, float* divergence, float expansion, uint64_t n, void* stream) {
 	if (n == 0) return HNS_OK;
 	hipLaunchKernelGGL(k_combustion_div, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, fuel, waste, divergence, expansion, n);

@@ -203,11 +203,12 @@ int hns_compute_sim(hns_grid*, hns_field* fields, int n_fields, int iterations, 
  *                    sourced into must NOT be flagged). The library only trips on gross mistakes: a signature of the array (its size and
  *                    4,096 evenly spread elements) must match the one taken when it was handed back. A sparse edit that misses the samples
  *                    is NOT detected and that field would silently stay stale on the device.
- *   resident[i] = 2  CHECKED. A 64-bit digest of EVERY element (taken when the array was handed back by a call that asked for it, taken
- *                    again now, on up to 8 host threads) must match as well: any edit is noticed and the field uploaded. Costs one pass
- *                    over the array at each end of the cook -- measured at 256^3: 23.1 ms per cook against 19.8 for the plain warm cook
- *                    (whose uploads run under the substep) and 11.8 vouched: the sound form, not the fast one. The first cook that asks
- *                    finds no digest to compare with and uploads.
+ *   resident[i] = 2  CHECKED. A 64-bit digest of EVERY element must match as well: any edit is noticed and the field uploaded. The digest is
+ *                    taken on the DEVICE when the field is handed back (of the buffer the array is downloaded from: the same bits, one pass at
+ *                    memory speed beside the downloads) by a call that asked for it, and on the HOST, on up to 8 threads, when the array comes
+ *                    in again (hns_digest.hpp: an order-independent sum over 16-byte pieces). Measured at 256^3: 14.8 ms per cook against 19.8
+ *                    for the plain warm cook and 11.9 vouched (profiles/r05_final_cook256.json); the first cook that asks finds no digest to
+ *                    compare with and uploads.
  * Either way the field is uploaded as usual when the check fails, when the topology changed, or when another operator used the state in
  * between. resident == NULL: hns_compute_sim. *uploads_skipped (may be NULL) receives the number of fields that stayed on the device.
  * Results are bit-identical to hns_compute_sim whenever the promise holds. */
