@@ -397,7 +397,7 @@ __device__ __forceinline__ void chain_store_piece(const PhaseMirror& m, int leaf
 	}
 }
 
-template <int LB, int K, bool ZERO, bool PAR, class M = NoMirror>
+template <int LB, int K, bool ZERO, bool PAR, class M = NoMirror, bool DD = false>
 __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, const int t, const int* __restrict__ recs, const int* __restrict__ any_absent, const float* __restrict__ div,
                                              const float* __restrict__ p_in, float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega, const M& m = M{}) {
 	using G = SbGeo<LB, K>;
@@ -485,15 +485,42 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 	{
 		const int cx2 = (x2 - H + 8) >> 3, cy2 = (y2 - H + 8) >> 3;
 		const unsigned rb2 = (unsigned)(((((x2 - H) & 7) << 3) | ((y2 - H) & 7)) * 32);
-		const int4 q2 = (!ZERO && valid2) ? *reinterpret_cast<const int4*>(recs + (size_t)blockIdx.x * G::REC + (cx2 * C + cy2) * C) : make_int4(-1, -1, -1, -1);
+		const int4 q2 = ((DD || !ZERO) && valid2) ? *reinterpret_cast<const int4*>(recs + (size_t)blockIdx.x * G::REC + (cx2 * C + cy2) * C) : make_int4(-1, -1, -1, -1);
 		const int e2 = max(0, max(H - x2, x2 - (T - 1 - H))) + max(0, max(H - y2, y2 - (T - 1 - H)));  // (as for div above, one step further)
 		const unsigned base2[4] = {e2 > H - 1 ? kBeyond : (unsigned)q2.x * 2048u + rb2, e2 > H ? kBeyond : (unsigned)q2.y * 2048u + rb2,
 		                           e2 > H ? kBeyond : (unsigned)q2.z * 2048u + rb2, e2 > H - 1 ? kBeyond : (unsigned)q2.w * 2048u + rb2};
+		// DD (round 5; grids beyond 40k leaves, hns_rbgs_block_launch): div arrives in the memory-order mapping too -- the row (x2, y2) this
+		// thread fetches p of: lanes 32 bytes apart instead of 64, two thirds of the L1 accesses per instruction -- and WITHOUT passing through registers:
+		// buffer_load_dwordx4 ... lds drops piece j of thread tid at D[j * NT + tid] (a wave-instruction fills one contiguous KiB of LDS). The area D lies under the
+		// p arrays, which are staged only after every row owner has read its six pieces back: two more barriers in a workgroup's chain. Out of the cache the
+		// fewer accesses win (512^3 250 -> 238 us per iteration pair... see DESIGN 7), in it the longer chain loses (256^3 +3 %, 128^3 +6 %): switched by size.
+		// div reaches one step less far than p. Issued in FRONT of p's loads: the hand-over runs while those are still in flight.
+		if constexpr (DD) {
+			const unsigned dbase[4] = {e2 > H - 2 ? kBeyond : (unsigned)q2.x * 2048u + rb2, e2 > H - 1 ? kBeyond : (unsigned)q2.y * 2048u + rb2,
+			                           e2 > H - 1 ? kBeyond : (unsigned)q2.z * 2048u + rb2, e2 > H - 2 ? kBeyond : (unsigned)q2.w * 2048u + rb2};
+			const __amdgpu_buffer_rsrc_t rdd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(div), 0, (int)field_bytes, 0x00020000);
+			const int wave0 = __builtin_amdgcn_readfirstlane(tid & ~63);
+#pragma unroll
+			for (int j = 0; j < NCH; ++j)
+				__builtin_amdgcn_raw_ptr_buffer_load_lds(rdd, (__attribute__((address_space(3))) void*)(L.a + j * G::NT + wave0), 16,
+				                                         (int)(dbase[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0, 0);
+		}
 #pragma unroll
 		for (int j = 0; j < NCH; ++j) pc[j] = ZERO ? sb4f{0.0f, 0.0f, 0.0f, 0.0f} : sb_load4(rp, (int)(base2[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
 	}
+	if constexpr (DD) {
+		// the DMA pieces have landed; p's six loads, issued BEHIND them, may still be in flight (vmcnt(6): loads return in order)
+		__builtin_amdgcn_s_waitcnt(ZERO ? 0x0F70 : 0x0F76);
+		__syncthreads();
+		const int mrow = (x - 1) * G::TC + (y - 1);  // this row's number in the fetch order (x2, y2)
+		const sb4f* D = reinterpret_cast<const sb4f*>(L.a);
 #pragma unroll
-	for (int j = 0; j < NCH; ++j) dc[j] = sb_load4(rd, (int)(base[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
+		for (int j = 0; j < NCH; ++j) dc[j] = valid ? D[j * G::NT + mrow] : sb4f{0.0f, 0.0f, 0.0f, 0.0f};
+		__syncthreads();  // (every row owner holds its div: the area may become the p arrays)
+	} else {
+#pragma unroll
+		for (int j = 0; j < NCH; ++j) dc[j] = sb_load4(rd, (int)(base[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
+	}
 #pragma unroll
 	for (int n = 0; n < NJ; ++n) {
 		if (rim_on[n]) {
@@ -596,7 +623,7 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 // M = NoMirror, or PhaseMirror for the chained sweep of a multi-GPU rank (hns_flags.hpp; lean form only): the workgroups of blocks that
 // hold a boundary leaf (bit 1 of the block's meta word; first in the launch order) wait for the peers' previous launch before they read a
 // ghost voxel, and store what the peers read of their boundary leaves into the peers' ghost copies too.
-template <int LB, int K, bool ZERO, bool LEAN = false, class M = NoMirror>
+template <int LB, int K, bool ZERO, bool LEAN = false, class M = NoMirror, bool DD = false>
 __global__ __attribute__((amdgpu_waves_per_eu(LEAN ? 6 : 1, 8))) __launch_bounds__((SbGeo<LB, K>::NT)) void k_rbgs_block(const int* __restrict__ recs, const int* __restrict__ any_absent, const float* __restrict__ div, const float* __restrict__ p_in,
                                                                 float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega, const int stagger, const M m = M{}) {
 	using G = SbGeo<LB, K>;
@@ -626,9 +653,9 @@ __global__ __attribute__((amdgpu_waves_per_eu(LEAN ? 6 : 1, 8))) __launch_bounds
 	if constexpr (LEAN) {
 		static_assert(G::CAN_LEAN, "the lean form is written for 24-voxel tiles");
 		if (__builtin_amdgcn_readfirstlane(t >= G::SEC))
-			sb_body_lean<LB, K, ZERO, true, M>(L, s_rec, t - G::SEC, recs, any_absent, div, p_in, p_out, field_bytes, dx2, omega, m);
+			sb_body_lean<LB, K, ZERO, true, M, DD>(L, s_rec, t - G::SEC, recs, any_absent, div, p_in, p_out, field_bytes, dx2, omega, m);
 		else
-			sb_body_lean<LB, K, ZERO, false, M>(L, s_rec, t, recs, any_absent, div, p_in, p_out, field_bytes, dx2, omega, m);
+			sb_body_lean<LB, K, ZERO, false, M, DD>(L, s_rec, t, recs, any_absent, div, p_in, p_out, field_bytes, dx2, omega, m);
 		if constexpr (!std::is_same<M, NoMirror>::value) chain_end(m, chain_leaf);
 	} else {
 		if (__builtin_amdgcn_readfirstlane(t >= G::SEC))
@@ -804,7 +831,7 @@ int hns_rbgs_block_shape(hns_grid* g, int* k_max) {
 // 16^3 blocks are swept by the lean form (row state in LDS, three workgroups per CU, dense LDS rows, p fetched and stored in memory
 // order); the rows-in-registers form remains for one-leaf blocks and as a cross-check. us per iteration, registers -> lean: 512 leaves
 // in 64 blocks 3.70 -> 3.37, 128^3 6.57 -> 5.62, 4k-leaf plume 8.34 -> 6.64, 256^3 35.3 -> 27.2, 512^3 304 -> 273, 66k-leaf plume
-// 84.8 -> 74.2 (profiles/r03_sorblock_notes.txt 11-12). Option "sor_block_lean" = auto | 0 | 1.
+// 84.8 -> 74.2 (profiles/r03_sorblock_notes.txt 11-12). Option "sor_block_lean" = auto | 0 | 1 | dma (1 with div through LDS-DMA at every size: what auto takes beyond 40k leaves).
 bool hns_rbgs_block_lean(hns_grid* g, int lb, int k) {
 	if (lb != 2 || k != 2) return false;
 	if (g->first_active != 0 || g->n_active != (uint64_t)g->topo.n_leaves) return true;  // (only the lean form knows which leaves of a block a launch range stores)
@@ -841,7 +868,14 @@ int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const fl
 	else if (lb == 1 && k == 4) SB_LAUNCH(1, 4, g->d_blk, g->n_active);
 	else if (lb == 2 && k == 2 && lean) {
 		const int sl = 0;  // (a launch-start stagger buys the lean form nothing: three workgroups per CU drift apart by themselves; option removed in round 4)
-		if (src_is_zero)
+		// div through LDS-DMA in the memory-order mapping where the sweep runs out of the cache (sb_body_lean, DD): 512^3 250 -> 238 us per iteration, the 66k-leaf
+		// plume 67.5 -> 65.2; at 256^3 and below the two extra barriers cost more than the accesses save (26.9 -> 27.7, 128^3 5.55 -> 5.86)
+		const bool dd = g->n_active > 40000 || options().sor_block_lean.load() == 3;  // ("sor_block_lean" = dma forces it: tests)
+		if (dd && src_is_zero)
+			hipLaunchKernelGGL((k_rbgs_block<2, 2, true, true, NoMirror, true>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, sl);
+		else if (dd)
+			hipLaunchKernelGGL((k_rbgs_block<2, 2, false, true, NoMirror, true>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, sl);
+		else if (src_is_zero)
 			hipLaunchKernelGGL((k_rbgs_block<2, 2, true, true>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, sl);
 		else
 			hipLaunchKernelGGL((k_rbgs_block<2, 2, false, true>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, sl);

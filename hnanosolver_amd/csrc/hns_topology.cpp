@@ -138,7 +138,7 @@ const char* const kWordsStencil[] = {"auto", "block", nullptr};
 const char* const kWordsSchedule[] = {"auto", "linear", "chunk", nullptr};
 const char* const kWordsBool[] = {"0", "1", nullptr};
 const char* const kWordsMirror[] = {"0", "1", "guarded", nullptr};
-const char* const kWordsAuto01[] = {"auto", "0", "1", nullptr};
+const char* const kWordsLean[] = {"auto", "0", "1", "dma", nullptr};
 const char* const kWordsDivergence[] = {"auto", "row", "coalesced", nullptr};
 const OptionDesc kOptions[] = {
     {"rbgs", &Options::rbgs, kWordsRbgs},
@@ -152,7 +152,7 @@ const OptionDesc kOptions[] = {
     {"sor_block_lb", &Options::sor_block_lb, nullptr},
     {"sor_block_k", &Options::sor_block_k, nullptr},
     {"sor_block_seg", &Options::sor_block_seg, nullptr},
-    {"sor_block_lean", &Options::sor_block_lean, kWordsAuto01},
+    {"sor_block_lean", &Options::sor_block_lean, kWordsLean},
     {"sor_block_stagger", &Options::sor_block_stagger, nullptr},
     {"schedule_segment", &Options::schedule_segment, nullptr},
     {"dist_wire_us", &Options::dist_wire_us, nullptr},

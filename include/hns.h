@@ -66,8 +66,9 @@ int hns_trim_memory(void);
  *                   iterations per launch on a block of leaves with a halo, hns_sorblock.hip). auto: by grid size
  *   "sor_block_lb"  0 = by size | 1 | 2: block edge of the temporally blocked form, in leaves
  *   "sor_block_k"   0 = by shape | 2 | 4: its iterations per launch (4: one-leaf blocks only)
- *   "sor_block_lean" auto | 0 | 1: 16^3-voxel blocks with the rows' p kept in LDS and three workgroups per CU (1) or in registers and two (0);
- *                   auto = 1 (the registers form is a cross-check).
+ *   "sor_block_lean" auto | 0 | 1 | dma: 16^3-voxel blocks with the rows' p kept in LDS and three workgroups per CU (1) or in registers and two (0);
+ *                   dma = 1 with div fetched in memory order by LDS-DMA and handed to the row owners through LDS (fewer L1 accesses, two more
+ *                   barriers). auto = 1 up to 40k leaves, dma beyond (where the sweep runs out of the cache); the registers form is a cross-check.
  *   "sor_block_seg" N: its blocks per XCD segment of the launch order (0: one chunk per XCD; read when the block table is built)
  *   "sor_block_stagger" N: its launch-start stagger between the two workgroups of a CU, x 1,024 cycles (default 8; 0 = off)
  *   "advect"        auto | generic (64-bit addressed advection kernels)

@@ -12,7 +12,7 @@ from oracle_lib import OracleGrid
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(1, 2), (1, 4), (2, 2), (2, -2)]  # (block edge in leaves, iterations per launch; negative: the lean form of the 16^3 blocks)
+SHAPES = [(1, 2), (1, 4), (2, 2), (2, -2), (2, -3)]  # (block edge in leaves, iterations per launch; negative: the lean form of the 16^3 blocks; -3: with div through LDS-DMA)
 
 
 def leaf_sets():
@@ -41,8 +41,8 @@ def restore_options():
 
 def solve(grid, div, p0, iters, **opts):
     if "sor_block_k" in opts:  # rows in registers (two workgroups per CU) or in LDS (three): forced either way, whatever the size
-        opts["sor_block_lean"] = "1" if int(opts["sor_block_k"]) < 0 else "0"
-        opts["sor_block_k"] = abs(int(opts["sor_block_k"]))
+        opts["sor_block_lean"] = {True: "1", False: "0"}[int(opts["sor_block_k"]) < 0] if int(opts["sor_block_k"]) != -3 else "dma"
+        opts["sor_block_k"] = 2 if int(opts["sor_block_k"]) == -3 else abs(int(opts["sor_block_k"]))
     for k, v in opts.items():
         H.set_option(k, str(v))
     p_a = p0.clone()
