@@ -489,12 +489,15 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 		const int e2 = max(0, max(H - x2, x2 - (T - 1 - H))) + max(0, max(H - y2, y2 - (T - 1 - H)));  // (as for div above, one step further)
 		const unsigned base2[4] = {e2 > H - 1 ? kBeyond : (unsigned)q2.x * 2048u + rb2, e2 > H ? kBeyond : (unsigned)q2.y * 2048u + rb2,
 		                           e2 > H ? kBeyond : (unsigned)q2.z * 2048u + rb2, e2 > H - 1 ? kBeyond : (unsigned)q2.w * 2048u + rb2};
+#pragma unroll
+		for (int j = 0; j < NCH; ++j) pc[j] = ZERO ? sb4f{0.0f, 0.0f, 0.0f, 0.0f} : sb_load4(rp, (int)(base2[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
 		// DD (round 5; grids beyond 40k leaves, hns_rbgs_block_launch): div arrives in the memory-order mapping too -- the row (x2, y2) this
 		// thread fetches p of: lanes 32 bytes apart instead of 64, two thirds of the L1 accesses per instruction -- and WITHOUT passing through registers:
 		// buffer_load_dwordx4 ... lds drops piece j of thread tid at D[j * NT + tid] (a wave-instruction fills one contiguous KiB of LDS). The area D lies under the
 		// p arrays, which are staged only after every row owner has read its six pieces back: two more barriers in a workgroup's chain. Out of the cache the
-		// fewer accesses win (512^3 250 -> 238 us per iteration pair... see DESIGN 7), in it the longer chain loses (256^3 +3 %, 128^3 +6 %): switched by size.
-		// div reaches one step less far than p. Issued in FRONT of p's loads: the hand-over runs while those are still in flight.
+		// fewer accesses win (512^3 250 -> 238 us per iteration, the 66k-leaf plume 67.5 -> 65.2), in it the longer chain loses (256^3 +3 %, 128^3 +6 %): switched by size.
+		// div reaches one step less far than p. Issued BEHIND p's loads and waited for with vmcnt(0): issued in front of them with a counted wait (vmcnt(6)) it
+		// measured the same, and a wait for EVERYTHING cannot be invalidated by a load the compiler schedules differently one day.
 		if constexpr (DD) {
 			const unsigned dbase[4] = {e2 > H - 2 ? kBeyond : (unsigned)q2.x * 2048u + rb2, e2 > H - 1 ? kBeyond : (unsigned)q2.y * 2048u + rb2,
 			                           e2 > H - 1 ? kBeyond : (unsigned)q2.z * 2048u + rb2, e2 > H - 2 ? kBeyond : (unsigned)q2.w * 2048u + rb2};
@@ -505,12 +508,9 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 				__builtin_amdgcn_raw_ptr_buffer_load_lds(rdd, (__attribute__((address_space(3))) void*)(L.a + j * G::NT + wave0), 16,
 				                                         (int)(dbase[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0, 0);
 		}
-#pragma unroll
-		for (int j = 0; j < NCH; ++j) pc[j] = ZERO ? sb4f{0.0f, 0.0f, 0.0f, 0.0f} : sb_load4(rp, (int)(base2[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
 	}
 	if constexpr (DD) {
-		// the DMA pieces have landed; p's six loads, issued BEHIND them, may still be in flight (vmcnt(6): loads return in order)
-		__builtin_amdgcn_s_waitcnt(ZERO ? 0x0F70 : 0x0F76);
+		__builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the DMA pieces have landed (and whatever was issued in front of them)
 		__syncthreads();
 		const int mrow = (x - 1) * G::TC + (y - 1);  // this row's number in the fetch order (x2, y2)
 		const sb4f* D = reinterpret_cast<const sb4f*>(L.a);
