@@ -33,6 +33,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <unordered_map>
 #include <memory>
 #include <initializer_list>
 #include <utility>
@@ -566,15 +567,58 @@ int build_plan(hns_dist* d, const int32_t* origins, int64_t n, int world, int ra
 		}
 	}
 
+	// Round 5: the ORDER of boundary leaves and of ghosts. A whole-leaf region that is a run of consecutive local leaves travels straight out of / into the
+	// field (Region::direct: no pack / unpack launch). In ascending leaf order that holds for x-slabs of a box, but in a slab along another axis the leaves next
+	// to the rank before and those next to the rank behind alternate through the list. So a leaf that other ranks hold copies of is ordered by WHO holds them
+	// -- the sorted list of those ranks, compared lexicographically, then by leaf number: with peers L < U the boundary reads [only L | L and U | only U] and
+	// both send regions are runs. Owner and ghost holder must enumerate a region alike: the holder sorts its ghosts by the same key, which it derives from the
+	// global leaf list like everything else in the plan.
+	std::unordered_map<int64_t, std::vector<int>> key_cache;
+	auto holders = [&](int64_t id) -> const std::vector<int>& {  // the other ranks that hold a copy of leaf `id` (partition-order number), ascending
+		auto it = key_cache.find(id);
+		if (it != key_cache.end()) return it->second;
+		std::vector<int> k;
+		const int own = owner(id);
+		if (id == g0 && world > 1) {
+			for (int q = 0; q < world; ++q)
+				if (q != own) k.push_back(q);
+		} else {
+			for (int j = 0; j < 27; ++j) {
+				const int64_t nb = topo.nbr27[(size_t)id * 27 + (size_t)j];
+				if (nb >= 0 && owner(nb) != own) k.push_back(owner(nb));
+			}
+			std::sort(k.begin(), k.end());
+			k.erase(std::unique(k.begin(), k.end()), k.end());
+		}
+		return key_cache.emplace(id, std::move(k)).first->second;
+	};
+	auto before = [&](int64_t a, int64_t b) {
+		const std::vector<int>&ka = holders(a), &kb = holders(b);
+		if (ka != kb) return std::lexicographical_compare(ka.begin(), ka.end(), kb.begin(), kb.end());
+		return a < b;
+	};
+	for (int q = 0; q < world; ++q) {
+		std::stable_sort(send_of[(size_t)q].begin(), send_of[(size_t)q].end(), [&](const std::pair<int64_t, Entry>& a, const std::pair<int64_t, Entry>& b) { return before(a.first, b.first); });
+		std::stable_sort(recv_of[(size_t)q].begin(), recv_of[(size_t)q].end(), [&](const std::pair<int64_t, Entry>& a, const std::pair<int64_t, Entry>& b) { return before(a.first, b.first); });
+	}
 	// local order [B | I | G]
 	d->local_global.clear();
 	std::vector<int> local_of_owned((size_t)n_owned, -1);
-	for (int pass = 0; pass < 2; ++pass)
+	{
+		std::vector<int64_t> bl;
 		for (int i = 0; i < n_owned; ++i)
-			if ((is_boundary[(size_t)i] != 0) == (pass == 0)) {
+			if (is_boundary[(size_t)i]) bl.push_back(o0 + i);
+		std::sort(bl.begin(), bl.end(), before);
+		for (int64_t id : bl) {
+			local_of_owned[(size_t)(id - o0)] = (int)d->local_global.size();
+			d->local_global.push_back(id);
+		}
+		for (int i = 0; i < n_owned; ++i)
+			if (!is_boundary[(size_t)i]) {
 				local_of_owned[(size_t)i] = (int)d->local_global.size();
 				d->local_global.push_back(o0 + i);
 			}
+	}
 	d->nB = 0;
 	for (char b : is_boundary) d->nB += b ? 1 : 0;
 	d->nI = n_owned - d->nB;

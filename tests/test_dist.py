@@ -64,6 +64,11 @@ def test_plan_properties(world, k, leaf_order):
     for r, d in enumerate(ranks):
         owner[d.owned_ids] = r
     ppos[part] = np.arange(n)
+
+    def holders(g):  # the other ranks that hold a copy of leaf g: owners of its neighbours; of the caller's leaf 0 (whose element 0 every rank mirrors): everybody else
+        if g == 0 and world > 1:
+            return tuple(q for q in range(world) if q != owner[0])
+        return tuple(sorted({int(owner[nb]) for nb in nbr[g] if nb >= 0 and owner[nb] != owner[g]}))
     plans = [(d.info(), d.local_leaves(), d.peers()) for d in ranks]
     depth = [99, 1, 2 * k - 1, 2 * k]
     vox = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij"), -1).reshape(-1, 3)  # x<<6|y<<3|z order
@@ -77,7 +82,9 @@ def test_plan_properties(world, k, leaf_order):
         is_b = (nb_owner != r).any(axis=1)
         if world > 1 and r == owner[0]:
             is_b[owned == 0] = True
-        assert loc[:nB].tolist() == owned[is_b].tolist() and loc[nB:nB + nI].tolist() == owned[~is_b].tolist()
+        # boundary leaves (and, below, ghosts) are ordered by WHO holds copies of them -- the sorted list of the other ranks, compared lexicographically --, then by
+        # position in the partition: a whole-leaf region is then a run of consecutive local leaves (it travels straight out of the field); interior leaves: partition order
+        assert loc[:nB].tolist() == sorted(owned[is_b].tolist(), key=lambda g: (holders(g), ppos[g])) and loc[nB:nB + nI].tolist() == owned[~is_b].tolist()
         ghosts = set(nbr[owned].reshape(-1).tolist()) - set(owned.tolist()) - {-1}
         if world > 1 and r != owner[0]:
             ghosts |= {0}
@@ -85,7 +92,7 @@ def test_plan_properties(world, k, leaf_order):
         assert [p.rank for p in peers] == sorted(p.rank for p in peers)
         pos = nB + nI
         for p in peers:  # ghosts grouped by owner, in partition order inside a group
-            mine = sorted((g for g in ghosts if owner[g] == p.rank), key=lambda g: ppos[g])
+            mine = sorted((g for g in ghosts if owner[g] == p.rank), key=lambda g: (holders(g), ppos[g]))
             assert loc[pos:pos + len(mine)].tolist() == mine
             pos += len(mine)
             # what I send to p is exactly what p expects from me: same leaves (global ids), same masks, same order
