@@ -122,6 +122,35 @@ def test_plan_properties(world, k, leaf_order):
         assert info["region_voxels_sent"]["advection inputs"] == sum(p.send[0].voxels for p in peers)
 
 
+def test_box_domains_keep_the_callers_leaf_order_and_the_plume_is_cut_along_its_axis():
+    """The partition rule of round 5 on the two shapes bench.py uses: `world` 256^3 slabs stacked along x (the weak-scaling domain: whole 128-voxel NanoVDB nodes per rank)
+    stay contiguous ranges of the caller's list -- rounds 1-4's partition, memory layout and all --, while BASELINE config 5's plume is cut into slabs along y, its own
+    axis, where every rank exchanges halos with the rank before and the rank behind it only."""
+    slab = fields.dense_leaves(256)
+    for world in (2, 8):
+        glob = HD.slab_domain(slab, 256, world)
+        for r in (0, world - 1):
+            d = HD.DistRank(glob, world, r, 1.0 / 256, 1, 0, plan_only=True)
+            b = HD.partition_bounds(len(glob), world)
+            assert d.partition_axis == -1 and d.first_owned == b[r] and d.owned_ids.tolist() == list(range(b[r], b[r + 1]))
+            # an end slab has one halo peer; `peers` also counts who it shares the element-0 mirror with: rank 0 owns the caller's leaf 0 and sends it to everybody
+            assert d.info()["halo_peers"] == 1 and d.info()["peers"] == (world - 1 if r == 0 else (1 if world == 2 else 2))
+            d.close()
+    d = HD.DistRank(HD.slab_domain(slab, 256, 8), 8, 3, 1.0 / 256, 1, 0, plan_only=True)
+    assert d.info()["halo_peers"] == 2 and d.info()["peers"] == 3  # rank 2, rank 4, and rank 0 (the element-0 mirror)
+    d.close()
+    origins, R = fields.config_leaves("plume1024")
+    info = []
+    for r in range(8):
+        d = HD.DistRank(origins, 8, r, 1.0 / R, 1, 2, plan_only=True)
+        assert d.partition_axis == 1 and d.first_owned == -1 and d.n_owned == len(origins) * (r + 1) // 8 - len(origins) * r // 8
+        info.append(d.info())
+        d.close()
+    assert [i["halo_peers"] for i in info] == [1, 2, 2, 2, 2, 2, 2, 1]
+    assert sorted(i["peers"] for i in info) == [2, 2, 2, 2, 3, 3, 3, 7]  # one more where the owner of the caller's leaf 0 is not a slab neighbour; that owner: everybody
+    assert HD.SlabBench._one_sided_k(len(origins), 8) == 2 and HD.SlabBench._one_sided_k(4800, 8) == 1  # the library's own rule (hns_dist_one_sided_sweeps)
+
+
 def _case(name):
     if name == "dense":
         return fields.dense_leaves(32), 32
