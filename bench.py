@@ -81,6 +81,7 @@ def parse():
     ap.add_argument("--cook", action="store_true", help="time the cook-equivalent hns_compute_sim call (upload + grid build + substep + download) instead")
     ap.add_argument("--full", action="store_true", help="time the FULL Compute_Sim substep instead (HNanoSolver.cu:150-356 on device-resident fields: five advected scalars, "
                                                         "combustion, buoyancy; SURVEY 8d's 812 B/voxel row) and print its own JSON line; single GPU")
+    ap.add_argument("--strong-timeout", type=int, default=600, help="seconds the strong_scaling record may take before it is abandoned and the headline printed without it (0 = no limit)")
     ap.add_argument("--no-strong", action="store_true", help="default workload only: skip the second record `strong_scaling` (BASELINE config 5, the 1024^3-extent plume "
                                                               "as ONE domain over the N ranks)")
     return ap.parse_args()
@@ -604,10 +605,27 @@ def main():
     if args.config == "256" and not args.partition and not args.no_strong:
         if world > 1:
             runner.rank_obj.close()
+        # The headline line must come out whatever happens to the second record. An exception is reported in its place; a HANG (a collective that never
+        # returns on a machine this path has not seen yet) is cut by an alarm on every rank: rank 0 prints the line with the headline and a note, and every
+        # rank leaves the process without touching the GPU again (a hung collective cannot be unwound; the children exit 0 so the launcher reports the line).
+        import signal
+
+        def strong_timed_out(signum, frame):
+            if rank == 0:
+                out["strong_scaling"] = {"error": f"the strong-scaling record did not complete within {args.strong_timeout} s and was abandoned; the headline above is complete"}
+                sys.stdout.write(json.dumps(out) + "\n")
+                sys.stdout.flush()
+            os._exit(0)
+
+        if args.strong_timeout > 0:
+            signal.signal(signal.SIGALRM, strong_timed_out)
+            signal.alarm(args.strong_timeout)
         try:
             strong = strong_scaling_record(args, world, rank, dt)
-        except Exception as e:  # noqa: BLE001 -- the headline line must come out whatever happens to the second record
+        except Exception as e:  # noqa: BLE001
             strong = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if args.strong_timeout > 0:
+            signal.alarm(0)
     if rank == 0:
         if strong is not None:
             out["strong_scaling"] = strong
