@@ -780,6 +780,11 @@ static int compute_sim_pipelined(hns_sim* s, FieldSplit& fs, int iterations, flo
 	const size_t count = (size_t)s->n;
 	s->sig_cur.resize(s->names.size(), 0);
 	s->dig_cur.resize(s->names.size(), 0);
+	{  // (refused before anything is enqueued: the digest kernels have 16 accumulators)
+		int checked = 0;
+		for (auto& r : resident) checked += r.second >= 2 ? 1 : 0;
+		if (checked > 16) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_compute_sim_resident: more than 16 CHECKED fields");
+	}
 	auto level_of = [&](const hns_field* f) {
 		for (auto& r : resident)
 			if (r.first == f) return r.second;
@@ -813,7 +818,6 @@ static int compute_sim_pipelined(hns_sim* s, FieldSplit& fs, int iterations, flo
 		}
 		if (bufs.empty()) return HNS_OK;
 		if (!s->d_dig) HNS_HIP(hipMalloc((void**)&s->d_dig, sizeof(unsigned long long) * 16));
-		if (bufs.size() > 16) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_compute_sim_resident: more than 16 checked fields");
 		HNS_HIP(hipMemsetAsync(s->d_dig, 0, sizeof(unsigned long long) * 16, on));
 		for (size_t i = 0; i < bufs.size(); ++i) HNS_TRY(hns_field_digest(bufs[i], dig_slots[i].second, s->d_dig + i, on));
 		return HNS_OK;
