@@ -455,16 +455,17 @@ namespace {
 // chunks of 128^3-voxel NanoVDB nodes and every rank touches SEVEN others: 14 point-to-point messages per exchange, 25+ exchanges per substep.
 // Here the leaves are put in slab order -- by leaf coordinate along ONE axis, the caller's order inside a plane of leaves --, THAT list is
 // cut into `world` equal ranges, and every range is put back into the caller's order: a rank touches the rank before and the rank behind it (plus the owner of the caller's leaf 0, whose element
-// 0 every rank mirrors). The axis is the one whose cuts cross the fewest leaves (the plume: y, its own axis -- 1,240 boundary leaves per rank
-// instead of 1,864, 2 halo peers instead of 7). If the cut along x selects the same leaf sets as the contiguous ranges did (every box domain
-// whose slabs are whole 128-voxel NanoVDB nodes: the weak-scaling slabs of bench.py), the caller's order is kept as it is: part_axis -1.
+// 0 every rank mirrors). The axis is the one whose cuts cross the fewest leaves (the plume: y, its own axis -- 1,398 boundary leaves per rank on average
+// instead of 1,914, 1 - 2 halo peers instead of 4 - 7). If the cut along x selects the same leaf sets as the contiguous ranges did (every box domain
+// whose slabs are whole 128-voxel NanoVDB nodes: the weak-scaling slabs of bench.py) AND costs no more than 1.1 x the cheapest cut, the caller's
+// order is kept as it is: part_axis -1.
 // order[i] = position in the caller's list of the i-th leaf in partition order. Every rank derives the same order from the same global list.
 int partition_order(const int32_t* origins, int64_t n, int world, bool leaf_order, std::vector<int64_t>& order) {
 	order.resize((size_t)n);
 	for (int64_t i = 0; i < n; ++i) order[(size_t)i] = i;
 	if (leaf_order || world <= 1 || n == 0) return -1;
-	std::vector<int64_t> best;
-	int64_t best_cost = -1;
+	std::vector<int64_t> best, along_x;
+	int64_t best_cost = -1, cost_x = -1;
 	int best_axis = -1;
 	for (int a = 0; a < 3; ++a) {
 		std::vector<int64_t> o = order;
@@ -482,18 +483,16 @@ int partition_order(const int32_t* origins, int64_t n, int world, bool leaf_orde
 			};
 			cost += plane(lo) + (hi != lo ? plane(hi) : 0);
 		}
+		if (a == 0) cost_x = cost, along_x = o;
 		if (best_cost < 0 || cost < best_cost) best_cost = cost, best_axis = a, best.swap(o);
 	}
-	// the same leaf sets as the contiguous ranges of the caller's order? Then that order stays (memory layout of a rank = the caller's)
-	bool same = true;
-	if (best_axis != 0) {  // (only the x cut can coincide with NanoVDB order; check it even if another axis is cheaper: equal sets keep rounds 1-4's layout)
-		std::vector<int64_t> o = order;
-		std::stable_sort(o.begin(), o.end(), [&](int64_t x, int64_t y) { return origins[(size_t)x * 3] < origins[(size_t)y * 3]; });
+	// Does the x cut select the same leaf sets as the contiguous ranges of the caller's order -- and is it (nearly) the cheapest cut? Then that order stays as it
+	// is: a rank's memory layout is the caller's, every whole-leaf region a slice of it (rounds 1-4's partition; bench.py's weak-scaling slabs)
+	bool same = cost_x >= 0 && cost_x * 10 <= best_cost * 11;
+	{
+		const std::vector<int64_t>& o = best_axis == 0 ? best : along_x;
 		for (int r = 0; r < world && same; ++r)
 			for (int64_t i = n * r / world; i < n * (r + 1) / world && same; ++i) same = o[(size_t)i] >= n * r / world && o[(size_t)i] < n * (r + 1) / world;
-	} else {
-		for (int r = 0; r < world && same; ++r)
-			for (int64_t i = n * r / world; i < n * (r + 1) / world && same; ++i) same = best[(size_t)i] >= n * r / world && best[(size_t)i] < n * (r + 1) / world;
 	}
 	if (same) return -1;
 	// the slabs decide WHICH leaves a rank owns; inside a rank they stay in the caller's order (a rank's memory layout then is NanoVDB order restricted to
