@@ -415,20 +415,38 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 	const int cx = (x - H + 8) >> 3, cy = (y - H + 8) >> 3;
 	const unsigned row_bytes = (unsigned)(((((x - H) & 7) << 3) | ((y - H) & 7)) * 32);
 	static_assert(LB == 2 && K == 2, "the store phase below is written for 16^3 blocks with a 4-voxel halo");
-	if (!PAR && t < 64) s_rec[t] = recs[(size_t)blockIdx.x * G::REC + t];  // the block record for the store phase (visible behind the staging barrier)
+	// (every id fetch below is UNCONDITIONAL -- lanes without a row / piece read entry 0 of the record and discard it: a conditional load is a branch with a
+	// wait for the loaded value at its end, and three of those in a row were three dependent memory round trips in front of the tile loads)
+	const int rec_word = recs[(size_t)blockIdx.x * G::REC + (t & 63)];  // the block record for the store phase: into LDS behind the tile loads' issue
 	const int* __restrict__ rec = recs + (size_t)blockIdx.x * G::REC + (LB == 1 ? 1 : 0) + (cx * C + cy) * C;
+	// The three id fetches -- the four leaf ids along z under the row this thread sweeps, those under the row (x2, y2) whose p it fetches (memory-order mapping, below)
+	// and the id under its rim piece -- are each issued as soon as their address is known and in front of everything that uses any of them (the scheduling barriers keep
+	// the order: left alone, the scheduler gathers the three behind ALL the address arithmetic, or pulls a use and its wait between them). Round 5 found them as three
+	// dependent round trips in front of the tile loads; now they are one.
+	static_assert(C == 4 && LB == 2, "the four ids along z are one aligned 16-byte piece of the record");
+	const int* brec = recs + (size_t)blockIdx.x * G::REC;
+	const int4 q4 = *reinterpret_cast<const int4*>(valid ? rec : brec);
+	__builtin_amdgcn_sched_barrier(0);
+	const int tid = t + (PAR ? G::SEC : 0);
+	const bool valid2 = tid < 2 * G::CROWS;
+	const int x2 = valid2 ? 1 + tid / G::TC : 1, y2 = valid2 ? 1 + tid - (x2 - 1) * G::TC : 1;
+	const int cx2 = (x2 - H + 8) >> 3, cy2 = (y2 - H + 8) >> 3;
+	const unsigned rb2 = (unsigned)(((((x2 - H) & 7) << 3) | ((y2 - H) & 7)) * 32);
+	const bool want2 = (DD || !ZERO) && valid2;
+	const int4 q2raw = *reinterpret_cast<const int4*>(brec + (want2 ? (cx2 * C + cy2) * C : 0));
+	__builtin_amdgcn_sched_barrier(0);
 	// Rim duty: the RIM rim rows of this parity (nobody updates them: the black values of p only, straight into LDS) as 16-byte pieces
 	// dealt over the section's threads. Side 0: x = 0, 1: x = T-1, 2: y = 0, 3: y = T-1; the m-th row of the right parity along the side.
 	// Only the pieces j = 1 .. NCH-2 are fetched: a rim row is H voxels from the block in x or y, so what it holds within H of the
 	// tile's z ends is more than H steps from every block voxel and never reaches one in 2K sweeps; those two pieces are zeroed.
-	// The piece's leaf id is fetched together with the row's own ids, its load issued in front of the row's: one memory round trip
-	// for ids, one for data.
+	// The piece's leaf id is fetched together with the row's own ids: one memory round trip for ids, one for data.
 	constexpr int NJ = 1, RJ = NCH - 2;
 	static_assert(G::RIM * RJ <= G::SEC && RJ == 4, "one rim piece per thread");
 	bool rim_on[NJ];
 	int rim_lds[NJ];       // float2 index of the piece in a colour array
 	unsigned rim_off[NJ];  // byte offset of the piece inside its leaf
-	int rim_id[NJ];
+	int rim_id[NJ], rim_at[NJ];  // (the piece's leaf id; where in the record it stands)
+	bool rim_want[NJ];
 	int rim_zero = 0;      // float2 offset of the end piece this thread zeroes (0: none)
 	{
 		constexpr int n = 0;
@@ -443,19 +461,17 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 		rim_lds[n] = (side >= 2 ? SbLdsDense<LB, K>::rim_row(rx) : SbLdsDense<LB, K>::row(rx, ry)) * HS4 * 2 + j;
 		// (a rim row off the block's own range in its other coordinate is more than H steps from every block voxel: it reads as 0)
 		const bool reach = along >= H && along < T - H;
-		rim_id[n] = (!ZERO && rim_on[n] && reach) ? recs[(size_t)blockIdx.x * G::REC + (LB == 1 ? 1 : 0) + (rcx * C + rcy) * C + rcz] : -1;
+		rim_want[n] = !ZERO && rim_on[n] && reach;
+		rim_at[n] = rim_want[n] ? (LB == 1 ? 1 : 0) + (rcx * C + rcy) * C + rcz : 0;
 		rim_zero = j == 1 ? -1 : (j == RJ ? 1 : 0);
 	}
+#pragma unroll
+	for (int n = 0; n < NJ; ++n) rim_id[n] = brec[rim_at[n]];
+	__builtin_amdgcn_sched_barrier(0);
 	unsigned base[C];
 	SbLeanRow<C, HALF> r;
 	int ids[C];
-	if (C == 4 && LB == 2) {  // (the four ids along z are one aligned 16-byte piece of the record)
-		const int4 q4 = valid ? *reinterpret_cast<const int4*>(rec) : make_int4(-1, -1, -1, -1);
-		ids[0] = q4.x, ids[1] = q4.y, ids[2] = q4.z, ids[C - 1] = q4.w;
-	} else {
-#pragma unroll
-		for (int cz = 0; cz < C; ++cz) ids[cz] = valid ? rec[cz] : -1;
-	}
+	ids[0] = valid ? q4.x : -1, ids[1] = valid ? q4.y : -1, ids[2] = valid ? q4.z : -1, ids[C - 1] = valid ? q4.w : -1;
 #pragma unroll
 	for (int cz = 0; cz < C; ++cz) {
 		r.ok[cz] = ids[cz] >= 0 ? 0xFFFFFFFFu : 0u;
@@ -474,23 +490,20 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 	}
 	const sb4i rp = sb_rsrc(p_in, field_bytes), rd = sb_rsrc(div, field_bytes), ro = sb_rsrc(p_out, field_bytes);
 	sb4f rimv[NJ], pc[NCH], dc[NCH];
-#pragma unroll
-	for (int n = 0; n < NJ; ++n) rimv[n] = ZERO ? sb4f{0.0f, 0.0f, 0.0f, 0.0f} : sb_load4(rp, (int)((unsigned)rim_id[n] * 2048u + rim_off[n]), 0, 0);  // (id -1: beyond the field, reads 0)
 	// p is fetched by a DIFFERENT thread than the one that sweeps the row: it only has to reach the row's LDS entry, so the interior rows
 	// are dealt over all threads in the order x, y -- both parities in one wave: its lanes are 32 bytes apart in memory and touch half
 	// the cache lines the parity-sorted sweep mapping would (256^3: 29.7 -> 26.5 us per iteration measured on the loads alone).
-	const int tid = t + (PAR ? G::SEC : 0);
-	const bool valid2 = tid < 2 * G::CROWS;
-	const int x2 = valid2 ? 1 + tid / G::TC : 1, y2 = valid2 ? 1 + tid - (x2 - 1) * G::TC : 1;
 	{
-		const int cx2 = (x2 - H + 8) >> 3, cy2 = (y2 - H + 8) >> 3;
-		const unsigned rb2 = (unsigned)(((((x2 - H) & 7) << 3) | ((y2 - H) & 7)) * 32);
-		const int4 q2 = ((DD || !ZERO) && valid2) ? *reinterpret_cast<const int4*>(recs + (size_t)blockIdx.x * G::REC + (cx2 * C + cy2) * C) : make_int4(-1, -1, -1, -1);
+		const int4 q2 = want2 ? q2raw : make_int4(-1, -1, -1, -1);
 		const int e2 = max(0, max(H - x2, x2 - (T - 1 - H))) + max(0, max(H - y2, y2 - (T - 1 - H)));  // (as for div above, one step further)
 		const unsigned base2[4] = {e2 > H - 1 ? kBeyond : (unsigned)q2.x * 2048u + rb2, e2 > H ? kBeyond : (unsigned)q2.y * 2048u + rb2,
 		                           e2 > H ? kBeyond : (unsigned)q2.z * 2048u + rb2, e2 > H - 1 ? kBeyond : (unsigned)q2.w * 2048u + rb2};
 #pragma unroll
 		for (int j = 0; j < NCH; ++j) pc[j] = ZERO ? sb4f{0.0f, 0.0f, 0.0f, 0.0f} : sb_load4(rp, (int)(base2[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
+		// (the rim piece behind them: its id was the last of the three to be asked for, and loads return in order)
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int n = 0; n < NJ; ++n) rimv[n] = ZERO ? sb4f{0.0f, 0.0f, 0.0f, 0.0f} : sb_load4(rp, (int)((unsigned)(rim_want[n] ? rim_id[n] : -1) * 2048u + rim_off[n]), 0, 0);  // (id -1: beyond the field, reads 0)
 		// DD (round 5; grids beyond 40k leaves, hns_rbgs_block_launch): div arrives in the memory-order mapping too -- the row (x2, y2) this
 		// thread fetches p of: lanes 32 bytes apart instead of 64, two thirds of the L1 accesses per instruction -- and WITHOUT passing through registers:
 		// buffer_load_dwordx4 ... lds drops piece j of thread tid at D[j * NT + tid] (a wave-instruction fills one contiguous KiB of LDS). The area D lies under the
@@ -521,6 +534,7 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 #pragma unroll
 		for (int j = 0; j < NCH; ++j) dc[j] = sb_load4(rd, (int)(base[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
 	}
+	if (!PAR && t < 64) s_rec[t] = rec_word;  // (visible behind the staging barrier)
 #pragma unroll
 	for (int n = 0; n < NJ; ++n) {
 		if (rim_on[n]) {
