@@ -5,6 +5,7 @@ unpack kernels, communication stream and events exactly as with RCCL).
 
   argv: config (256 | 128 | plume1024 ...)  world  [sweeps_per_exchange]   [--partition: split ONE config domain]
         [--leaf-order: contiguous ranges of the leaf list, the partition of rounds 1-4]  [--rank=N: the rank measured alone]
+        [--lone-only: nothing but that rank's loopback substeps -- for rocprofv3 --kernel-trace --stats of one rank's kernels]
 
 Weak scaling (default): `world` slabs of the config stacked along x. All ranks share the device, so the device time of a
 lockstep substep is compared with world x the plain single-GPU substep of one slab: their ratio is the per-rank overhead
@@ -42,6 +43,26 @@ def timed(fn, n=10, warm=3):
     return 1e3 * (time.perf_counter() - t0) / n
 
 
+lone_only = "--lone-only" in sys.argv
+if lone_only:
+    st = D.current_stream()
+    glob = origins if partition else HD.slab_domain(origins, R, world)
+    lone_rank = pick[0] if pick else (0 if world < 3 else world // 2)
+    lone = HD.DistRank(glob, world, lone_rank, vs, n_scalars=1, sweeps_per_exchange=k, leaf_order=leaf_order)
+    lone.connect_loopback()
+    own = glob[lone.owned_ids].copy()
+    if not partition:
+        own[:, 0] %= R
+    g = fields.synthetic_fields(own, R)
+    lone.upload(g["vel"], [g["density"]])
+    print(json.dumps({"config": config, "world": world, "rank": lone_rank, "one_rank_loopback_substep_ms": round(timed(lambda: lone.core_substep(iters, dt, st), n=20), 3), "info": {x: lone.info()[x] for x in ("boundary_leaves", "interior_leaves", "ghost_leaves", "peers", "halo_peers")}}))
+    # the same leaves (owned only) as a plain single-GPU grid: what the rank's work costs without being a rank
+    f = fields.synthetic_fields(own, R)
+    grid = api.create_grid_from_leaves(own, vs)
+    sim = D.Sim(grid, ["density"])
+    sim.upload({"vel": f["vel"], "density": f["density"]})
+    print(json.dumps({"owned_leaves_as_a_plain_grid_substep_ms": round(timed(lambda: sim.core_substep(iters, dt, vs, st), n=20), 3), "leaves": len(own)}))
+    sys.exit(0)
 f = fields.synthetic_fields(origins, R)
 grid = api.create_grid_from_leaves(origins, vs)
 sim = D.Sim(grid, ["density"])
