@@ -46,7 +46,7 @@ struct Options {
 	std::atomic<int> sor_block_lb{0};          // "sor_block_lb": temporally blocked SOR (hns_sorblock.hip), block edge in leaves: 0 = by size, 1, 2
 	std::atomic<int> sor_block_k{0};           // "sor_block_k": ... iterations per launch: 0 = by shape, 2, 4 (4: one-leaf blocks only)
 	std::atomic<int> sor_block_stagger{8};     // "sor_block_stagger": ... launch-start stagger of the two workgroups of a CU, x 1,024 cycles (0 = off; hns_sorblock.hip)
-	std::atomic<int> sor_block_lean{0};        // "sor_block_lean" = auto | 0 | 1 | dma (stored 0 / 1 / 2 / 3): ... its lean form (row state in LDS, three workgroups per CU); dma: div through LDS-DMA; auto = by size
+	std::atomic<int> sor_block_lean{0};        // "sor_block_lean" = auto | 0 | 1 | dma | xy (stored 0 .. 4): ... its lean forms (row state in LDS, three workgroups per CU); xy = auto: the sweep threads fetch their own rows; 1: waves sorted by parity; dma: 1 with div through LDS-DMA
 	std::atomic<int> sor_block_seg{0};         // "sor_block_seg": ... blocks per XCD segment of its launch order (0: one chunk per XCD; read when the block table is built)
 };
 Options& options();

@@ -1137,8 +1137,10 @@ int hns_grid_rbgs_plan(hns_grid* g, int iterations, char* description, uint64_t 
 		while (left >= 2) left -= (k_max >= 4 && left >= 4) ? 4 : 2, ++n;
 		n += left;
 		k = k_max;
-		snprintf(buf, sizeof(buf), "k_rbgs_block<%d,%d>: %d red+black iterations per launch on %s blocks with a %d-voxel halo, p read and written once per launch%s", lb, k_max, k_max,
-		         lb == 1 ? "one-leaf (8^3-voxel)" : "16^3-voxel", 2 * k_max, hns_rbgs_block_lean(g, lb, k_max) ? " (lean form: rows in LDS, three workgroups per CU)" : "");
+		const bool lean = hns_rbgs_block_lean(g, lb, k_max), xy = lean && (options().sor_block_lean.load() & ~4) == 0;  // (auto | xy)
+		snprintf(buf, sizeof(buf), "k_rbgs_block%s<%d,%d>: %d red+black iterations per launch on %s blocks with a %d-voxel halo, p read and written once per launch%s", xy ? "_xy" : "", lb, k_max, k_max,
+		         lb == 1 ? "one-leaf (8^3-voxel)" : "16^3-voxel", 2 * k_max,
+		         !lean ? "" : (xy ? " (XY form: rows in LDS, three workgroups per CU, the sweep threads fetch their own rows)" : " (lean form: rows in LDS, three workgroups per CU, waves sorted by parity)"));
 	} else {
 		const int form = rbgs_form(g, opt == kRbgsBlock ? kRbgsAuto : opt);
 		const char* names[] = {"?", "k_rbgs_color: two launches per iteration, in place (the reference's decomposition)", "k_rbgs_wave: one launch = one red+black iteration, one wave per leaf",

@@ -630,6 +630,251 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The XY form of the lean kernel (round 5): the thread that SWEEPS a row is the thread that FETCHES it.
+// The lean form sorts the rows by the parity of x+y into two sections of waves so that the parity is a template parameter of the sweep code; the price is that a wave's rows lie
+// 64 bytes apart in memory (every other z-row of a leaf) -- ~40 L1 accesses per load instruction -- which is why p goes through a separate fetch mapping and div either pays the 40
+// or takes the LDS-DMA detour with its two barriers. Round 5 measured that instructions are not what this kernel waits for, and that div fetched at coalesced addresses WITHOUT a
+// hand-over would be worth 5.7 % at 256^3 (r05_sorblock_notes.txt 11). So here thread t owns the interior row (x, y) = (1 + t / 22, 1 + t % 22): consecutive lanes are consecutive z-rows
+// of a leaf (32 bytes apart: ~24 accesses per instruction for p AND div), the parity is a per-lane value (pointer selects at the staging, two selects per updated voxel for the z
+// neighbours), there is no fetch mapping, no hand-over and no section. LDS: the same 50,880 bytes, the rows of BOTH parities in one (x, y) order -- a wave's 64 rows are 64 consecutive
+// entries of either colour array, so the 16-byte accesses at the 48-byte row stride stay free of bank conflicts:
+//   black array: planes x = 0 .. T-1, rows y = 1 .. T-2 (entry x * TC + y - 1), then the rim rows y = 0 / y = T-1 of every plane (entry T * TC + 2 x + (y != 0));
+//   red array:   planes x = 1 .. T-2 only (entry (x - 1) * TC + y - 1 = the row's black entry - TC): nobody reads a red value of plane 0 / T-1 or of a rim row.
+// A row's colour arrays hold its red / black values in ascending z (which z are red depends on the row's parity: even z if x+y is even); the four lateral neighbours of a voxel have the
+// other colour at the same index of their rows' arrays (sb_sweep_lean). Voxels within S of the tile's z rim are stale at sweep S: the j ranges below are the UNION over both parities of
+// what the lean form computes (40 instead of 38 updates per row; a stale value is only ever read by stale voxels).
+// ---------------------------------------------------------------------------------------------------------------
+struct SbLdsXY {
+	using G = SbGeo<2, 2>;
+	static constexpr int T = G::T, TC = G::TC, HS4 = G::HS4;
+	static constexpr int NB = (T * TC + 2 * T) * HS4, NR = TC * TC * HS4;  // float4
+	float4 a[NB + NR];  // (padding between the two arrays -- 48 / 64 / 128 bytes -- was measured: nothing, runs/r05ar.sh)
+	__device__ __forceinline__ float4* black() { return a; }
+	__device__ __forceinline__ float4* red() { return a + NB; }
+	static __device__ __forceinline__ int brow(int x, int y) { return x * TC + y - 1; }            // black entry of an interior-y row of any plane
+	static __device__ __forceinline__ int brim(int x, int y) { return T * TC + 2 * x + (y != 0); }  // black entry of a rim row (y = 0 or T-1)
+};
+static_assert(sizeof(SbLdsXY) == sizeof(SbLdsDense<2, 2>), "the XY form must fit three workgroups per CU like the lean form");
+
+// one colour sweep S of the row this thread owns: entry `bi` in the black array, bi - TC in the red one; par = (x + y) & 1; yp / ym = black entries of the rows (x, y +- 1)
+template <int S, bool MASKED, class Row>
+__device__ __forceinline__ void sb_sweep_xy(Row& r, SbLdsXY& L, const int bi, const int ypb, const int ymb, const int par, const int dist, const float omega) {
+	using G = SbGeo<2, 2>;
+	constexpr int H = G::H, HALF = G::HALF, HS4 = G::HS4, NQ = G::NQ, TC = G::TC, K = 2;
+	constexpr bool red = (S & 1) != 0;
+	const float(&dX)[HALF] = red ? r.dR : r.dB;
+	// the colour being updated at z' = 2j + zo: zo = 1 ("up") for the red voxels of an odd row and the black voxels of an even one
+	const bool up = red ? par != 0 : par == 0;
+	// updated: S <= z' <= T-1-S; union over zo = 0 / 1 (see above)
+	constexpr int jlo = S / 2, jhi = (G::T - 1 - S) / 2 + 1;
+	constexpr int qlo = jlo / 4, qhi = (jhi + 3) / 4;
+	if (dist >= S) {
+		// red sweep: own red at bi - TC (red array), own black at bi, lateral neighbours' black at bi +- TC, ypb, ymb.
+		// black sweep (dist >= 2: every neighbour is an interior row of planes 1 .. T-2): own black at bi, own red at bi - TC, neighbours' red at bi - TC +- TC, bi - TC +- 1.
+		sb4f* LXo4 = reinterpret_cast<sb4f*>((red ? L.red() + (bi - TC) * HS4 : L.black() + bi * HS4));
+		const sb4f* LYo4 = reinterpret_cast<const sb4f*>((red ? L.black() + bi * HS4 : L.red() + (bi - TC) * HS4));
+		const float4* LY = red ? L.black() : L.red() - TC * HS4;  // (indexed with BLACK entry numbers either way)
+		float Y[HALF];
+#pragma unroll
+		for (int q = 0; q < NQ; ++q) {
+			const sb4f y4 = LYo4[q];
+			Y[4 * q] = y4.x, Y[4 * q + 1] = y4.y, Y[4 * q + 2] = y4.z, Y[4 * q + 3] = y4.w;
+		}
+		const sb4f* pxp = reinterpret_cast<const sb4f*>(LY + (bi + TC) * HS4);
+		const sb4f* pxm = reinterpret_cast<const sb4f*>(LY + (bi - TC) * HS4);
+		const sb4f* pyp = reinterpret_cast<const sb4f*>(LY + (red ? ypb : bi + 1) * HS4);
+		const sb4f* pym = reinterpret_cast<const sb4f*>(LY + (red ? ymb : bi - 1) * HS4);
+#pragma unroll
+		for (int q = qlo; q < qhi; ++q) {
+			sb4f x4 = LXo4[q], xp4 = pxp[q], xm4 = pxm[q], yp4 = pyp[q], ym4 = pym[q];
+			if (4 * q < jlo || 4 * q + 4 > jhi) {  // a piece only part of which is updated: keep its accesses whole (sb_sweep_lean)
+				asm volatile("" : "+v"(x4));
+				asm volatile("" : "+v"(xp4));
+				asm volatile("" : "+v"(xm4));
+				asm volatile("" : "+v"(yp4));
+				asm volatile("" : "+v"(ym4));
+			}
+			float X[4] = {x4.x, x4.y, x4.z, x4.w};
+			const float xp[4] = {xp4.x, xp4.y, xp4.z, xp4.w}, xm[4] = {xm4.x, xm4.y, xm4.z, xm4.w}, yp[4] = {yp4.x, yp4.y, yp4.z, yp4.w}, ym[4] = {ym4.x, ym4.y, ym4.z, ym4.w};
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				const int j = 4 * q + e;
+				if (j < jlo || j >= jhi) continue;
+				const float below = j > 0 ? Y[j > 0 ? j - 1 : 0] : 0.0f, above = j + 1 < HALF ? Y[j + 1 < HALF ? j + 1 : 0] : 0.0f;
+				const float zm = up ? Y[j] : below, zp = up ? above : Y[j];
+				const float pGS = ((xp[e] + xm[e] + yp[e] + ym[e] + zp + zm) - dX[j]) * kInv6;  // Kernel.cu:621 (dX = div * dx^2)
+				const float cand = X[e] + omega * (pGS - X[e]);                                   // Kernel.cu:622
+				const int cz = (2 * j - H + 8) >> 3;
+				X[e] = MASKED ? __uint_as_float(__float_as_uint(cand) & r.ok[cz]) : cand;
+			}
+			sb4f o4 = sb4f{X[0], X[1], X[2], X[3]};
+			if (4 * q < jlo || 4 * q + 4 > jhi) asm volatile("" : "+v"(o4));
+			LXo4[q] = o4;
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+	if (S < 2 * K) __syncthreads();
+}
+
+template <int S, bool MASKED>
+struct SbSweepsXY {
+	template <class Row>
+	static __device__ __forceinline__ void run(Row& r, SbLdsXY& L, const int bi, const int ypb, const int ymb, const int par, const int dist, const float omega) {
+		sb_sweep_xy<S, MASKED>(r, L, bi, ypb, ymb, par, dist, omega);
+		if constexpr (S < 4) SbSweepsXY<S + 1, MASKED>::run(r, L, bi, ypb, ymb, par, dist, omega);
+	}
+};
+
+// M = NoMirror, or PhaseMirror for the chained sweep of a multi-GPU rank (k_rbgs_block, which see: boundary workgroups wait for the peers' previous launch and store what the peers
+// read of their boundary leaves into the peers' ghost copies as well)
+template <bool ZERO, class M = NoMirror>
+__global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__((SbGeo<2, 2>::NT)) void k_rbgs_block_xy(const int* __restrict__ recs, const int* __restrict__ any_absent, const float* __restrict__ div, const float* __restrict__ p_in,
+                                                                                                                float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega, const M m = M{}) {
+	using G = SbGeo<2, 2>;
+	constexpr int H = G::H, T = G::T, C = G::C, HALF = G::HALF, NCH = G::NCH, HS4 = G::HS4, TC = G::TC;
+	__shared__ SbLdsXY L;
+	__shared__ int s_rec[64];
+	const int t = threadIdx.x;
+	int chain_leaf = 0x7fffffff;  // (chain_begin / chain_end take a leaf number: below n_boundary = "this workgroup waits and mirrors")
+	if constexpr (!std::is_same<M, NoMirror>::value) {
+		if (__builtin_amdgcn_readfirstlane(any_absent[blockIdx.x]) & 2) chain_leaf = 0;
+		chain_begin(m, chain_leaf);
+		__syncthreads();
+	}
+	const bool valid = t < TC * TC;
+	const int xq = valid ? t / TC : 0;
+	const int x = 1 + xq, y = valid ? 1 + t - xq * TC : 1;
+	const int par = (x + y) & 1;
+	const int bi = SbLdsXY::brow(x, y);
+	const int ypb = y == T - 2 ? SbLdsXY::brim(x, T - 1) : bi + 1, ymb = y == 1 ? SbLdsXY::brim(x, 0) : bi - 1;
+	const int dist = valid ? min(min(x, T - 1 - x), min(y, T - 1 - y)) : -1;
+	const int cx = (x - H + 8) >> 3, cy = (y - H + 8) >> 3;
+	const unsigned row_bytes = (unsigned)(((((x - H) & 7) << 3) | ((y - H) & 7)) * 32);
+	const int* brec = recs + (size_t)blockIdx.x * G::REC;
+	// (id fetches: unconditional, each issued as soon as its address is known, nothing that uses one between them -- see sb_body_lean)
+	const int rec_word = brec[t & 63];
+	const int4 q4 = *reinterpret_cast<const int4*>(brec + (valid ? (cx * C + cy) * C : 0));
+	__builtin_amdgcn_sched_barrier(0);
+	// rim duty: the black values of the rows of the planes x = 0 / T-1 and of the rim rows y = 0 / T-1 (nobody updates them), one 16-byte piece j = 1 .. NCH-2 per thread (the end
+	// pieces cannot reach the block and are zeroed); a rim row off the block's own range in its other coordinate cannot either and reads as 0
+	constexpr int RJ = NCH - 2, NRIM = 4 * TC;
+	static_assert(NRIM * RJ <= G::NT && RJ == 4, "one rim piece per thread");
+	const bool rim_on = t < NRIM * RJ;
+	int rim_b2, rim_zero, rim_par;  // (float2 index of the piece in the black array)
+	unsigned rim_off;
+	bool rim_want;
+	int rim_at;
+	{
+		const int mr = rim_on ? t >> 2 : 0, j = 1 + (t & 3);
+		const int side = mr / TC, along = 1 + (mr - side * TC);
+		const int rx = side == 0 ? 0 : (side == 1 ? T - 1 : along), ry = side == 2 ? 0 : (side == 3 ? T - 1 : along);
+		const int rcx = (rx - H + 8) >> 3, rcy = (ry - H + 8) >> 3, rcz = (4 * j - H + 8) >> 3;
+		rim_off = (unsigned)(((((rx - H) & 7) << 3) | ((ry - H) & 7)) * 32 + ((4 * j - H) & 7) * 4);
+		rim_b2 = (side >= 2 ? SbLdsXY::brim(rx, ry) : SbLdsXY::brow(rx, ry)) * HS4 * 2 + j;
+		rim_par = (rx + ry) & 1;
+		rim_want = !ZERO && rim_on && along >= H && along < T - H;
+		rim_at = rim_want ? (rcx * C + rcy) * C + rcz : 0;
+		rim_zero = j == 1 ? -1 : (j == RJ ? 1 : 0);
+	}
+	const int rim_id = brec[rim_at];
+	const int meta_word = any_absent[blockIdx.x];
+	__builtin_amdgcn_sched_barrier(0);
+	SbLeanRow<C, HALF> r;
+	unsigned base[C], dbase[C];  // where the row's pieces lie in p / in div (what cannot reach the block in 2K sweeps -- div: 2K - 1 -- is not fetched: an offset beyond the field reads 0)
+	constexpr unsigned kBeyond = 0xFFFFF000u;
+	{
+		const int ids[C] = {valid ? q4.x : -1, valid ? q4.y : -1, valid ? q4.z : -1, valid ? q4.w : -1};
+		const int e = max(0, max(H - x, x - (T - 1 - H))) + max(0, max(H - y, y - (T - 1 - H)));
+#pragma unroll
+		for (int cz = 0; cz < C; ++cz) {
+			r.ok[cz] = ids[cz] >= 0 ? 0xFFFFFFFFu : 0u;
+			const unsigned b = (unsigned)ids[cz] * 2048u + row_bytes;
+			const bool end = cz == 0 || cz == C - 1;  // (the end pieces are the only users of the first and last leaf cell along z)
+			base[cz] = e > (end ? H - 1 : H) ? kBeyond : b;
+			dbase[cz] = e > (end ? H - 2 : H - 1) ? kBeyond : b;
+		}
+	}
+	const sb4i rp = sb_rsrc(p_in, field_bytes), rd = sb_rsrc(div, field_bytes), ro = sb_rsrc(p_out, field_bytes);
+	sb4f pc[NCH], dc[NCH], rimv;
+#pragma unroll
+	for (int j = 0; j < NCH; ++j) pc[j] = ZERO ? sb4f{0.0f, 0.0f, 0.0f, 0.0f} : sb_load4(rp, (int)(base[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
+	__builtin_amdgcn_sched_barrier(0);
+	rimv = ZERO ? sb4f{0.0f, 0.0f, 0.0f, 0.0f} : sb_load4(rp, (int)((unsigned)(rim_want ? rim_id : -1) * 2048u + rim_off), 0, 0);
+#pragma unroll
+	for (int j = 0; j < NCH; ++j) dc[j] = sb_load4(rd, (int)(dbase[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
+	if (t < 64) s_rec[t] = rec_word;  // (the block record for the store phase; visible behind the staging barrier)
+	if (rim_on) {
+		float2* LK = reinterpret_cast<float2*>(L.black()) + rim_b2;  // (black only: even z of a row with odd x+y, odd z of one with even x+y)
+		*LK = rim_par ? make_float2(rimv.x, rimv.z) : make_float2(rimv.y, rimv.w);
+		if (rim_zero) LK[rim_zero] = make_float2(0.0f, 0.0f);
+	}
+	if (valid) {
+		// the row's p split by colour: its even z are red if x+y is even, black if odd
+		float4* LE = par ? L.black() + bi * HS4 : L.red() + (bi - TC) * HS4;
+		float4* LO = par ? L.red() + (bi - TC) * HS4 : L.black() + bi * HS4;
+#pragma unroll
+		for (int q = 0; q < G::NQ; ++q) {
+			const sb4f u = pc[2 * q], v = pc[2 * q + 1];
+			LE[q] = make_float4(u.x, u.z, v.x, v.z);
+			LO[q] = make_float4(u.y, u.w, v.y, v.w);
+		}
+	}
+	const int meta = __builtin_amdgcn_readfirstlane(meta_word);
+#pragma unroll
+	for (int j = 0; j < NCH; ++j) {
+		const float d0 = dc[j].x * dx2, d1 = dc[j].y * dx2, d2 = dc[j].z * dx2, d3 = dc[j].w * dx2;  // Kernel.cu:621: divVal * dx2
+		r.dR[2 * j] = par ? d1 : d0, r.dB[2 * j] = par ? d0 : d1;
+		r.dR[2 * j + 1] = par ? d3 : d2, r.dB[2 * j + 1] = par ? d2 : d3;
+	}
+	__syncthreads();
+	if ((meta & 1) == 0)
+		SbSweepsXY<1, false>::run(r, L, bi, ypb, ymb, par, dist, omega);
+	else
+		SbSweepsXY<1, true>::run(r, L, bi, ypb, ymb, par, dist, omega);
+	// store phase (sb_body_lean): the block's 16 x 16 rows x four 16-byte pieces in memory order, values out of the rows' LDS entries, leaf ids out of the record's LDS copy
+	__syncthreads();
+	{
+		int mirror_id[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // chained rank: the block's leaves this launch stores, as scalars (-1: not stored)
+		if constexpr (!std::is_same<M, NoMirror>::value) {
+			if (meta & 2) {
+#pragma unroll
+				for (int c = 0; c < 8; ++c)
+					mirror_id[c] = (meta >> (8 + c)) & 1 ? __builtin_amdgcn_readfirstlane(s_rec[((1 + (c >> 2)) * C + 1 + ((c >> 1) & 1)) * C + 1 + (c & 1)]) : -1;
+			}
+		}
+		const float2* B2 = reinterpret_cast<const float2*>(L.black());
+		const float2* R2 = reinterpret_cast<const float2*>(L.red());
+#pragma unroll
+		for (int n = 0; n < 2; ++n) {
+			const int pq = t + n * G::NT;
+			const int jz = pq & 1, yy = (pq >> 1) & 15, czb = (pq >> 5) & 1, xx = pq >> 6;
+			const int sx = xx + H, sy = yy + H, j = H / 4 + 2 * czb + jz;
+			const int sp = (sx + sy) & 1;
+			const int sb = SbLdsXY::brow(sx, sy);
+			const float2 rr = R2[(sb - TC) * HS4 * 2 + j], bb = B2[sb * HS4 * 2 + j];
+			const int cell = (((xx >> 3) << 1) | (yy >> 3)) << 1 | czb;
+			const int id = (meta >> (8 + cell)) & 1 ? s_rec[((1 + (xx >> 3)) * C + 1 + (yy >> 3)) * C + 1 + czb] : -1;  // (a leaf outside the launch range is a source only)
+			sb4f v;
+			v.x = sp ? bb.x : rr.x, v.y = sp ? rr.x : bb.x, v.z = sp ? bb.y : rr.y, v.w = sp ? rr.y : bb.y;
+			sb_store4(v, ro, (int)((unsigned)id * 2048u + (unsigned)((((xx & 7) << 3) | (yy & 7)) * 32 + jz * 16)), 0, 0);
+			if constexpr (!std::is_same<M, NoMirror>::value) {
+				// (sb_body_lean: piece n of every thread lies in the block's x half n, the walk over that half's four leaves and over a leaf's table entries is wave-uniform)
+				if (meta & 2) {
+#pragma unroll
+					for (int cc = 0; cc < 4; ++cc) {
+						const int c = 4 * n + cc;
+						const int lc = mirror_id[c];
+						if (lc < 0 || lc >= m.n_boundary) continue;
+						chain_store_piece(m, lc, c == cell, ((xx & 7) << 3) | (yy & 7), jz, v);
+					}
+				}
+			}
+		}
+	}
+	if constexpr (!std::is_same<M, NoMirror>::value) chain_end(m, chain_leaf);
+}
+
 // recs: one record per workgroup, in launch order. LB = 1: {leaf, nbr27[27]} (the grid's d_blk); LB = 2: the 4 x 4 x 4 leaves
 // under the tile, cell (cx, cy, cz) at (cx*4 + cy)*4 + cz, -1 = absent. ZERO: p_in is known to be 0 (first launch of a solve,
 // HNanoSolver.cu:113) and is not read. The first half of the workgroup's waves takes the rows with even x+y, the second half
@@ -845,7 +1090,8 @@ int hns_rbgs_block_shape(hns_grid* g, int* k_max) {
 // 16^3 blocks are swept by the lean form (row state in LDS, three workgroups per CU, dense LDS rows, p fetched and stored in memory
 // order); the rows-in-registers form remains for one-leaf blocks and as a cross-check. us per iteration, registers -> lean: 512 leaves
 // in 64 blocks 3.70 -> 3.37, 128^3 6.57 -> 5.62, 4k-leaf plume 8.34 -> 6.64, 256^3 35.3 -> 27.2, 512^3 304 -> 273, 66k-leaf plume
-// 84.8 -> 74.2 (profiles/r03_sorblock_notes.txt 11-12). Option "sor_block_lean" = auto | 0 | 1 | dma (1 with div through LDS-DMA at every size: what auto takes beyond 40k leaves).
+// 84.8 -> 74.2 (profiles/r03_sorblock_notes.txt 11-12). Option "sor_block_lean" = auto | 0 | 1 | dma | xy: auto = xy (k_rbgs_block_xy, round 5: the sweep threads fetch their own rows; a further
+// 128^3 5.57 -> 5.04, 256^3 25.4 -> 22.8, 66k-leaf plume 62.0 -> 59.3, 512^3 226 -> 220); 1 = the parity-sorted form, with div through LDS-DMA beyond 40k leaves (dma: at every size).
 bool hns_rbgs_block_lean(hns_grid* g, int lb, int k) {
 	if (lb != 2 || k != 2) return false;
 	if (g->first_active != 0 || g->n_active != (uint64_t)g->topo.n_leaves) return true;  // (only the lean form knows which leaves of a block a launch range stores)
@@ -885,7 +1131,13 @@ int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const fl
 		// div through LDS-DMA in the memory-order mapping where the sweep runs out of the cache (sb_body_lean, DD): 512^3 250 -> 238 us per iteration, the 66k-leaf
 		// plume 67.5 -> 65.2; at 256^3 and below the two extra barriers cost more than the accesses save (26.9 -> 27.7, 128^3 5.55 -> 5.86)
 		const bool dd = g->n_active > 40000 || options().sor_block_lean.load() == 3;  // ("sor_block_lean" = dma forces it: tests)
-		if (dd && src_is_zero)
+		const int lean_word = options().sor_block_lean.load();  // 0 auto | 2 "1" | 3 "dma" | 4 "xy"
+		if (lean_word == 0 || lean_word == 4) {  // the XY form (the sweep threads are the fetch threads: k_rbgs_block_xy), the default at every size since round 5
+			if (src_is_zero)
+				hipLaunchKernelGGL(k_rbgs_block_xy<true>, dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega);
+			else
+				hipLaunchKernelGGL(k_rbgs_block_xy<false>, dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega);
+		} else if (dd && src_is_zero)
 			hipLaunchKernelGGL((k_rbgs_block<2, 2, true, true, NoMirror, true>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, sl);
 		else if (dd)
 			hipLaunchKernelGGL((k_rbgs_block<2, 2, false, true, NoMirror, true>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, sl);
@@ -914,7 +1166,12 @@ extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_block_mirror_launc
 	}
 	if (!tab || !n_sb) return fail(HNS_ERR_RUNTIME, "hns_rbgs_block_mirror_launch: no block records");
 	const float dx2 = dx * dx;  // Kernel.cu:608
-	if (src_is_zero)
+	const bool xy = options().sor_block_lean.load() == 0 || options().sor_block_lean.load() == 4;  // (auto | xy; "1" keeps the parity-sorted lean form)
+	if (xy && src_is_zero)
+		hipLaunchKernelGGL((k_rbgs_block_xy<true, PhaseMirror>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, *m);
+	else if (xy)
+		hipLaunchKernelGGL((k_rbgs_block_xy<false, PhaseMirror>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, *m);
+	else if (src_is_zero)
 		hipLaunchKernelGGL((k_rbgs_block<2, 2, true, true, PhaseMirror>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, 0, *m);
 	else
 		hipLaunchKernelGGL((k_rbgs_block<2, 2, false, true, PhaseMirror>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, 0, *m);

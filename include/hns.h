@@ -66,9 +66,11 @@ int hns_trim_memory(void);
  *                   iterations per launch on a block of leaves with a halo, hns_sorblock.hip). auto: by grid size
  *   "sor_block_lb"  0 = by size | 1 | 2: block edge of the temporally blocked form, in leaves
  *   "sor_block_k"   0 = by shape | 2 | 4: its iterations per launch (4: one-leaf blocks only)
- *   "sor_block_lean" auto | 0 | 1 | dma: 16^3-voxel blocks with the rows' p kept in LDS and three workgroups per CU (1) or in registers and two (0);
- *                   dma = 1 with div fetched in memory order by LDS-DMA and handed to the row owners through LDS (fewer L1 accesses, two more
- *                   barriers). auto = 1 up to 40k leaves, dma beyond (where the sweep runs out of the cache); the registers form is a cross-check.
+ *   "sor_block_lean" auto | 0 | 1 | dma | xy: 16^3-voxel blocks with the rows' p kept in LDS and three workgroups per CU (1, dma, xy) or in registers and two (0).
+ *                   xy (round 5, what auto takes at every size): the thread that sweeps a row fetches it -- rows owned in (x, y) order, a wave's lanes 32 bytes apart
+ *                   in memory for p AND div, the parity of x+y a per-lane value. 1: waves sorted by that parity (a template parameter of the sweep code), p through a
+ *                   separate fetch mapping; dma = 1 with div fetched in memory order by LDS-DMA and handed to the row owners through LDS (what 1 takes beyond 40k
+ *                   leaves). 0, 1 and dma are cross-checks now.
  *   "sor_block_seg" N: its blocks per XCD segment of the launch order (0: one chunk per XCD; read when the block table is built)
  *   "sor_block_stagger" N: its launch-start stagger between the two workgroups of a CU, x 1,024 cycles (default 8; 0 = off)
  *   "advect"        auto | generic (64-bit addressed advection kernels)

@@ -55,6 +55,7 @@ VARIANTS = {
     "sor_two_iterations_per_launch_16cube_blocks": {"rbgs": "block", "sor_block_lb": "2", "sor_block_k": "2", "sor_block_lean": "0"},
     "sor_two_iterations_per_launch_16cube_blocks_rows_in_lds": {"rbgs": "block", "sor_block_lb": "2", "sor_block_k": "2", "sor_block_lean": "1"},
     "sor_two_iterations_per_launch_16cube_blocks_div_by_lds_dma": {"rbgs": "block", "sor_block_lb": "2", "sor_block_k": "2", "sor_block_lean": "dma"},
+    "sor_two_iterations_per_launch_16cube_blocks_sweep_threads_fetch": {"rbgs": "block", "sor_block_lb": "2", "sor_block_k": "2", "sor_block_lean": "xy"},  # the default of 16^3 blocks since round 5
     "schedule_linear": {"schedule": "linear"},
     "sor_one_direction": {"alternate": "0", "rbgs": "pair"},
     "all_kernels_forwards": {"rev": "0"},

@@ -12,7 +12,7 @@ from oracle_lib import OracleGrid
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(1, 2), (1, 4), (2, 2), (2, -2), (2, -3)]  # (block edge in leaves, iterations per launch; negative: the lean form of the 16^3 blocks; -3: with div through LDS-DMA)
+SHAPES = [(1, 2), (1, 4), (2, 2), (2, -2), (2, -3), (2, -5)]  # (block edge in leaves, iterations per launch; negative: the lean form of the 16^3 blocks; -3: with div through LDS-DMA; -5: the XY form)
 
 
 def leaf_sets():
@@ -41,8 +41,9 @@ def restore_options():
 
 def solve(grid, div, p0, iters, **opts):
     if "sor_block_k" in opts:  # rows in registers (two workgroups per CU) or in LDS (three): forced either way, whatever the size
-        opts["sor_block_lean"] = {True: "1", False: "0"}[int(opts["sor_block_k"]) < 0] if int(opts["sor_block_k"]) != -3 else "dma"
-        opts["sor_block_k"] = 2 if int(opts["sor_block_k"]) == -3 else abs(int(opts["sor_block_k"]))
+        k = int(opts["sor_block_k"])
+        opts["sor_block_lean"] = {-3: "dma", -5: "xy"}.get(k, "1" if k < 0 else "0")
+        opts["sor_block_k"] = 2 if k in (-3, -5) else abs(k)
     for k, v in opts.items():
         H.set_option(k, str(v))
     p_a = p0.clone()
