@@ -37,7 +37,7 @@ class hns_dist_stats(C.Structure):
     _fields_ = [("world", C.c_int), ("rank", C.c_int), ("peers", C.c_int), ("sweeps_per_exchange", C.c_int),
                 ("boundary_leaves", C.c_uint64), ("interior_leaves", C.c_uint64), ("ghost_leaves", C.c_uint64),
                 ("region_voxels_sent", C.c_uint64 * 4), ("bytes_sent", C.c_uint64 * 4), ("messages_sent", C.c_uint64), ("exchanges", C.c_uint64),
-                ("halo_peers", C.c_uint64)]
+                ("halo_peers", C.c_uint64), ("packed_exchanges", C.c_uint64)]
 
 
 HNS_DIST_IPC_BLOB_BYTES = 2048

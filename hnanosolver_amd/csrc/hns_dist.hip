@@ -354,6 +354,7 @@ struct Peer {
 
 struct Pending {  // an exchange that has been posted and not yet consumed
 	bool active = false;
+	bool prepacked = false;  // the boundary kernel wrote the messages itself (PackMirror): no pack launch
 	int type = 0, parity = 0;
 	hipStream_t stream = nullptr;  // where its boundary kernel, packing, transfer and unpacking run
 	std::vector<std::pair<float*, int>> fields;  // (device field, ncomp) in message order
@@ -430,10 +431,14 @@ struct hns_dist {
 		const unsigned char* mask = nullptr;  // null: whole leaves
 	} mir_type[4];
 	unsigned n_boundary_records = 0;
+	// the blocked boundary sweep of the exchanged pressure loop packs its own messages (hns_flags.hpp: PackMirror): tables per region type (X_D1, X_P), one allocation
+	void* pack_tables = nullptr;
+	PackMirror pack_type[4];
+	bool pack_ok[4] = {false, false, false, false};
 	bool chain = false;         // ... and every other kernel of the substep delivers its own halo too (no communication stream at all)
 	uint32_t sweep_seq = 0;
 	// statistics of the last substep
-	uint64_t bytes_sent[X_COUNT] = {0, 0, 0, 0}, messages_sent = 0, exchanges = 0;
+	uint64_t bytes_sent[X_COUNT] = {0, 0, 0, 0}, messages_sent = 0, exchanges = 0, packed_exchanges = 0;
 	// hipEvent bracketing of the pressure loop (communication included)
 	bool timing = false;
 	std::vector<hipEvent_t> tev;
@@ -813,7 +818,75 @@ void hns_dist_destroy(hns_dist* d) {
 		if (g) hns_grid_destroy(g);
 	if (d->arena) hns_arena_put(d->arena, d->arena_bytes, d->device);
 	if (d->tables) (void)hipFree(d->tables);
+	if (d->pack_tables) (void)hipFree(d->pack_tables);
 	delete d;
+}
+
+// PackMirror tables of the region types the exchanged pressure loop sends (X_P between blocks of sweeps, X_D1 behind the last): per boundary leaf the peers that read it, where its
+// first travelling voxel stands in that peer's message, its 64-byte mask and the count of travelling voxels in front of each row. A peer whose region travels straight out of the
+// field (whole consecutive leaves) has no entries: nothing is packed for it either way.
+static int build_pack_tables(hns_dist* d) {
+	if (d->world < 2 || d->peers.empty() || d->peers.size() > (size_t)kMirrorMaxPeers || d->nB == 0) return HNS_OK;
+	struct Host {
+		std::vector<int> first;
+		std::vector<int2> entry;
+		std::vector<unsigned char> mask;
+		std::vector<unsigned short> pre;
+	} h[4];
+	size_t bytes = 0;
+	for (int t : {X_D1, X_P}) {
+		std::vector<std::vector<std::pair<int, int>>> of((size_t)d->nB);  // per boundary leaf: (peer index, index in that peer's region)
+		bool fits = true;
+		for (size_t pi = 0; pi < d->peers.size(); ++pi) {
+			const Region& r = d->peers[pi].send[t];
+			if (r.direct >= 0) continue;
+			for (size_t i = 0; i < r.leaf.size(); ++i) {
+				if (r.leaf[i] < 0 || r.leaf[i] >= d->nB) fits = false;
+				else of[(size_t)r.leaf[i]].emplace_back((int)pi, (int)i);
+			}
+		}
+		if (!fits) continue;
+		Host& o = h[t];
+		o.first.assign((size_t)d->nB + 1, 0);
+		for (int l = 0; l < d->nB; ++l) {
+			o.first[(size_t)l] = (int)o.entry.size();
+			for (auto& e : of[(size_t)l]) {
+				const Region& r = d->peers[(size_t)e.first].send[t];
+				o.entry.push_back(make_int2(e.first, r.off[(size_t)e.second]));
+				const unsigned char* m = r.mask.data() + (size_t)e.second * 64;
+				o.mask.insert(o.mask.end(), m, m + 64);
+				unsigned short run = 0;
+				for (int row = 0; row < 64; ++row) {
+					o.pre.push_back(run);
+					run = (unsigned short)(run + __builtin_popcount(m[row]));
+				}
+			}
+		}
+		o.first[(size_t)d->nB] = (int)o.entry.size();
+		bytes += pad256(sizeof(int) * o.first.size()) + pad256(sizeof(int2) * o.entry.size()) + pad256(o.mask.size()) + pad256(sizeof(unsigned short) * o.pre.size());
+		d->pack_ok[t] = true;
+	}
+	if (!bytes) return HNS_OK;
+	if (hipMalloc(&d->pack_tables, bytes) != hipSuccess) return fail(HNS_ERR_HIP, "hns_dist_create: allocating the pack tables failed");
+	char* q = (char*)d->pack_tables;
+	int rc = HNS_OK;
+	auto put = [&](const void* src, size_t n) -> void* {
+		void* r = q;
+		if (n && hipMemcpy(q, src, n, hipMemcpyHostToDevice) != hipSuccess) rc = fail(HNS_ERR_HIP, "hns_dist_create: uploading the pack tables failed");
+		q += pad256(n);
+		return r;
+	};
+	for (int t : {X_D1, X_P}) {
+		if (!d->pack_ok[t]) continue;
+		PackMirror& m = d->pack_type[t];
+		m.n_boundary = d->nB;
+		m.first = (const int*)put(h[t].first.data(), sizeof(int) * h[t].first.size());
+		m.entry = (const int2*)put(h[t].entry.data(), sizeof(int2) * h[t].entry.size());
+		m.mask = (const unsigned char*)put(h[t].mask.data(), h[t].mask.size());
+		m.row_pre = (const unsigned short*)put(h[t].pre.data(), sizeof(unsigned short) * h[t].pre.size());
+		for (int i = 0; i < kMirrorMaxPeers; ++i) m.msg[i] = nullptr;
+	}
+	return rc;
 }
 
 hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_leaves, int world, int rank, float voxel_size, int n_scalars,
@@ -876,7 +949,7 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 		// boundary waves poll, store twice and signal, and as the head of XCD 0's chunk they made that XCD the last to finish)
 		if (i == 2 && (sweeps_per_exchange == 1 || blocked_mirror(d)) && options().dist_spread.load() != 0) (*gs[i])->sched_prefix = (uint64_t)d->nB;
 		// the chained blocked sweep (hns_sorblock.hip) must know which leaves of the owned range are boundary leaves whatever the launch order is
-		if (i == 2) (*gs[i])->chain_boundary = (uint64_t)d->nB;
+		if (i == 2 || i == 0) (*gs[i])->chain_boundary = (uint64_t)d->nB;  // (the boundary range too: its blocked sweep may pack the peers' messages, build_pack_tables)
 		if ((rc = hns_grid_set_active_range(*gs[i], first[i], count[i])) != HNS_OK) return bail(rc);
 		if ((rc = hns_grid_set_outside_element(*gs[i], outside)) != HNS_OK) return bail(rc);
 	}
@@ -974,6 +1047,7 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 				}
 		if (rc != HNS_OK) return bail(rc);
 	}
+	if ((rc = build_pack_tables(d)) != HNS_OK) return bail(rc);
 	for (int i = 0; i < 2; ++i)
 		if (hipEventCreateWithFlags(&d->ev_post[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ev_done[i], hipEventDisableTiming) != hipSuccess)
 			return bail(fail(HNS_ERR_HIP, "hns_dist_create: event creation failed"));
@@ -1241,7 +1315,7 @@ int hns_dist_info(const hns_dist* d, hns_dist_stats* out) {
 		out->bytes_sent[t] = d->bytes_sent[t];
 		for (const Peer& p : d->peers) out->region_voxels_sent[t] += (uint64_t)p.send[t].voxels;
 	}
-	out->messages_sent = d->messages_sent, out->exchanges = d->exchanges;
+	out->messages_sent = d->messages_sent, out->exchanges = d->exchanges, out->packed_exchanges = d->packed_exchanges;
 	for (const Peer& p : d->peers) {
 		bool halo = false;
 		for (int t = 1; t < X_COUNT; ++t) halo = halo || p.send[t].voxels || p.recv[t].voxels;
@@ -1427,8 +1501,10 @@ int post(hns_dist* d, int type, std::vector<std::pair<float*, int>> fields, hipS
 		HNS_HIP(hipEventRecord(d->ev_ready, st));
 		HNS_HIP(hipStreamWaitEvent(cs, d->ev_ready, 0));
 	}
+	x.prepacked = false;
 	HNS_TRY(boundary(cs));
-	HNS_TRY(halo_copy_exchange(d, true, x, cs));
+	if (!x.prepacked) HNS_TRY(halo_copy_exchange(d, true, x, cs));
+	else ++d->packed_exchanges;
 	for (Peer& p : d->peers) {
 		const size_t fl = message_floats(x, p.send[type]);
 		if (fl) d->bytes_sent[type] += sizeof(float) * fl, ++d->messages_sent;
@@ -1641,7 +1717,21 @@ struct Step {
 		auto part = [=](hns_grid* g, hipStream_t s) {
 			return g->n_active ? hns_rbgs_iterate(g, D->div, s0, d0, vs, omega_compute(vs), tail, nullptr, s, zero) : (int)HNS_OK;
 		};
-		HNS_TRY(post(d, last ? X_D1 : X_P, Fields{{dst, 1}}, st, [=](hipStream_t s) { return part(D->gB, s); }));
+		const int xt = last ? X_D1 : X_P;
+		HNS_TRY(post(d, xt, Fields{{dst, 1}}, st, [=](hipStream_t s) -> int {
+			// two iterations in one blocked launch: the boundary sweep writes the peers' messages as it stores (PackMirror; option "dist_pack")
+			if (tail == 2 && D->pack_ok[xt] && options().dist_pack.load() != 0) {
+				PackMirror m = D->pack_type[xt];
+				for (size_t pi = 0; pi < D->peers.size(); ++pi) m.msg[pi] = D->peers[pi].sbuf[D->pending.parity];
+				bool done = false;
+				HNS_TRY(hns_rbgs_block_pack_launch(D->gB, D->div, s0, d0, vs, omega_compute(vs), zero, &m, s, &done));
+				if (done) {
+					D->pending.prepacked = true;
+					return HNS_OK;
+				}
+			}
+			return part(D->gB, s);
+		}));
 		HNS_TRY(part(d->gI, st));
 		std::swap(src, dst);
 		it += tail;
@@ -1896,7 +1986,7 @@ int hns_dist_core_substep(hns_dist* d, int iterations, float dt, void* stream) {
 	if (!d->local_ranks.empty() && d->world > 1) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_core_substep: locally connected ranks step together (hns_dist_local_core_substep)");
 	if (d->ipc_status && *(volatile int*)d->ipc_status) return fail(HNS_ERR_RUNTIME, "hns_dist: a peer did not answer within 20 s (one-sided transport); results are invalid");
 	memset(d->bytes_sent, 0, sizeof(d->bytes_sent));
-	d->messages_sent = d->exchanges = 0;
+	d->messages_sent = d->exchanges = d->packed_exchanges = 0;
 	Step s{d, iterations, dt, (hipStream_t)stream};
 	for (int ph = 0, n = s.n_phases(); ph < n; ++ph) HNS_TRY(s.run(ph));
 	return HNS_OK;
@@ -1910,7 +2000,7 @@ int hns_dist_local_core_substep(hns_dist* const* ranks, int world, int iteration
 		HNS_TRY(check_step(ranks[r], iterations, dt));
 		if ((int)ranks[r]->local_ranks.size() != world) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_local_core_substep: ranks are not locally connected");
 		memset(ranks[r]->bytes_sent, 0, sizeof(ranks[r]->bytes_sent));
-		ranks[r]->messages_sent = ranks[r]->exchanges = 0;
+		ranks[r]->messages_sent = ranks[r]->exchanges = ranks[r]->packed_exchanges = 0;
 		steps.push_back(Step{ranks[r], iterations, dt, (hipStream_t)stream});
 	}
 	// a message may be the sender's field itself (whole-leaf regions are not packed): every rank takes delivery of the previous
@@ -1955,7 +2045,7 @@ int hns_dist_sim_substep(hns_dist* d, int iterations, float dt, const hns_combus
 	if (!d->local_ranks.empty() && d->world > 1) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_sim_substep: locally connected ranks step together (hns_dist_local_sim_substep)");
 	if (d->ipc_status && *(volatile int*)d->ipc_status) return fail(HNS_ERR_RUNTIME, "hns_dist: a peer did not answer within 20 s (one-sided transport); results are invalid");
 	memset(d->bytes_sent, 0, sizeof(d->bytes_sent));
-	d->messages_sent = d->exchanges = 0;
+	d->messages_sent = d->exchanges = d->packed_exchanges = 0;
 	Step s{d, iterations, dt, (hipStream_t)stream};
 	HNS_TRY(sim_step_args(d, params, field_index, has_collision, s));
 	for (int ph = 0, n = s.n_phases(); ph < n; ++ph) HNS_TRY(s.run(ph));
@@ -1970,7 +2060,7 @@ int hns_dist_local_sim_substep(hns_dist* const* ranks, int world, int iterations
 		HNS_TRY(check_step(ranks[r], iterations, dt));
 		if ((int)ranks[r]->local_ranks.size() != world) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dist_local_sim_substep: ranks are not locally connected");
 		memset(ranks[r]->bytes_sent, 0, sizeof(ranks[r]->bytes_sent));
-		ranks[r]->messages_sent = ranks[r]->exchanges = 0;
+		ranks[r]->messages_sent = ranks[r]->exchanges = ranks[r]->packed_exchanges = 0;
 		steps.push_back(Step{ranks[r], iterations, dt, (hipStream_t)stream});
 		HNS_TRY(sim_step_args(ranks[r], params, field_index, has_collision, steps.back()));
 	}

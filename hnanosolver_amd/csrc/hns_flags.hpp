@@ -82,10 +82,23 @@ struct PhaseMirror {
 };
 struct NoMirror {};  // the same kernels on a single GPU: every chain_* call below compiles to nothing
 
+// The blocked boundary sweep of an EXCHANGED pressure loop (RCCL / loopback / local transports; hns_dist.hip: sor_block_exchanged) packs its own message: the voxels a peer reads of
+// a boundary leaf go into that peer's send buffer in the message order (leaves in region order, rows x*8+y ascending, z ascending, travelling voxels only) as the block is stored --
+// plain stores, the send that follows reads them in stream order -- and the separate pack launch (7.5 us in a chain of four latency-bound launches per exchange) is gone.
+struct PackMirror {
+	int n_boundary;                 // local leaves [0, n_boundary) may have entries
+	const int* first;               // [n_boundary + 1]: entries of leaf l are first[l] .. first[l + 1]
+	const int2* entry;              // {peer index, voxel offset of the leaf's first travelling voxel in that peer's message}
+	const unsigned char* mask;      // 64 bytes per entry: byte x*8+y, bit z = the voxel travels
+	const unsigned short* row_pre;  // 64 per entry: travelling voxels of the leaf in front of row x*8+y
+	float* msg[kMirrorMaxPeers];    // the peers' send buffers of this exchange
+};
+
 __device__ __forceinline__ float* chain_out(const PhaseMirror& m, int peer, int out) { return (float*)(m.peer_arena[peer] + (size_t)m.out_unit[out] * m.peer_unit[peer]); }
 
 // first thing in every workgroup (before any ghost voxel is read; multi-wave workgroups need a barrier after it)
 __device__ __forceinline__ void chain_begin(const NoMirror&, int) {}
+__device__ __forceinline__ void chain_begin(const PackMirror&, int) {}
 __device__ __forceinline__ void chain_begin(const PhaseMirror& m, int leaf) {
 	leaf = __builtin_amdgcn_readfirstlane(leaf);  // (workgroup-uniform: keeps everything derived from it in scalar registers)
 	// this launch has started, so the previous launch of this rank is complete (every boundary workgroup waited for its
@@ -96,6 +109,7 @@ __device__ __forceinline__ void chain_begin(const PhaseMirror& m, int leaf) {
 }
 // last thing in every workgroup
 __device__ __forceinline__ void chain_end(const NoMirror&, int) {}
+__device__ __forceinline__ void chain_end(const PackMirror&, int) {}
 __device__ __forceinline__ void chain_end(const PhaseMirror& m, int leaf) {
 	if (__builtin_amdgcn_readfirstlane(leaf) < m.n_boundary) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -397,6 +397,24 @@ __device__ __forceinline__ void chain_store_piece(const PhaseMirror& m, int leaf
 	}
 }
 
+// the same piece into the peers' MESSAGES (PackMirror: the boundary sweep of an exchanged pressure loop packs what it stores)
+__device__ __forceinline__ void chain_store_piece(const PackMirror& m, int leaf, bool mine, int row, int half, sb4f v) {
+	const int e1 = m.first[leaf + 1];
+	for (int e = m.first[leaf]; e < e1; ++e) {
+		const int2 t = m.entry[e];
+		if (!mine) continue;
+		const unsigned byte = m.mask[(size_t)e * 64 + row];
+		const unsigned bits = (byte >> (4 * half)) & 0xFu;
+		if (!bits) continue;
+		float* q = m.msg[t.x] + (size_t)t.y + m.row_pre[(size_t)e * 64 + row] + __popc(byte & ((1u << (4 * half)) - 1u));
+		const float f[4] = {v.x, v.y, v.z, v.w};
+		int c = 0;
+#pragma unroll
+		for (int z = 0; z < 4; ++z)
+			if (bits >> z & 1) q[c++] = f[z];
+	}
+}
+
 template <int LB, int K, bool ZERO, bool PAR, class M = NoMirror, bool DD = false>
 __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, const int t, const int* __restrict__ recs, const int* __restrict__ any_absent, const float* __restrict__ div,
                                              const float* __restrict__ p_in, float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega, const M& m = M{}) {
@@ -1148,6 +1166,31 @@ int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const fl
 	} else if (lb == 2 && k == 2) SB_LAUNCH(2, 2, sb_tab, n_sb);
 	else return fail(HNS_ERR_INVALID_ARGUMENT, "hns_rbgs_block_launch: unsupported block shape");
 #undef SB_LAUNCH
+	return HNS_OK;
+}
+
+// The boundary sweep of an exchanged pressure loop that packs its own messages (hns_flags.hpp: PackMirror), two iterations per launch over the grid's launch range (the rank's
+// boundary leaves); *done = false and nothing launched where that range is not swept in 16^3 blocks by the XY form.
+extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_block_pack_launch(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero,
+                                                                                 const hns::PackMirror* m, void* stream, bool* done) {
+	*done = false;
+	int k = 0;
+	const int lw = options().sor_block_lean.load();
+	if ((lw != 0 && lw != 4) || hns_rbgs_block_shape(g, &k) != 2 || k != 2 || !hns_rbgs_block_lean(g, 2, 2)) return HNS_OK;
+	const unsigned bytes = (unsigned)((size_t)g->topo.n_leaves * 2048u);
+	const int* tab;
+	uint64_t n_sb;
+	{
+		std::lock_guard<std::mutex> lock(g->build_mutex);
+		tab = (const int*)g->d_sb_tab, n_sb = g->n_sb;
+	}
+	if (!tab || !n_sb) return HNS_OK;
+	const float dx2 = dx * dx;  // Kernel.cu:608
+	if (src_is_zero)
+		hipLaunchKernelGGL((k_rbgs_block_xy<true, PackMirror>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, *m);
+	else
+		hipLaunchKernelGGL((k_rbgs_block_xy<false, PackMirror>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, *m);
+	*done = true;
 	return HNS_OK;
 }
 

@@ -160,6 +160,7 @@ const OptionDesc kOptions[] = {
     {"divergence", &Options::divergence_form, kWordsDivergence},
     {"dist_spread", &Options::dist_spread, kWordsBool},
     {"dist_block", &Options::dist_block, kWordsBool},
+    {"dist_pack", &Options::dist_pack, kWordsBool},
     {"dist_chain", &Options::dist_chain, kWordsBool},
 };
 const Options kDefaults;

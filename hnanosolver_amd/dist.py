@@ -108,7 +108,7 @@ class DistRank:
         return {"world": s.world, "rank": s.rank, "peers": s.peers, "halo_peers": int(s.halo_peers), "sweeps_per_exchange": s.sweeps_per_exchange, "boundary_leaves": int(s.boundary_leaves),
                 "interior_leaves": int(s.interior_leaves), "ghost_leaves": int(s.ghost_leaves),
                 "region_voxels_sent": dict(zip(REGION_TYPES, [int(x) for x in s.region_voxels_sent])),
-                "bytes_sent": dict(zip(REGION_TYPES, [int(x) for x in s.bytes_sent])), "messages_sent": int(s.messages_sent), "exchanges": int(s.exchanges)}
+                "bytes_sent": dict(zip(REGION_TYPES, [int(x) for x in s.bytes_sent])), "messages_sent": int(s.messages_sent), "exchanges": int(s.exchanges), "packed_exchanges": int(s.packed_exchanges)}
 
     def local_leaves(self) -> np.ndarray:
         i = self.info()

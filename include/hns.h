@@ -88,6 +88,7 @@ int hns_trim_memory(void);
  *                   LDS (auto: the latter from 16,384 leaves)
  *   "dist_block"    1 | 0: a rank with sweeps_per_exchange >= 2 sweeps its boundary and interior launch ranges with the temporally
  *                   blocked SOR form, two iterations per launch, ghost leaves as tile sources (0 = one iteration per launch)
+ *   "dist_pack"     1 | 0: that boundary sweep (exchanged pressure loop, sweeps_per_exchange = 2) writes the voxels its peers read straight into their messages: no pack launch per exchange
  *   "dist_spread"   1 | 0: hns_dist_create with sweeps_per_exchange = 1 deals the boundary leaves of the owned launch range out
  *                   to all XCDs first
  *   "dist_mirror"   1 | 0 | guarded: with sweeps_per_exchange = 1 over the ipc or local transport the SOR sweep writes its boundary rows
@@ -337,6 +338,7 @@ typedef struct {
 	uint64_t messages_sent, exchanges; /* point-to-point messages / exchange rounds of the last substep              */
 	uint64_t halo_peers; /* peers this rank exchanges div / p / reach-1 halo voxels with (slab partition: the rank before and the rank behind it);
 	                        `peers` also counts ranks it only shares the element-0 mirror of the caller's leaf 0 with (its owner: every rank) */
+	uint64_t packed_exchanges; /* exchanges of the last substep whose messages the boundary sweep wrote itself (no pack launch; option "dist_pack") */
 } hns_dist_stats;
 
 /* sweeps_per_exchange (1..4, 0 = default 4): the pressure loop refreshes the ghosts of p after every k-th fused sweep and

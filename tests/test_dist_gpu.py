@@ -113,6 +113,31 @@ def test_exchanged_ranks_with_and_without_blocked_range_sweeps(name, world, k, b
         H.set_option("dist_block", None)
 
 
+@pytest.mark.parametrize("pack", [1, 0])
+def test_exchanged_blocked_boundary_sweep_packs_its_own_messages(pack):
+    """Round 5: on the exchanged path (option dist_mirror = 0 over the local transport = what RCCL ranks run) with sweeps_per_exchange = 2 and a boundary
+    range of more than 600 leaves, the boundary sweep of the XY form writes the voxels its peers read straight into their messages (PackMirror) and the
+    pack launch is skipped; dist_pack = 0 keeps the pack launch. Either way the owned voxels equal the single grid bit for bit."""
+    import hnanosolver_amd as H
+
+    R, world, iters = 208, 2, 6
+    origins = fields.dense_leaves(R)  # 26^3 leaves: a slab face is 676 boundary leaves, swept in 16^3 blocks
+    names = ["density"]
+    _, want = single_grid(origins, R, names, iters, 1)
+    H.set_option("dist_mirror", "0")
+    H.set_option("dist_pack", str(pack))
+    try:
+        ranks, b = run_local(origins, R, world, 2, names, iters, 1)
+        check(ranks, b, want, names)
+        info = [d.info() for d in ranks]
+    finally:
+        H.set_option("dist_mirror", None)
+        H.set_option("dist_pack", None)
+    assert all(i["boundary_leaves"] > 600 for i in info), info
+    # three exchanges of p per substep (6 iterations, two per exchange), every one packed by the boundary sweep -- or none
+    assert all(i["packed_exchanges"] == (iters // 2 if pack else 0) for i in info), [(i["packed_exchanges"], i["exchanges"]) for i in info]
+
+
 def test_chained_blocked_sweep_does_not_depend_on_the_launch_order_option():
     """dist_spread = 0 (boundary leaves / blocks not dealt out to all XCDs first) changes the launch order only: which blocks wait
     for the peers and mirror their boundary leaves is a property of the plan."""
