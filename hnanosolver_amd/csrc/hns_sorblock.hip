@@ -754,12 +754,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__((SbGeo<2
 	__shared__ SbLdsXY L;
 	__shared__ int s_rec[64];
 	const int t = threadIdx.x;
-	int chain_leaf = 0x7fffffff;  // (chain_begin / chain_end take a leaf number: below n_boundary = "this workgroup waits and mirrors")
-	if constexpr (!std::is_same<M, NoMirror>::value) {
-		if (__builtin_amdgcn_readfirstlane(any_absent[blockIdx.x]) & 2) chain_leaf = 0;
-		chain_begin(m, chain_leaf);
-		__syncthreads();
-	}
 	const bool valid = t < TC * TC;
 	const int xq = valid ? t / TC : 0;
 	const int x = 1 + xq, y = valid ? 1 + t - xq * TC : 1;
@@ -812,6 +806,14 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__((SbGeo<2
 			base[cz] = e > (end ? H - 1 : H) ? kBeyond : b;
 			dbase[cz] = e > (end ? H - 2 : H - 1) ? kBeyond : b;
 		}
+	}
+	// A chained rank's boundary workgroup waits for the peers' previous launch HERE -- behind the id fetches, which read nothing a peer writes, and in front of the first load that can touch
+	// a ghost voxel: the flag's round trip overlaps the ids' instead of preceding it.
+	int chain_leaf = 0x7fffffff;  // (chain_begin / chain_end take a leaf number: below n_boundary = "this workgroup waits and mirrors")
+	if constexpr (!std::is_same<M, NoMirror>::value) {
+		if (__builtin_amdgcn_readfirstlane(meta_word) & 2) chain_leaf = 0;
+		chain_begin(m, chain_leaf);
+		__syncthreads();
 	}
 	const sb4i rp = sb_rsrc(p_in, field_bytes), rd = sb_rsrc(div, field_bytes), ro = sb_rsrc(p_out, field_bytes);
 	sb4f pc[NCH], dc[NCH], rimv;
