@@ -901,7 +901,41 @@ __global__ __launch_bounds__(64) void k_divergence_row(const GridDev g, const fl
 	int slot, src, RF;
 	face_duty(l, slot, src, RF);
 	float h[24];
-	if (l < 32) glb_row3(u, rec[1 + slot], src, h);
+	if constexpr (COAL) {
+		// (round 5) the four lateral face layers in memory order too: face f's eight Vec3f rows are 8 x 96 bytes -- one contiguous 768-byte run for the x faces, eight 96-byte runs for the y
+		// faces -- fetched by 48 lanes, a 16-byte piece each, ONE instruction per face (12-16 L1 accesses) instead of one row per lane (32 lanes x six instructions, every lane on a cache
+		// line of its own: 192 accesses); handed to the face-row lanes through the hand-over buffer, which the own rows have left by then. A timing-only build without these loads
+		// ran 10 us faster at 256^3 (profiles/r05_divergence_face_bounds.txt).
+		float4 fv[4];
+		const int fr = l / 6, fk = l - fr * 6;  // lane -> (row of the face, piece of the row), l < 48
+#pragma unroll
+		for (int f = 0; f < 4; ++f) {
+			const int nf = __builtin_amdgcn_readfirstlane(rec[1 + (f == 0 ? 4 : (f == 1 ? 22 : (f == 2 ? 10 : 16)))]);
+			const int srow = f == 0 ? 56 + fr : (f == 1 ? fr : (f == 2 ? fr * 8 + 7 : fr * 8));
+			const float4* q = reinterpret_cast<const float4*>(u + ((size_t)(nf < 0 ? 0 : nf) * 512 + srow * 8) * 3) + fk;
+			fv[f] = (nf >= 0 && l < 48) ? *q : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();  // (every lane has read its own row out of s_own)
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		if (l < 48) {
+#pragma unroll
+			for (int f = 0; f < 4; ++f) s_own[f * 48 + l] = fv[f];
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		if (l < 32) {
+			const int f = l >> 3, i = l & 7;
+#pragma unroll
+			for (int k = 0; k < 6; ++k) {
+				const float4 w = s_own[f * 48 + i * 6 + k];
+				h[4 * k] = w.x, h[4 * k + 1] = w.y, h[4 * k + 2] = w.z, h[4 * k + 3] = w.w;
+			}
+		}
+	} else {
+		if (l < 32) glb_row3(u, rec[1 + slot], src, h);
+	}
 
 	float ux[8], uy[8];
 #pragma unroll
