@@ -35,9 +35,11 @@ __device__ v3f hns_buffer_load_v3f32(v4i rsrc, int voffset, int soffset, int aux
 __device__ float hns_buffer_load_f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 typedef float v2f32 __attribute__((ext_vector_type(2)));
 __device__ v2f32 hns_buffer_load_v2f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+__device__ v4f32 hns_buffer_load_v4f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 
 constexpr unsigned kOutside = 0xFFFFE000u;        // float-field byte offsets at or above this read as 0 (and 3x it still lies past a Vec3f field)
-constexpr uint64_t kNarrowBytes = 0xFFFF0000ull;  // largest Vec3f field the 32-bit path accepts
+constexpr uint64_t kNarrowBytes = 0xFFFF0000ull;  // largest Vec3f field the 32-bit path accepts (and largest 16-byte-per-voxel field of the q4 path)
 
 __device__ __forceinline__ v4i field_rsrc(const float* p, unsigned bytes) {
 	const unsigned long long a = (unsigned long long)p;
@@ -547,6 +549,10 @@ struct ScalarPtrs {
 	const float* in[HNS_MAX_SCALARS];
 	float* out[HNS_MAX_SCALARS];
 	int n;
+	// k_advect_scalars_n<true> (round 6): four more fields that arrive as ONE 16-byte element per voxel -- {fuel, waste, temperature, flame} as the fused
+	// divergence / combustion kernel leaves them (hns_pressure.hip: CombustFuse) -- and leave as four float arrays like every other field
+	const float* q4;
+	float* q4_out[4];
 };
 
 // setupInterpolation (Kernel.cu:163-196): indices and weights in the order 000,100,010,110,001,101,011,111 of (x,y,z)
@@ -568,6 +574,10 @@ __device__ __forceinline__ void interp_from_taps(const Taps& T, int oob, int (&i
 }
 
 // 32-bit addressed form (no collision field). Out-of-domain taps read element g.oob, as in the generic kernel.
+// Q4: besides the P.n float fields, the four fields of P.q4. A corner tap of those four is ONE 16-byte gather instead of four 4-byte (z-paired: 8-byte) ones: the
+// kernel is bound by L1 accesses per gather instruction (profiles/r05_advect_notes.txt 2), and a quad of lanes costs an access whatever its width -- sixteen
+// gathers for the four fields' two samples instead of thirty-two. Per field the arithmetic is the same chain of fused multiply-adds in the same order.
+template <bool Q4>
 __global__ __launch_bounds__(512) void k_advect_scalars_n(const GridDev g, const float* __restrict__ u, const ScalarPtrs P, const float scaled_dt) {
 	__shared__ int s_nbr[27];
 	__shared__ int s_base[27];
@@ -617,6 +627,42 @@ __global__ __launch_bounds__(512) void k_advect_scalars_n(const GridDev g, const
 	const int e[6] = {tile_nbr<0, -1>(n), tile_nbr<0, 1>(n), tile_nbr<1, -1>(n), tile_nbr<1, 1>(n), tile_nbr<2, -1>(n), tile_nbr<2, 1>(n)};
 	unsigned ho = n < 384 ? halo_off(s_b4, n) : 0u;
 	ho = ho >= kOutside ? oob4 : ho;  // out-of-domain neighbours read element g.oob here (Kernel.cu:225)
+	if constexpr (Q4) {
+		__shared__ v4f32 s_tile4[kTile];
+		const v4i rq = field_rsrc(P.q4, bytes1 * 4u);  // element = 16 bytes: byte offset = 4 x the float-field byte offset
+		const v4f32 phiOrig = hns_buffer_load_v4f32(rq, (int)(own << 2), 0, 0);
+		s_tile4[n] = phiOrig;
+		if (n < 384) s_tile4[512 + n] = hns_buffer_load_v4f32(rq, (int)(ho << 2), 0, 0);
+		v4f32 phiF = {0.0f, 0.0f, 0.0f, 0.0f}, phiB = {0.0f, 0.0f, 0.0f, 0.0f};
+		{
+			v4f32 c[8];
+#pragma unroll
+			for (int q = 0; q < 8; ++q) c[q] = hns_buffer_load_v4f32(rq, (int)(bo[q] << 2), 0, 0);
+#pragma unroll
+			for (int q = 0; q < 8; ++q) phiF = __builtin_elementwise_fma(c[q], v4f32{bw[q], bw[q], bw[q], bw[q]}, phiF);
+		}
+		{
+			v4f32 c[8];
+#pragma unroll
+			for (int q = 0; q < 8; ++q) c[q] = hns_buffer_load_v4f32(rq, (int)(fo[q] << 2), 0, 0);
+#pragma unroll
+			for (int q = 0; q < 8; ++q) phiB = __builtin_elementwise_fma(c[q], v4f32{fw[q], fw[q], fw[q], fw[q]}, phiB);
+		}
+		const v4f32 error = phiOrig - phiB;
+		const v4f32 phiCorr = __builtin_elementwise_fma(v4f32{0.5f, 0.5f, 0.5f, 0.5f}, error, phiF);
+		__syncthreads();
+		v4f32 mn = phiOrig, mx = phiOrig;
+#pragma unroll
+		for (int d = 0; d < 6; ++d) {
+			const v4f32 v = s_tile4[e[d]];
+			mn = __builtin_elementwise_min(mn, v);
+			mx = __builtin_elementwise_max(mx, v);
+		}
+		mn = __builtin_elementwise_min(mn, phiF);
+		mx = __builtin_elementwise_max(mx, phiF);
+		const v4f32 r = __builtin_elementwise_max(mn, __builtin_elementwise_min(phiCorr, mx));
+		P.q4_out[0][idx] = r.x, P.q4_out[1][idx] = r.y, P.q4_out[2][idx] = r.z, P.q4_out[3][idx] = r.w;
+	}
 	for (int s = 0; s < P.n; ++s) {
 		const v4i rf = field_rsrc(P.in[s], bytes1);
 		float* tile = s_tile[s & 1];
@@ -775,6 +821,7 @@ int hns_dev_advect_scalars(hns_grid* g, const float* vel3, const float* const* i
 		ScalarPtrs P;
 		P.n = n - base < HNS_MAX_SCALARS ? n - base : HNS_MAX_SCALARS;
 		for (int s = 0; s < HNS_MAX_SCALARS; ++s) {
+			P.q4 = nullptr, P.q4_out[0] = P.q4_out[1] = P.q4_out[2] = P.q4_out[3] = nullptr;
 			P.in[s] = s < P.n ? in[base + s] : nullptr;
 			P.out[s] = s < P.n ? out[base + s] : nullptr;
 			if (s < P.n && (!P.in[s] || !P.out[s])) {
@@ -790,12 +837,41 @@ int hns_dev_advect_scalars(hns_grid* g, const float* vel3, const float* const* i
 			// backwards: the gradient kernel has just written the velocity front to back; starting on its cached tail also
 			// leaves the head cached for the next substep's advect_vector (256^3: -1 % here, -4 % there). Option "rev" = 0: forwards.
 			gd.rev = options().rev.load();
-			hipLaunchKernelGGL(k_advect_scalars_n, grid, block, 0, (hipStream_t)stream, gd, vel3, P, scaled_dt);
+			hipLaunchKernelGGL(k_advect_scalars_n<false>, grid, block, 0, (hipStream_t)stream, gd, vel3, P, scaled_dt);
 		}
 		else
 			hipLaunchKernelGGL(k_advect_scalars<false>, grid, block, 0, (hipStream_t)stream, g->dev(), vel3, P, sdf, scaled_dt);
 	}
 	return launch_status("hns_dev_advect_scalars");
 }
+
+// advect_scalars over the four fields of `q4` (one 16-byte element per voxel in, four float arrays out) and n more float fields, one launch (hns_sim_substep; no collision
+// field). Applies where hns_advect_q4_ok(g).
+int hns_advect_scalars_q4(hns_grid* g, const float* vel3, const float* q4, float* const* q4_out, const float* const* in, float* const* out, int n, float dt, float inv_dx,
+                          void* stream) {
+	if (int rc = check_grid(g, "hns_advect_scalars_q4")) return rc;
+	NULLCHK(!vel3 || !q4 || !q4_out || (n > 0 && (!in || !out)), "hns_advect_scalars_q4");
+	if (!hns_advect_q4_ok(g) || n > HNS_MAX_SCALARS) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_advect_scalars_q4: grid too large for 32-bit offsets, or too many fields");
+	if (g->n_active == 0) return HNS_OK;
+	ScalarPtrs P;
+	P.n = n;
+	P.q4 = q4;
+	for (int c = 0; c < 4; ++c) {
+		NULLCHK(!q4_out[c], "hns_advect_scalars_q4");
+		P.q4_out[c] = q4_out[c];
+	}
+	for (int s = 0; s < HNS_MAX_SCALARS; ++s) {
+		P.in[s] = s < n ? in[s] : nullptr;
+		P.out[s] = s < n ? out[s] : nullptr;
+		NULLCHK(s < n && (!P.in[s] || !P.out[s]), "hns_advect_scalars_q4");
+	}
+	GridDev gd = g->dev();
+	gd.rev = options().rev.load();  // (as hns_dev_advect_scalars)
+	hipLaunchKernelGGL(k_advect_scalars_n<true>, dim3((unsigned)g->n_active), dim3(512), 0, (hipStream_t)stream, gd, vel3, P, dt * inv_dx);
+	return launch_status("hns_advect_scalars_q4");
+}
+
+// can this grid's fields take the q4 path (32-bit byte offsets into a 16-byte-per-voxel array)?
+bool hns_advect_q4_ok(const hns_grid* g) { return narrow_fields(g) && (uint64_t)g->topo.n_leaves * 8192u <= hns::kNarrowBytes; }
 
 }  // extern "C"

@@ -69,7 +69,8 @@ struct hns_sim {
 	std::vector<float*> nxt;  // scratch / next value        (the reference's d_outputs)
 	float* vel = nullptr;  // d_velocity      (Vec3f AoS, 3n floats: the host/reference layout, so H2D/D2H are plain copies)
 	float* adv = nullptr;  // d_advectedVel
-	float* tmp = nullptr;  // out-of-place vorticity target
+	float* tmp = nullptr;  // out-of-place vorticity target; the buoyed u* of the fused divergence / combustion / buoyancy launch
+	float* q4 = nullptr;   // {fuel, waste, temperature, flame} as one 16-byte element per voxel between that launch and advect_scalars (sims that hold those four fields)
 	float* div = nullptr;
 	float* p_a = nullptr;
 	float* p_b = nullptr;
@@ -255,7 +256,8 @@ static hns_sim* sim_create(hns_grid* g, const char* const* float_names, int n_fl
 	}
 	if (rc == HNS_OK) {
 		const size_t unit = (sizeof(float) * (size_t)(s->n ? s->n : 1) + 255) & ~(size_t)255;  // one float field, 256-byte aligned
-		const size_t units = 3 * 3 + 3 + 2 * s->names.size();                                   // vel, adv, tmp | div, p_a, p_b | cur, nxt per field
+		const bool combust = s->find("fuel") >= 0 && s->find("waste") >= 0 && s->find("temperature") >= 0 && s->find("flame") >= 0;
+		const size_t units = 3 * 3 + 3 + 2 * s->names.size() + (combust ? 4 : 0);               // vel, adv, tmp | div, p_a, p_b | cur, nxt per field | q4
 		Arena a{nullptr, 0, -1};
 		rc = arena_get(unit * units, s->device, a);
 		if (rc == HNS_OK) {
@@ -272,6 +274,7 @@ static hns_sim* sim_create(hns_grid* g, const char* const* float_names, int n_fl
 				s->cur.push_back(take(1));
 				s->nxt.push_back(take(1));
 			}
+			if (combust) s->q4 = take(4);
 			s->p_result = s->p_a;
 			if (zero && hipMemsetAsync(a.p, 0, unit * units, (hipStream_t)stream) != hipSuccess) rc = fail(HNS_ERR_HIP, "hns_sim_create: clearing the field memory failed");
 		}
@@ -476,9 +479,13 @@ static int sim_advect_scalars(hns_sim* s, const float* sdf, bool coll, float dt,
 
 // One substep in the order of reference HNanoSolver.cu:150-356, cut at the two points where it starts to need more input
 // fields, so that the operator path can enqueue each part as soon as its inputs are on the device:
-//   part A  needs velocity (+ collision_sdf)      collision, advect_vector, vorticity, divergence
-//   part B  needs fuel/waste/temperature/flame     combustion, buoyancy, pressure solve, gradient subtraction, collision
+//   part A  needs velocity (+ collision_sdf)      collision, advect_vector, vorticity
+//   part B  needs fuel/waste/temperature/flame     divergence, combustion, buoyancy, pressure solve, gradient subtraction, collision
 //   part C  needs every advected float field       advect_scalars
+// Round 6: without a collision field (and while a 16-byte-per-voxel array stays 32-bit addressable) part B opens with ONE launch for divergence + combustion +
+// buoyancy (hns_divergence_combust_buoyancy: 60 B/voxel instead of 16 + 40 + 28) that leaves the four combustion fields as one 16-byte element per voxel in s->q4, and
+// part C gathers those four from there (hns_advect_scalars_q4: a corner tap of the four is one gather, not four). Same expressions in the same order per voxel:
+// bit-identical to the separate launches, which remain the path with a collision field and the hns_dev_* entry points.
 namespace {
 struct Substep {
 	hns_sim* s;
@@ -486,9 +493,14 @@ struct Substep {
 	float dt, voxel_size, inv_dx;
 	const hns_combustion_params* params;
 	int ci[4];
-	bool coll;
+	bool coll, fused;
 	const float* sdf;
 	void* stream;
+	hipEvent_t* stage_events = nullptr;  // six events of hns_sim_stage_timing, or null
+	int mark(int k) {
+		if (stage_events) HNS_HIP(hipEventRecord(stage_events[k], (hipStream_t)stream));
+		return HNS_OK;
+	}
 
 	int prepare(hns_sim* sim, int iters, float dt_, float vs, const hns_combustion_params* prm, int has_collision, void* st) {
 		s = sim;
@@ -510,10 +522,16 @@ struct Substep {
 		const int i_sdf = has_collision ? s->find("collision_sdf") : -1;  // :66-75
 		coll = i_sdf >= 0;
 		sdf = coll ? s->cur[i_sdf] : nullptr;
+		size_t advected = 0;
+		for (const std::string& n : s->names) advected += n != "collision_sdf";
+		// (every leaf active: the pointwise kernels of the separate path run over ALL voxels, read-only ghost leaves included, and advection taps read them there)
+		fused = !coll && s->q4 && s->grid->d_blk && s->grid->n_active == (uint64_t)s->grid->topo.n_leaves && !options().stencil_block.load() && hns_advect_q4_ok(s->grid) &&
+		        advected - 4 <= 8 && options().fuse_pointwise.load();
 		return HNS_OK;
 	}
 	int part_a() {
 		hns_grid* g = s->grid;
+		HNS_TRY(mark(0));
 		if (coll) HNS_TRY(hns_dev_enforce_collision_boundaries(g, s->vel, sdf, voxel_size, stream));  // :153-157
 		HNS_TRY(hns_dev_advect_vector(g, s->vel, s->adv, sdf, coll, dt, inv_dx, stream));  // :162-170
 		if ((int)params->factorScale != 0) {  // :172-176. With (int)factorScale == 0 every vorticity-magnitude tap collapses onto the centre, the
@@ -522,40 +540,48 @@ struct Substep {
 			                                      params->vorticityScale, params->factorScale, stream));
 			std::swap(s->adv, s->tmp);
 		}
-		return hns_dev_divergence(g, s->adv, s->div, inv_dx, stream);  // :181-188
+		return HNS_OK;
 	}
 	int part_b() {
 		hns_grid* g = s->grid;
-		HNS_TRY(hns_dev_combustion_oxygen(s->cur[ci[0]], s->cur[ci[1]], s->cur[ci[2]], s->div, s->cur[ci[3]], s->nxt[ci[0]], s->nxt[ci[1]],
-		                                  s->nxt[ci[2]], s->nxt[ci[3]], params->temperatureRelease, params->expansionRate, s->n, stream));  // :211-221
-		HNS_TRY(hns_dev_temperature_buoyancy(s->adv, s->nxt[ci[2]], s->adv, dt, params->ambientTemp, params->buoyancyStrength, s->n,
-		                                     stream));  // :226-234 (temperature AFTER combustion)
-		for (int c = 0; c < 4; ++c) std::swap(s->cur[ci[c]], s->nxt[ci[c]]);  // :239-246
+		HNS_TRY(mark(1));
+		if (fused) {  // :181-234 in one launch; the four fields' new values live in s->q4 until part C (cur[] / nxt[] of those four are not touched here)
+			HNS_TRY(hns_divergence_combust_buoyancy(g, s->adv, s->div, inv_dx, s->cur[ci[0]], s->cur[ci[1]], s->cur[ci[2]], s->cur[ci[3]], s->q4, s->tmp,
+			                                        params->temperatureRelease, params->expansionRate, dt, params->ambientTemp, params->buoyancyStrength, stream));
+			std::swap(s->adv, s->tmp);
+		} else {
+			HNS_TRY(hns_dev_divergence(g, s->adv, s->div, inv_dx, stream));  // :181-188
+			HNS_TRY(hns_dev_combustion_oxygen(s->cur[ci[0]], s->cur[ci[1]], s->cur[ci[2]], s->div, s->cur[ci[3]], s->nxt[ci[0]], s->nxt[ci[1]],
+			                                  s->nxt[ci[2]], s->nxt[ci[3]], params->temperatureRelease, params->expansionRate, s->n, stream));  // :211-221
+			HNS_TRY(hns_dev_temperature_buoyancy(s->adv, s->nxt[ci[2]], s->adv, dt, params->ambientTemp, params->buoyancyStrength, s->n,
+			                                     stream));  // :226-234 (temperature AFTER combustion)
+			for (int c = 0; c < 4; ++c) std::swap(s->cur[ci[c]], s->nxt[ci[c]]);  // :239-246
+		}
+		HNS_TRY(mark(2));
 		HNS_TRY(sim_pressure(s, iterations, voxel_size, omega_compute(voxel_size), stream));  // :256-272
+		HNS_TRY(mark(3));
 		HNS_TRY(hns_dev_subtract_pressure_gradient(g, s->adv, s->p_result, s->vel, sdf, coll,
 		                                           inv_dx, stream));  // :278-289
 		if (coll) HNS_TRY(hns_dev_enforce_collision_boundaries(g, s->vel, sdf, voxel_size, stream));  // :292-296
 		return HNS_OK;
 	}
-	// Part B in the order the cook pipeline wants it. The pressure solve reads nothing but the divergence, and combustion's
-	// contribution to it depends on fuel and waste only: B1 (those two fields on the device) finishes the divergence and
-	// solves; B2 (temperature and flame too) does what B1 skipped. Buoyancy moves from before the solve to after it, which
-	// changes nothing: the solve does not read the velocity and nothing in between reads what buoyancy writes.
-	int part_b1() {
-		HNS_TRY(hns_combustion_div(s->cur[ci[0]], s->cur[ci[1]], s->div, params->expansionRate, s->n, stream));
-		return sim_pressure(s, iterations, voxel_size, omega_compute(voxel_size), stream);
-	}
-	int part_b2() {
-		hns_grid* g = s->grid;
-		HNS_TRY(hns_combustion_fields(s->cur[ci[0]], s->cur[ci[1]], s->cur[ci[2]], s->cur[ci[3]], s->nxt[ci[0]], s->nxt[ci[1]], s->nxt[ci[2]], s->nxt[ci[3]],
-		                              params->temperatureRelease, s->n, stream));
-		HNS_TRY(hns_dev_temperature_buoyancy(s->adv, s->nxt[ci[2]], s->adv, dt, params->ambientTemp, params->buoyancyStrength, s->n, stream));
-		for (int c = 0; c < 4; ++c) std::swap(s->cur[ci[c]], s->nxt[ci[c]]);
-		HNS_TRY(hns_dev_subtract_pressure_gradient(g, s->adv, s->p_result, s->vel, sdf, coll, inv_dx, stream));
-		if (coll) HNS_TRY(hns_dev_enforce_collision_boundaries(g, s->vel, sdf, voxel_size, stream));
+	int part_c() {  // :321-356
+		HNS_TRY(mark(4));
+		if (!fused) return sim_advect_scalars(s, sdf, coll, dt, inv_dx, stream);
+		std::vector<const float*> ins;
+		std::vector<float*> outs;
+		float* q4_out[4];
+		for (int c = 0; c < 4; ++c) q4_out[c] = s->nxt[ci[c]];
+		for (size_t i = 0; i < s->names.size(); ++i) {
+			if (s->names[i] == "collision_sdf" || (int)i == ci[0] || (int)i == ci[1] || (int)i == ci[2] || (int)i == ci[3]) continue;  // :327
+			ins.push_back(s->cur[i]);
+			outs.push_back(s->nxt[i]);
+		}
+		HNS_TRY(hns_advect_scalars_q4(s->grid, s->vel, s->q4, q4_out, ins.data(), outs.data(), (int)ins.size(), dt, inv_dx, stream));
+		for (size_t i = 0; i < s->names.size(); ++i)
+			if (s->names[i] != "collision_sdf") std::swap(s->cur[i], s->nxt[i]);
 		return HNS_OK;
 	}
-	int part_c() { return sim_advect_scalars(s, sdf, coll, dt, inv_dx, stream); }  // :321-356
 };
 }  // namespace
 
@@ -566,9 +592,18 @@ extern "C" int hns_sim_substep(hns_sim* s, int iterations, float dt, float voxel
 	if (s->n == 0) return HNS_OK;  // HNanoSolver.cu:26-28
 	Substep step;
 	HNS_TRY(step.prepare(s, iterations, dt, voxel_size, params, has_collision, stream));
+	// hns_sim_stage_timing: the same five brackets as the core substep -- {collision + advect_vector + vorticity, divergence + combustion + buoyancy (one launch when
+	// fused), pressure loop, gradient subtraction + collision, advect_scalars}
+	const bool staged = s->stage_timing && s->sev_used + 6 <= s->sev.size();
+	step.stage_events = staged ? &s->sev[s->sev_used] : nullptr;
 	HNS_TRY(step.part_a());
 	HNS_TRY(step.part_b());
-	return step.part_c();
+	HNS_TRY(step.part_c());
+	if (staged) {
+		HNS_HIP(hipEventRecord(step.stage_events[5], (hipStream_t)stream));
+		s->sev_used += 6;
+	}
+	return HNS_OK;
 }
 
 extern "C" int hns_sim_core_substep(hns_sim* s, int iterations, float dt, float voxel_size, void* stream) {
@@ -706,8 +741,8 @@ int make_sim(hns_grid* g, const FieldSplit& fs, SimGuard& guard, void* stream) {
 
 // hns_compute_sim's data movement. The reference uploads everything, runs, downloads everything (HNanoSolver.cu:87-133,
 // 361-371). Here the fields go up in the order the substep consumes them, on a transfer stream of the sim's own, and each
-// part of the substep is enqueued on the caller's stream as soon as its inputs are queued: advect_vector + divergence
-// run under the upload of fuel and waste, the pressure solve under the upload of every other field (Substep::part_b1),
+// part of the substep is enqueued on the caller's stream as soon as its inputs are queued: advect_vector runs under the
+// upload of the four combustion fields, the pressure solve under the upload of every other field (Substep::part_b),
 // and advect_scalars under the download of the final velocity. Same kernels, same order per buffer; only the overlap
 // differs. Option "cook_pipeline" = 0 falls back to upload-all / run / download-all.
 // What a host array and the device buffer it was downloaded from have in common afterwards. Two strengths (hns_compute_sim_resident):
@@ -858,7 +893,7 @@ static int compute_sim_pipelined(hns_sim* s, FieldSplit& fs, int iterations, flo
 	}
 	hipStream_t st = (hipStream_t)stream, xf = s->xfer;
 	HNS_TRY(step.prepare(s, iterations, dt, voxel_size, params, has_collision, stream));
-	auto is_fuel_or_waste = [](const char* n) { return !strcmp(n, "fuel") || !strcmp(n, "waste"); };
+	auto is_combustion_field = [](const char* n) { return !strcmp(n, "fuel") || !strcmp(n, "waste") || !strcmp(n, "temperature") || !strcmp(n, "flame"); };
 	auto handoff = [&](hipEvent_t e, hipStream_t from, hipStream_t to) -> int {
 		HNS_HIP(hipEventRecord(e, from));
 		HNS_HIP(hipStreamWaitEvent(to, e, 0));
@@ -872,14 +907,13 @@ static int compute_sim_pipelined(hns_sim* s, FieldSplit& fs, int iterations, flo
 	HNS_TRY(handoff(s->xev[1], xf, st));
 	HNS_TRY(step.part_a());
 	for (hns_field* f : fs.floats)
-		if (is_fuel_or_waste(f->name)) HNS_TRY(upload(f, xf));
+		if (is_combustion_field(f->name)) HNS_TRY(upload(f, xf));
 	HNS_TRY(handoff(s->xev[2], xf, st));
-	HNS_TRY(step.part_b1());  // the solve runs while every remaining field is still on its way
-	for (hns_field* f : fs.floats)  // "collision_sdf" went up first if this call uses it; if not, nothing reads it and it returns zeroed
-		if (!is_fuel_or_waste(f->name) && strcmp(f->name, "collision_sdf") != 0) HNS_TRY(upload(f, xf));
-	HNS_TRY(handoff(s->xev[4], xf, st));
-	HNS_TRY(step.part_b2());
+	HNS_TRY(step.part_b());  // the solve runs while every remaining field is still on its way
 	HNS_HIP(hipEventRecord(s->xev[3], st));  // s->vel is final here
+	for (hns_field* f : fs.floats)  // "collision_sdf" went up first if this call uses it; if not, nothing reads it and it returns zeroed
+		if (!is_combustion_field(f->name) && strcmp(f->name, "collision_sdf") != 0) HNS_TRY(upload(f, xf));
+	HNS_TRY(handoff(s->xev[4], xf, st));
 	HNS_TRY(step.part_c());
 	HNS_TRY(digest_on_device(st));  // (every field is final on the device here; the kernels run beside the downloads)
 	HNS_HIP(hipStreamWaitEvent(xf, s->xev[3], 0));

@@ -48,6 +48,7 @@ struct Options {
 	std::atomic<int> sor_block_k{0};           // "sor_block_k": ... iterations per launch: 0 = by shape, 2, 4 (4: one-leaf blocks only)
 	std::atomic<int> sor_block_stagger{8};     // "sor_block_stagger": ... launch-start stagger of the two workgroups of a CU, x 1,024 cycles (0 = off; hns_sorblock.hip)
 	std::atomic<int> sor_block_lean{0};        // "sor_block_lean" = auto | 0 | 1 | dma | xy (stored 0 .. 4): ... its lean forms (row state in LDS, three workgroups per CU); xy = auto: the sweep threads fetch their own rows; 1: waves sorted by parity; dma: 1 with div through LDS-DMA
+	std::atomic<int> fuse_pointwise{1};        // "fuse": hns_sim_substep / hns_compute_sim without a collision field run divergence + combustion + buoyancy as one launch and advect the four combustion fields out of one 16-byte-per-voxel array
 	std::atomic<int> sor_block_seg{0};         // "sor_block_seg": ... blocks per XCD segment of its launch order (0: one chunk per XCD; read when the block table is built)
 };
 Options& options();
@@ -189,7 +190,16 @@ extern "C" __attribute__((visibility("hidden"))) int hns_chain_subtract_pressure
                                                                                           const hns::PhaseMirror* m, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_count_boundary_records(hns_grid* g, int n_boundary, unsigned* d_scratch, unsigned* out2, void* stream);
 
-// implemented in hns_pointwise.hip: combustion_oxygen split into its divergence update (needs fuel, waste) and the rest
+// the fused middle of hns_sim_substep (round 6): divergence + combustion_oxygen + temperature_buoyancy in one launch (hns_pressure.hip), leaving {fuel, waste, temperature,
+// flame} as one 16-byte element per voxel, and the advect_scalars launch that gathers its taps from that array (hns_advect.hip)
+extern "C" __attribute__((visibility("hidden"))) int hns_divergence_combust_buoyancy(hns_grid* g, const float* vel3, float* div, float inv_dx, const float* fuel, const float* waste,
+                                                                                      const float* temperature, const float* flame, float* q4, float* vel3_out, float temp_gain,
+                                                                                      float expansion, float dt, float ambient, float strength, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int hns_advect_scalars_q4(hns_grid* g, const float* vel3, const float* q4, float* const* q4_out, const float* const* in,
+                                                                            float* const* out, int n, float dt, float inv_dx, void* stream);
+extern "C" __attribute__((visibility("hidden"))) bool hns_advect_q4_ok(const hns_grid* g);
+
+// implemented in hns_pointwise.hip: combustion_oxygen split into its divergence update (needs fuel, waste) and the rest (hns_dist.hip: the boundary leaves' divergence first)
 extern "C" __attribute__((visibility("hidden"))) int hns_combustion_div(const float* fuel, const float* waste, float* divergence, float expansion, uint64_t n,
                                                                         void* stream);
 extern "C" __attribute__((visibility("hidden"))) int hns_combustion_fields(const float* fuel, const float* waste, const float* temperature, const float* flame,

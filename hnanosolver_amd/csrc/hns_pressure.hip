@@ -17,6 +17,7 @@
 //     traffic instead of the >=16 B of two in-place launches.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <utility>
 
 #include "hns_device.hpp"
@@ -862,22 +863,55 @@ __device__ __forceinline__ void face_duty(int l, int& slot, int& src, int& R) {
 	R = f == 0 ? RT_ROW(-1, i) : (f == 1 ? RT_ROW(8, i) : (f == 2 ? RT_ROW(i, -1) : RT_ROW(i, 8)));
 }
 
+// What hns_sim_substep fuses into the divergence launch (round 6; reference HNanoSolver.cu:181-234 runs three launches: divergence, combustion_oxygen, temperature_buoyancy).
+// The lane that owns a z-row of the leaf has its eight divergences and its eight velocities in registers: it also burns the row's eight voxels
+// (combustion_oxygen, Kernel.cu:923-966: div += burn * expansion), writes {fuel, waste, temperature, flame} as ONE 16-byte element per voxel (`q4`: what
+// k_advect_scalars_n<true> gathers its taps from, hns_advect.hip) and the velocity with the buoyancy of the NEW temperature (temperature_buoyancy, Kernel.cu:831-847)
+// into a second buffer -- the neighbours' divergences still read the un-buoyed u*. 60 B/voxel in one pass instead of 16 + 40 + 28 in three.
+struct NoFuse {};
+struct CombustFuse {
+	const float* fuel;
+	const float* waste;
+	const float* temp;
+	const float* flame;
+	float4* q4;    // out: {fuel, waste, temperature, flame} after combustion, one element per voxel
+	float* u_out;  // out: u* + buoyancy
+	float temp_gain, expansion, dt, ambient, strength;
+};
+__device__ __forceinline__ void ld_row8(const float* f, size_t at, float (&v)[8]) {
+	const float4* q = reinterpret_cast<const float4*>(f + at);
+	const float4 a = q[0], b = q[1];
+	v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+}
+
 // divergence (reference Kernel.cu:499-519): (xp - xm + yp - ym + zp - zm) * inv_dx with xp = (c.x + u(+x).x) * 0.5f, ...
 // COAL (round 4; grids of 16k leaves and more, hns_dev_divergence): the leaf's own 6 KB are fetched in memory order -- lane l takes the
 // 16-byte pieces l, 64 + l, ... so that an instruction touches 8 whole cache lines instead of a piece of each of the 48 -- and handed to
 // the row owners through LDS (the wave's own 6 KB; one wave per workgroup, so only the wave's LDS order matters). Round 3 measured it
 // (64.1 -> 62.9 us at 256^3, 133 -> 123 on the 66k-leaf plume, but 11.8 -> 13.4 at 128^3: 12.6 KB of LDS per wave halve the waves in
 // flight where the grid is small) and dropped it; it is now switched by size instead.
-template <class M, bool COAL = false>
-__global__ __launch_bounds__(64) void k_divergence_row(const GridDev g, const float* __restrict__ u, float* __restrict__ div, const float inv_dx, const M m) {
-	__shared__ __attribute__((aligned(16))) RowTile TX, TY;  // ux rows (x faces), uy rows (y faces)
-	__shared__ __attribute__((aligned(16))) float4 s_own[COAL ? 384 : 1];
+template <class M, bool COAL, class F>
+__device__ __forceinline__ void divergence_row_body(const GridDev& g, const float* __restrict__ u, float* __restrict__ div, const float inv_dx, const M& m, const F& fz) {
+	constexpr bool FUSE = !std::is_same<F, NoFuse>::value;
+	// ux rows (x faces), uy rows (y faces), and the hand-over buffer of the coalesced form. FUSE: all three carved out of one array, which the out-going q4 / velocity rows
+	// are then staged in once the divergence has been read out of the tiles (576 float4: 64 rows x (8 + 1 pad))
+	__shared__ __attribute__((aligned(16))) RowTile TXs, TYs;
+	__shared__ __attribute__((aligned(16))) float4 s_owns[COAL ? 384 : 1];
+	__shared__ __attribute__((aligned(16))) float4 s_mem[FUSE ? (COAL ? 784 : 576) : 1];
+	RowTile& TX = FUSE ? *reinterpret_cast<RowTile*>(s_mem) : TXs;
+	RowTile& TY = FUSE ? *reinterpret_cast<RowTile*>(s_mem + 200) : TYs;
+	float4* const s_own = FUSE ? s_mem + 400 : s_owns;
 	const int l = threadIdx.x, x = l >> 3, y = l & 7;
 	const int* __restrict__ rec = g.blk + (size_t)launch_pos(g, blockIdx.x) * 28;
 	const int leaf = __builtin_amdgcn_readfirstlane(rec[0]);
 	chain_begin(m, leaf);
 	const int n_zm = __builtin_amdgcn_readfirstlane(rec[1 + 12]), n_zp = __builtin_amdgcn_readfirstlane(rec[1 + 14]);
 	float r[24];
+	float c_fu[8], c_wa[8], c_te[8], c_fl[8];  // FUSE: the row's four combustion fields (32 contiguous bytes each)
+	if constexpr (FUSE) {
+		const size_t at = (size_t)leaf * 512 + l * 8;
+		ld_row8(fz.fuel, at, c_fu), ld_row8(fz.waste, at, c_wa), ld_row8(fz.temp, at, c_te), ld_row8(fz.flame, at, c_fl);
+	}
 	if constexpr (COAL) {
 		const float4* q = reinterpret_cast<const float4*>(u + (size_t)leaf * 1536);
 		float4 v[6];
@@ -966,11 +1000,69 @@ __global__ __launch_bounds__(64) void k_divergence_row(const GridDev g, const fl
 		const float f = (cz + zpv) * 0.5f, gg = (cz + zmv) * 0.5f;
 		d[z] = (a - b + c - e + f - gg) * inv_dx;
 	}
+	if constexpr (FUSE) {
+		// branch-free (selects between bit-exact alternatives): with branches the compiler carries r[] and d[] through them as whole vectors and spills.
+		// The lane's eight q4 elements (128 bytes) and its velocity row (96 bytes) leave through LDS in MEMORY order -- lane l stores the 16-byte pieces l, 64 + l, ... --
+		// instead of 16 bytes per lane at a 128 / 96-byte stride (measured at 256^3: 285 us for the launch, more than the three separate launches' 247).
+		auto wave_sync = [] {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		};
+		float ro[24];
+		wave_sync();  // (every lane has read its neighbours' rows out of the tiles)
+#pragma unroll
+		for (int z = 0; z < 8; ++z) {
+			// combustion_oxygen (Kernel.cu:923-966), the expressions of k_combustion_oxygen (hns_pointwise.hip)
+			const float f0 = c_fu[z], wa = c_wa[z], fl = c_fl[z], t0 = c_te[z];
+			const float fu = f0 < 0.001f ? 0.0f : f0;
+			const float oxy = 1.0f - fu - wa;
+			const bool burns = !(oxy < 0.0f);  // (no oxygen left: the voxel passes through)
+			const float burn = fminf(oxy, fu);
+			const float te = burns ? t0 + burn * fz.temp_gain : t0;
+			s_mem[l * 9 + z] = make_float4(burns ? fu - burn : fu, burns ? wa + burn * 2.0f : wa, te, burns ? fmaxf(fl, fminf(1.0f, burn * 10.0f)) : fl);
+			const float dd = d[z] + burn * fz.expansion;
+			d[z] = burns ? dd : d[z];
+			// temperature_buoyancy (Kernel.cu:831-847) with the temperature combustion has just written; x and z go through the same add as in
+			// k_temperature_buoyancy (-0 + 0 = +0)
+			const bool hot = !(te <= fz.ambient);
+			const float tempDiff = te - fz.ambient;
+			const float bx = r[3 * z] + fz.dt * 0.0f, by = r[3 * z + 1] + fz.dt * fmaxf(0.0f, tempDiff * fz.strength), bz = r[3 * z + 2] + fz.dt * 0.0f;
+			ro[3 * z] = hot ? bx : r[3 * z], ro[3 * z + 1] = hot ? by : r[3 * z + 1], ro[3 * z + 2] = hot ? bz : r[3 * z + 2];
+		}
+		wave_sync();
+		float4* q4 = fz.q4 + (size_t)leaf * 512;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const int i = k * 64 + l;
+			q4[i] = s_mem[(i >> 3) * 9 + (i & 7)];
+		}
+		wave_sync();
+#pragma unroll
+		for (int k = 0; k < 6; ++k) s_mem[l * 7 + k] = make_float4(ro[4 * k], ro[4 * k + 1], ro[4 * k + 2], ro[4 * k + 3]);
+		wave_sync();
+		float4* uo = reinterpret_cast<float4*>(fz.u_out + (size_t)leaf * 1536);
+#pragma unroll
+		for (int k = 0; k < 6; ++k) {
+			const int i = k * 64 + l, row = __mul24(i, 10923) >> 16;  // i / 6 for i < 384
+			uo[i] = s_mem[row * 7 + (i - row * 6)];
+		}
+	}
 	float4* q = reinterpret_cast<float4*>(div + (size_t)leaf * 512 + l * 8);
 	q[0] = make_float4(d[0], d[1], d[2], d[3]);
 	q[1] = make_float4(d[4], d[5], d[6], d[7]);
 	chain_store_row(m, 0, leaf, l, make_float4(d[0], d[1], d[2], d[3]), make_float4(d[4], d[5], d[6], d[7]));
 	chain_end(m, leaf);
+}
+template <class M, bool COAL = false>
+__global__ __launch_bounds__(64) void k_divergence_row(const GridDev g, const float* __restrict__ u, float* __restrict__ div, const float inv_dx, const M m) {
+	divergence_row_body<M, COAL, NoFuse>(g, u, div, inv_dx, m, NoFuse{});
+}
+// the fused launch of hns_sim_substep (CombustFuse above). Four waves per SIMD: left alone the scheduler hoists every load and takes 256 registers (one wave per SIMD)
+template <bool COAL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_divergence_combust_buoyancy(const GridDev g, const float* __restrict__ u, float* __restrict__ div, const float inv_dx,
+                                                                                                               const CombustFuse fz) {
+	divergence_row_body<NoMirror, COAL, CombustFuse>(g, u, div, inv_dx, NoMirror{}, fz);
 }
 
 }  // namespace hns
@@ -999,6 +1091,26 @@ int hns_dev_divergence(hns_grid* g, const float* vel3, float* div, float inv_dx,
 			hipLaunchKernelGGL((k_divergence_row<NoMirror, false>), dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, vel3, div, inv_dx, NoMirror{});
 	}
 	return launch_status("hns_dev_divergence");
+}
+
+// divergence + combustion_oxygen + temperature_buoyancy as one launch (hns_sim_substep; see CombustFuse). Same form choice and launch order as hns_dev_divergence.
+int hns_divergence_combust_buoyancy(hns_grid* g, const float* vel3, float* div, float inv_dx, const float* fuel, const float* waste, const float* temperature,
+                                    const float* flame, float* q4, float* vel3_out, float temp_gain, float expansion, float dt, float ambient, float strength,
+                                    void* stream) {
+	if (int rc = check_grid(g, "hns_divergence_combust_buoyancy")) return rc;
+	NULLCHK(!vel3 || !div || !fuel || !waste || !temperature || !flame || !q4 || !vel3_out, "hns_divergence_combust_buoyancy");
+	if (vel3 == vel3_out) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_divergence_combust_buoyancy: the buoyed velocity must not alias the velocity the divergence reads");
+	if (g->n_active == 0) return HNS_OK;
+	if (!g->d_blk) return fail(HNS_ERR_RUNTIME, "hns_divergence_combust_buoyancy: the grid has no launch tables");
+	GridDev gd = g->dev();
+	gd.rev = options().rev.load();
+	const CombustFuse fz{fuel, waste, temperature, flame, reinterpret_cast<float4*>(q4), vel3_out, temp_gain, expansion, dt, ambient, strength};
+	const int form = options().divergence_form.load();
+	if (form == 2 || (form == 0 && g->n_active >= 16384))
+		hipLaunchKernelGGL(k_divergence_combust_buoyancy<true>, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, vel3, div, inv_dx, fz);
+	else
+		hipLaunchKernelGGL(k_divergence_combust_buoyancy<false>, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, vel3, div, inv_dx, fz);
+	return launch_status("hns_divergence_combust_buoyancy");
 }
 
 // the same kernels as ONE launch of a chained multi-GPU rank (hns_flags.hpp: PhaseMirror): boundary leaves first, their

@@ -162,6 +162,7 @@ const OptionDesc kOptions[] = {
     {"dist_block", &Options::dist_block, kWordsBool},
     {"dist_pack", &Options::dist_pack, kWordsBool},
     {"dist_chain", &Options::dist_chain, kWordsBool},
+    {"fuse", &Options::fuse_pointwise, kWordsBool},
 };
 const Options kDefaults;
 }  // namespace

@@ -81,6 +81,9 @@ int hns_trim_memory(void);
  *   "rev"           1 | 0 (divergence and advect_scalars walk the leaves backwards)
  *   "cook_cache"    1 | 0 (operator calls keep their device buffers with the grid)
  *   "cook_pipeline" 1 | 0 (hns_compute_sim overlaps its transfers with the substep)
+ *   "fuse"          1 | 0 (hns_sim_substep / hns_compute_sim without a collision field: divergence + combustion_oxygen + temperature_buoyancy as ONE launch that leaves
+ *                   {fuel, waste, temperature, flame} as one 16-byte element per voxel, which advect_scalars then gathers its taps from; 0 = the reference's three
+ *                   launches over five float arrays. Same bits)
  *   "dist_wire_us"  N: the loopback transport of hns_dist holds every exchange N microseconds (emulated wire time)
  *   "dist_chain"    1 | 0: with dist_mirror, every kernel of the substep of such a rank delivers its own halo (no exchanges at all
  *                   after the first substep); 0 = only the SOR sweeps do (read when the ranks connect; all ranks must agree)
@@ -250,9 +253,10 @@ int hns_sim_pressure_solve(hns_sim*, int iterations, float voxel_size, void* str
  * number of fused-iteration launches they contained. hns_sim_timing(sim, 0) switches it off. */
 int hns_sim_timing(hns_sim*, int max_solves);
 int hns_sim_pressure_time(hns_sim*, float* total_ms, long long* launches);
-/* hns_sim_stage_timing(sim, n) brackets the five stages of the next n hns_sim_core_substep calls (six events per substep;
+/* hns_sim_stage_timing(sim, n) brackets the five stages of the next n hns_sim_core_substep / hns_sim_substep calls (six events per substep;
  * a switch of its own because the events cost microseconds each on the launch stream); hns_sim_stage_times: ms5 receives the
- * summed milliseconds of {advect_vector, divergence, pressure loop, gradient subtraction, advect_scalars} over *substeps. */
+ * summed milliseconds of {advect_vector, divergence, pressure loop, gradient subtraction, advect_scalars} over *substeps
+ * (hns_sim_substep: {collision + advect_vector + vorticity, divergence + combustion + buoyancy, pressure loop, gradient + collision, advect_scalars}). */
 int hns_sim_stage_timing(hns_sim*, int max_substeps);
 int hns_sim_stage_times(hns_sim*, float* ms5, long long* substeps);
 /* Raw device pointers of the sim's buffers (Vec3f AoS velocity, float fields, divergence, pressure). */

@@ -62,6 +62,9 @@ VARIANTS = {
     "divergence_block": {"stencil": "block"},
     "divergence_own_leaf_in_memory_order": {"divergence": "coalesced"},  # the default from 16,384 leaves (round 4)
     "cook_unpipelined_uncached": {"cook_pipeline": "0", "cook_cache": "0"},
+    # round 6: the default substep without a collision field runs divergence + combustion + buoyancy as ONE launch and advects {fuel, waste, temperature, flame} out of one
+    # 16-byte-per-voxel array; this is the reference's own decomposition (three launches, five float arrays)
+    "substep_unfused": {"fuse": "0"},
 }
 ALL_OPTIONS = sorted({k for v in VARIANTS.values() for k in v})
 
