@@ -81,7 +81,9 @@ def parse():
     ap.add_argument("--cook", action="store_true", help="time the cook-equivalent hns_compute_sim call (upload + grid build + substep + download) instead")
     ap.add_argument("--full", action="store_true", help="time the FULL Compute_Sim substep instead (HNanoSolver.cu:150-356 on device-resident fields: five advected scalars, "
                                                         "combustion, buoyancy; SURVEY 8d's 812 B/voxel row) and print its own JSON line; single GPU")
-    ap.add_argument("--strong-timeout", type=int, default=600, help="seconds the strong_scaling record may take before it is abandoned and the headline printed without it (0 = no limit)")
+    ap.add_argument("--strong-timeout", type=int, default=600, help="seconds EACH of the strong_scaling records may take before a watchdog thread abandons it and prints the line without it (0 = no limit)")
+    ap.add_argument("--no-one-sided", action="store_true", help="N > 1, default workload: skip the third record `strong_scaling_one_sided` (config 5 again over the one-sided transport "
+                                                                 "where it connects and reproduces RCCL bit for bit)")
     ap.add_argument("--no-strong", action="store_true", help="default workload only: skip the second record `strong_scaling` (BASELINE config 5, the 1024^3-extent plume "
                                                               "as ONE domain over the N ranks)")
     return ap.parse_args()
@@ -212,6 +214,35 @@ def cpu_baseline(origins, R, iterations, budget_s=25.0):
     }
 
 
+class Watchdog:
+    """Cuts a hang the main thread cannot see: a daemon timer THREAD that, after `seconds`, runs `last_words()` and leaves the process with os._exit(0). A Python signal
+    handler (signal.alarm) only runs when the main thread returns to the bytecode loop, which a collective that never returns does not do; a thread runs while the main
+    thread is blocked in C with the GIL released (dist.barrier, torch.cuda.synchronize, ctypes calls all release it). seconds <= 0: no watchdog."""
+
+    def __init__(self, seconds, last_words):
+        import threading
+
+        self._fired = threading.Event()
+        self._timer = None
+        if seconds and seconds > 0:
+            self._timer = threading.Timer(seconds, self._fire, args=(last_words,))
+            self._timer.daemon = True
+            self._timer.start()
+
+    def _fire(self, last_words):
+        self._fired.set()
+        try:
+            last_words()
+        finally:
+            os._exit(0)
+
+    def cancel(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            if self._fired.is_set():  # (fired a moment ago: it is printing the line and taking the process down -- do not print a second one)
+                time.sleep(3600)
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, as a CHILD process
     (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), let rank 0's JSON line
@@ -267,7 +298,7 @@ def ghost_note_of(runner):
         return f"ghost check did not complete: {type(e).__name__}: {e}"[:300]
 
 
-def strong_scaling_record(args, world, rank, dt):
+def strong_scaling_record(args, world, rank, dt, transport=None):
     """BASELINE.json configs[4] beside the weak-scaling headline, in the same JSON line: the 1024^3-extent plume (65,944 leaves) as ONE domain split over the N
     ranks (N = 1: the whole domain on the one GPU -- the curve's first point). Same step, same timing rule, same checks (against the single-GPU run of the
     whole domain before, ghost voxels against their owners after). `value` = substeps/s of the one domain."""
@@ -292,7 +323,7 @@ def strong_scaling_record(args, world, rank, dt):
     else:
         from hnanosolver_amd import dist as HD
 
-        runner = HD.SlabBench(origins, R, rank, world, args.iterations, dt, partition=True, sweeps_per_exchange=args.sweeps_per_exchange, transport=args.transport,
+        runner = HD.SlabBench(origins, R, rank, world, args.iterations, dt, partition=True, sweeps_per_exchange=args.sweeps_per_exchange, transport=transport or args.transport,
                               reference_transport="ipc" if args.share_one_gpu else "rccl")
         if not args.no_verify:
             try:
@@ -315,18 +346,22 @@ def strong_scaling_record(args, world, rank, dt):
 
 
 FULL_BYTES_PER_VOXEL = 812  # core 688 + vorticity 24 + combustion 40 + buoyancy 28 + four more advected scalars 4 x 8
-FULL_STAGE_BYTES = {"advect_vector": 24, "divergence": 16, "combustion_oxygen": 40, "temperature_buoyancy": 28, "pressure": BYTES_PER_VOXEL_ITER, "gradient": 28,
-                    "advect_scalars_S5": 12 + 8 * 5}
+# the five brackets of hns_sim_stage_timing over hns_sim_substep, with SURVEY 8d's algorithmic bytes per voxel (pressure: per iteration)
+FULL_STAGE_BYTES = {"advect_vector": 24, "divergence": 16 + 40 + 28, "pressure": BYTES_PER_VOXEL_ITER, "gradient": 28, "advect_scalars": 12 + 8 * 5}
+FULL_STAGE_NAME = {"advect_vector": "advect_vector", "divergence": "divergence_combustion_buoyancy", "pressure": "pressure", "gradient": "gradient", "advect_scalars": "advect_scalars_S5"}
+FUSED_MIDDLE_BYTES = 60  # what the fused launch must move: u* in 12, div out 4, four scalars in 16 and out 16, buoyed u* out 12
 
 
 def full_substep(args):
     """The whole Compute_Sim substep a SOP cook runs (reference HNanoSolver.cu:150-356; SURVEY 8d's last row): advect_vector, [vorticity confinement:
     an exact copy at the default factor_scale 0.5, skipped], divergence, combustion, buoyancy, 50 RB-SOR iterations, gradient subtraction, advect_scalars
-    over the five float fields -- on device-resident fields, K timed substeps between synchronisations. `kernels`: each stage's kernel launched on its own
-    after the timed region on the same arrays, bracketed by events on the launch stream (a stage alone finds its inputs warmer or colder in the Infinity
-    Cache than inside the substep; the rocprofv3 kernel statistics of this command, profiles/r05_final_full256_kernel_stats.csv, are the in-substep figures)."""
+    over the five float fields -- on device-resident fields, K timed substeps between synchronisations. Round 6: divergence + combustion + buoyancy are ONE
+    launch and the four combustion fields are advected out of one 16-byte-per-voxel array (option "fuse"; bit-identical to the separate launches).
+    `kernels`: the five stages bracketed by hipEvents on the launch stream INSIDE substeps of a short pass of its own after the timed region
+    (hns_sim_stage_timing; the rocprofv3 kernel statistics of this command, profiles/r06_full256_kernel_stats.csv, must agree)."""
     import torch
 
+    import hnanosolver_amd as H
     from hnanosolver_amd import api, device as D, fields
 
     origins, R = fields.config_leaves(args.config)
@@ -348,43 +383,28 @@ def full_substep(args):
     p_ms, p_iters = sim.pressure_time()
     ms = 1e3 * elapsed / args.steps
     sor_form, sor_launches, _ = D.rbgs_plan(grid, args.iterations)
-
-    # every stage's kernel alone, on arrays of the same size
-    dev = "cuda"
-    u = torch.from_numpy(f["vel"]).to(dev)
-    u2, u3 = torch.empty_like(u), torch.empty_like(u)
-    sc = [torch.from_numpy(f[n]).to(dev) for n in names]
-    sc2 = [torch.empty_like(t) for t in sc]
-    div = torch.zeros(n_vox, device=dev)
-    p_a, p_b = torch.zeros(n_vox, device=dev), torch.zeros(n_vox, device=dev)
-    inv_dx = 1.0 / vs
-
-    def alone(fn, reps=5):
-        fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
-
-    stage_ms = {
-        "advect_vector": alone(lambda: D.advect_vector(grid, u, u2, dt, inv_dx)),
-        "divergence": alone(lambda: D.divergence(grid, u2, div, inv_dx)),
-        "combustion_oxygen": alone(lambda: D.combustion_oxygen(sc[2], sc[3], sc[1], div, sc[4], sc2[2], sc2[3], sc2[1], sc2[4], prm.temperatureRelease, prm.expansionRate)),
-        "temperature_buoyancy": alone(lambda: D.temperature_buoyancy(u2, sc2[1], u2, dt, prm.ambientTemp, prm.buoyancyStrength)),
-        "pressure": p_ms / max(1, args.steps),  # (inside the timed substeps: events around the pressure loops)
-        "gradient": alone(lambda: D.subtract_pressure_gradient(grid, u2, p_a, u3, inv_dx)),
-        "advect_scalars_S5": alone(lambda: D.advect_scalars(grid, u3, sc, sc2, dt, inv_dx)),
-    }
+    n_st = min(args.steps, 10)
+    sim.timing(0)
+    sim.stage_timing(n_st)
+    for _ in range(n_st):
+        step()
+    torch.cuda.synchronize()
+    stage_ms, n_sub = sim.stage_times()
+    fused = H.get_option("fuse") == "1"
     kernels = {}
-    for st, t_ms in stage_ms.items():
+    for st, tot in stage_ms.items():
+        t_ms = tot / max(1, n_sub)
         alg = FULL_STAGE_BYTES[st] * n_vox * (args.iterations if st == "pressure" else 1)
         gbs = alg / (t_ms * 1e-3) / 1e9 if t_ms > 0 else None
-        kernels[st] = {"ms_per_substep": t_ms, "algorithmic_bytes": alg, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS if gbs else None,
-                       "share_of_substep": t_ms / ms, "timed": "inside the substeps" if st == "pressure" else "alone, after the timed region"}
+        ent = {"ms_per_substep": t_ms, "algorithmic_bytes": alg, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS if gbs else None, "share_of_substep": t_ms / ms,
+               "timed": "hipEvents on the launch stream inside the substeps of a pass after the timed region"}
+        if st == "divergence":
+            ent["launches"] = 1 if fused else 3
+            if fused:
+                ent["frac_compulsory"] = FUSED_MIDDLE_BYTES * n_vox / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if t_ms > 0 else None
+                ent["note"] = ("one launch (k_divergence_combust_buoyancy): `frac` prices SURVEY 8d's 16 + 40 + 28 B/voxel of the three reference launches, "
+                               f"`frac_compulsory` the {FUSED_MIDDLE_BYTES} B/voxel the fused launch must move")
+        kernels[FULL_STAGE_NAME[st]] = ent
     sub_bytes = (FULL_BYTES_PER_VOXEL - 600 + 12 * args.iterations - 24) * n_vox  # (the vorticity pass, 24 B/voxel, is an exact copy at factor_scale < 1 and skipped)
     gbs = sub_bytes / (ms * 1e-3) / 1e9
     print(json.dumps({
@@ -392,7 +412,9 @@ def full_substep(args):
         "value": args.steps / elapsed, "unit": "substeps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}^3 dense-active grid" if args.config.isdigit() else args.config, "active_voxels_per_gpu": n_vox, "pressure_iterations": args.iterations,
-                   "substep": "Compute_Sim order (HNanoSolver.cu:150-356), S = 5 advected scalars, combustion, buoyancy; vorticity confinement at factor_scale 0.5 is an exact copy and skipped",
+                   "substep": "Compute_Sim order (HNanoSolver.cu:150-356), S = 5 advected scalars, combustion, buoyancy; vorticity confinement at factor_scale 0.5 is an exact copy and skipped; "
+                              + ("divergence + combustion + buoyancy fused into one launch, {fuel, waste, temperature, flame} advected out of one 16-byte-per-voxel array" if fused
+                                 else "option fuse = 0: the reference's three launches over five float arrays"),
                    "algorithmic_bytes_per_voxel_substep": FULL_BYTES_PER_VOXEL - 600 + 12 * args.iterations - 24, "sor_form": sor_form},
         "roofline": {"kernel": "whole substep", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_substep": sub_bytes, "pressure_ms_per_iteration": p_ms / max(1, p_iters), "kernel_launches_per_solve": sor_launches, "kernels": kernels},
@@ -600,35 +622,37 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(origins, R, args.iterations)
-    # one driver command, both curves: the default workload also runs BASELINE config 5 as one domain over the same ranks (collective: every rank takes part)
-    strong = None
+    # One driver command, all curves: the default workload also runs BASELINE config 5 as one domain over the same ranks (collective: every rank takes part) -- `strong_scaling`
+    # over the transport of the headline (RCCL by default) and, for N > 1, `strong_scaling_one_sided`: --transport auto semantics, i.e. the one-sided transport (every kernel
+    # stores its halo into the peers' hipIpc-mapped ghost voxels, no exchanges) if it connects on this machine and reproduces three RCCL substeps bit for bit, else RCCL again.
+    # The headline line must come out whatever happens to these records. An exception is reported in the record's place. A HANG (a collective that never returns on a
+    # machine this path has not seen yet) blocks the main thread inside C (dist.barrier, torch.cuda.synchronize, a ctypes hns_dist_* call), where no Python signal handler
+    # runs: a WATCHDOG THREAD cuts it -- those calls release the GIL. When it fires, rank 0 prints the line with everything measured so far and a note in place of
+    # the record that hung, and every rank leaves the process at once without touching the GPU again (a hung collective cannot be unwound; nothing re-execs). All ranks exit 0:
+    # the headline in the line is complete and valid, the abandoned record says so itself, and a non-zero exit would make the launcher discard the line.
+    records = []
     if args.config == "256" and not args.partition and not args.no_strong:
-        if world > 1:
-            runner.rank_obj.close()
-        # The headline line must come out whatever happens to the second record. An exception is reported in its place; a HANG (a collective that never
-        # returns on a machine this path has not seen yet) is cut by an alarm on every rank: rank 0 prints the line with the headline and a note, and every
-        # rank leaves the process without touching the GPU again (a hung collective cannot be unwound; the children exit 0 so the launcher reports the line).
-        import signal
-
-        def strong_timed_out(signum, frame):
+        records.append(("strong_scaling", None))
+        if world > 1 and not args.no_one_sided:
+            records.append(("strong_scaling_one_sided", "auto"))
+    if records and world > 1:
+        runner.rank_obj.close()
+    for key, transport in records:
+        def last_words(key=key):
             if rank == 0:
-                out["strong_scaling"] = {"error": f"the strong-scaling record did not complete within {args.strong_timeout} s and was abandoned; the headline above is complete"}
+                out[key] = {"error": f"the {key} record did not complete within {args.strong_timeout} s and was abandoned (watchdog thread); everything else in this line is complete"}
                 sys.stdout.write(json.dumps(out) + "\n")
                 sys.stdout.flush()
-            os._exit(0)
 
-        if args.strong_timeout > 0:
-            signal.signal(signal.SIGALRM, strong_timed_out)
-            signal.alarm(args.strong_timeout)
+        dog = Watchdog(args.strong_timeout, last_words)
         try:
-            strong = strong_scaling_record(args, world, rank, dt)
+            rec = strong_scaling_record(args, world, rank, dt, transport)
         except Exception as e:  # noqa: BLE001
-            strong = {"error": f"{type(e).__name__}: {e}"[:300]}
-        if args.strong_timeout > 0:
-            signal.alarm(0)
+            rec = {"error": f"{type(e).__name__}: {e}"[:300]}
+        dog.cancel()
+        if rank == 0:
+            out[key] = rec
     if rank == 0:
-        if strong is not None:
-            out["strong_scaling"] = strong
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -212,6 +212,7 @@ struct IpcSegs {
 };
 
 // Copies the segments into the peers' memory, 4,096 floats per workgroup (the receivers are ready: k_ipc_ready ran).
+template <bool FENCE>  // (FENCE: the destination is another process's / device's memory; false: the loopback stand-in, this rank's own buffers)
 __global__ __launch_bounds__(256) void k_ipc_put(const IpcSegs segs) {
 	int s = 0;
 	while (s + 1 < segs.n && blockIdx.x >= segs.wg0[s + 1]) ++s;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void k_ipc_put(const IpcSegs segs) {
 			if (i < n) dst[i] = src[i];
 		}
 	}
-	__threadfence_system();
+	if (FENCE) __threadfence_system();
 }
 
 // after the puts (kernel boundary + fence): tell every peer its message has landed, then wait for theirs
@@ -393,7 +394,7 @@ struct hns_dist {
 	// streams and events
 	hipStream_t cs = nullptr;
 	std::shared_ptr<void> cs_owner;  // keeps `cs` alive: locally connected ranks all use ONE communication stream (see connect_local)
-	hipEvent_t ev_post[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_ready = nullptr;
+	hipEvent_t ev_post[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_bdone[2] = {nullptr, nullptr}, ev_ready = nullptr;  // (ev_bdone: the boundary kernel of an exchange has run)
 	int parity = 0;
 	Pending pending;
 	bool phi_in_flight = false;  // the exchange of phi (and u) that opens the next substep has already been posted
@@ -812,6 +813,7 @@ void hns_dist_destroy(hns_dist* d) {
 	for (int i = 0; i < 2; ++i) {
 		if (d->ev_post[i]) (void)hipEventDestroy(d->ev_post[i]);
 		if (d->ev_done[i]) (void)hipEventDestroy(d->ev_done[i]);
+		if (d->ev_bdone[i]) (void)hipEventDestroy(d->ev_bdone[i]);
 	}
 	d->cs_owner.reset();  // destroys the stream with its last user
 	for (hns_grid* g : {d->gB, d->gI, d->gO, d->gA})
@@ -1049,7 +1051,8 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 	}
 	if ((rc = build_pack_tables(d)) != HNS_OK) return bail(rc);
 	for (int i = 0; i < 2; ++i)
-		if (hipEventCreateWithFlags(&d->ev_post[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ev_done[i], hipEventDisableTiming) != hipSuccess)
+		if (hipEventCreateWithFlags(&d->ev_post[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ev_done[i], hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&d->ev_bdone[i], hipEventDisableTiming) != hipSuccess)
 			return bail(fail(HNS_ERR_HIP, "hns_dist_create: event creation failed"));
 	if (hipEventCreateWithFlags(&d->ev_ready, hipEventDisableTiming) != hipSuccess) return bail(fail(HNS_ERR_HIP, "hns_dist_create: event creation failed"));
 	if (err) *err = HNS_OK;
@@ -1486,23 +1489,34 @@ int unpack(hns_dist* d, Pending& x) {
 // caller then launches the interior kernel on `st`, which runs concurrently with all of that (an interior leaf touches no
 // ghost and no ghost-facing leaf writes what it reads). complete(): `st` waits for the end of that chain.
 // RCCL: sends and receives are one group on the communication stream. Local: the peers pull at complete().
-template <class BoundaryFn>
-int post(hns_dist* d, int type, std::vector<std::pair<float*, int>> fields, hipStream_t st, BoundaryFn boundary) {
+// Round 6: `interior(st)` -- the same kernel over the interior leaves -- is handed in and enqueued HERE, right behind the boundary kernel and in front of the pack / transfer /
+// unpack calls. Enqueued after them (rounds 2-5) it reached the device only once the host had issued the whole boundary chain, and by then that chain had run: the two
+// streams never overlapped (profiles/r06_dist_exchanged_timeline_before.txt; the loop is bound by the HOST's ~10 runtime calls per exchange).
+// in_line: the whole exchange -- `boundary(st)`, pack, transfer, unpack -- on the compute stream itself, in order, no events, complete on return (round 6: the pressure loop
+// whose one launch over all owned leaves packs its own messages; also what locally connected ranks do).
+template <class BoundaryFn, class InteriorFn>
+int post(hns_dist* d, int type, std::vector<std::pair<float*, int>> fields, hipStream_t st, BoundaryFn boundary, InteriorFn interior, bool in_line = false) {
 	if (d->pending.active) return fail(HNS_ERR_RUNTIME, "hns_dist: an exchange is already in flight");
-	if (d->world == 1) return boundary(st);  // nobody to talk to: the boundary range is empty, keep everything on one stream
+	if (d->world == 1) {  // nobody to talk to: the boundary range is empty, keep everything on one stream
+		HNS_TRY(boundary(st));
+		return interior(st);
+	}
 	if (!d->comm && !d->loopback && !d->ipc && d->local_ranks.empty())
 		return fail(HNS_ERR_RUNTIME, "hns_dist: not connected (call hns_dist_connect_rccl, hns_dist_connect_ipc or hns_dist_connect_local first)");
 	Pending& x = d->pending;
 	x.active = true, x.type = type, x.parity = d->parity, x.fields = std::move(fields);
 	d->parity ^= 1;
-	const hipStream_t cs = d->single_stream ? st : d->cs;
+	const bool one_stream = d->single_stream || in_line;
+	const hipStream_t cs = one_stream ? st : d->cs;
 	x.stream = cs;
-	if (!d->single_stream) {
+	if (!one_stream) {
 		HNS_HIP(hipEventRecord(d->ev_ready, st));
 		HNS_HIP(hipStreamWaitEvent(cs, d->ev_ready, 0));
 	}
 	x.prepacked = false;
 	HNS_TRY(boundary(cs));
+	if (!one_stream) HNS_HIP(hipEventRecord(d->ev_bdone[x.parity], cs));
+	HNS_TRY(interior(st));
 	if (!x.prepacked) HNS_TRY(halo_copy_exchange(d, true, x, cs));
 	else ++d->packed_exchanges;
 	for (Peer& p : d->peers) {
@@ -1523,7 +1537,7 @@ int post(hns_dist* d, int type, std::vector<std::pair<float*, int>> fields, hipS
 		IpcSegs sg;
 		sg.n = 0, sg.wg0[0] = 0;
 		auto flush = [&]() {
-			if (sg.n) hipLaunchKernelGGL(k_ipc_put, dim3(sg.wg0[sg.n]), dim3(256), 0, cs, sg);
+			if (sg.n) hipLaunchKernelGGL(k_ipc_put<true>, dim3(sg.wg0[sg.n]), dim3(256), 0, cs, sg);
 			sg.n = 0;
 		};
 		for (size_t i = 0; i < d->peers.size(); ++i) {
@@ -1566,22 +1580,45 @@ int post(hns_dist* d, int type, std::vector<std::pair<float*, int>> fields, hipS
 		HNS_NCCL(rccl().GroupEnd());
 	} else if (d->loopback) {  // same streams, events and copy sizes as a real exchange, but the payload is this rank's own
 		if (const int us = options().dist_wire_us.load()) hipLaunchKernelGGL(k_wire_delay, dim3(1), dim3(1), 0, cs, (long long)us * 100);
+		// all messages of the exchange as ONE copy launch (round 6; a hipMemcpyAsync per peer and field cost the host 5-8 us each, two to fourteen of them per exchange):
+		// what stands in for the one send / receive group of the RCCL path
+		IpcSegs sg;
+		sg.n = 0, sg.wg0[0] = 0;
+		auto flush = [&]() {
+			if (sg.n) hipLaunchKernelGGL(k_ipc_put<false>, dim3(sg.wg0[sg.n]), dim3(256), 0, cs, sg);
+			sg.n = 0;
+		};
 		for (Peer& p : d->peers) {
 			const Region &rs = p.send[type], &rr = p.recv[type];
 			int before = 0;
 			for (auto& f : x.fields) {
 				const size_t nr = (size_t)std::min(rs.voxels, rr.voxels) * (size_t)f.second;
-				if (nr)
-					HNS_HIP(hipMemcpyAsync(segment(rr, f.first, f.second, p.rbuf[x.parity], before), segment(rs, f.first, f.second, p.sbuf[x.parity], before), sizeof(float) * nr,
-					                       hipMemcpyDeviceToDevice, cs));
+				if (nr) {
+					if (sg.n == kIpcMaxSegs) flush();
+					sg.dst[sg.n] = segment(rr, f.first, f.second, p.rbuf[x.parity], before), sg.src[sg.n] = segment(rs, f.first, f.second, p.sbuf[x.parity], before), sg.floats[sg.n] = (unsigned)nr;
+					sg.wg0[sg.n + 1] = sg.wg0[sg.n] + (unsigned)((nr + 4095) / 4096);
+					++sg.n;
+				}
 				before += f.second;
 			}
 		}
+		flush();
+		HNS_TRY(launch_status("hns_dist: loopback exchange"));
 	} else {
 		if (!d->single_stream) HNS_HIP(hipEventRecord(d->ev_post[x.parity], cs));  // packed: the peers may pull
 		return HNS_OK;
 	}
+	if (in_line && !d->single_stream) {  // received regions -> ghost voxels behind the transfer on the same stream: nothing left to wait for
+		HNS_TRY(halo_copy_exchange(d, false, x, cs));
+		x.active = false;
+		return HNS_OK;
+	}
 	return unpack(d, x);
+}
+
+template <class BoundaryFn>
+int post(hns_dist* d, int type, std::vector<std::pair<float*, int>> fields, hipStream_t st, BoundaryFn boundary) {
+	return post(d, type, std::move(fields), st, boundary, [](hipStream_t) { return (int)HNS_OK; });
 }
 
 // Make the posted exchange's data visible in the ghost voxels before anything else runs on the compute stream.
@@ -1618,6 +1655,19 @@ int complete(hns_dist* d, hipStream_t st) {
 	return HNS_OK;
 }
 
+// Between two blocks of the exchanged pressure loop that sweep owned leaves only: the compute stream needs the boundary KERNEL of the posted exchange (interior tiles read the
+// boundary leaves' new p), not its messages -- the ghost voxels are read by the next boundary kernel alone, which follows the unpack in stream order on the communication
+// stream. So the compute stream waits for ev_bdone, the exchange is forgotten, and no cross-stream edge is left on the chain boundary sweep -> transfer -> unpack -> next
+// boundary sweep. (The last exchange of a solve is completed in full by the phase behind it.) Two-stream transports only; false = the caller must complete() in full.
+bool complete_boundary_only(hns_dist* d, hipStream_t st) {
+	Pending& x = d->pending;
+	if (!x.active) return true;
+	if (d->single_stream || !(d->comm || d->loopback || d->ipc) || options().dist_pipeline.load() == 0) return false;
+	if (hipStreamWaitEvent(st, d->ev_bdone[x.parity], 0) != hipSuccess) return false;
+	x.active = false;
+	return true;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // the core substep as a sequence of phases; a phase ends where an exchange has been posted
 // ---------------------------------------------------------------------------------------------------------------
@@ -1648,6 +1698,14 @@ struct Step {
 
 	// Do both launch ranges of the split sweep take two iterations in ONE launch each (result in dst for both)? Asked of the library's own
 	// plan, so that whatever hns_rbgs_iterate does with `2` is what this loop assumes.
+	// Round 6: a SMALL rank (up to 16,384 owned leaves: BASELINE config 5 in 8 ranks has 8,243 each) runs its short phases -- the sweeps of the pressure loop, the divergence,
+	// the gradient subtraction -- as ONE launch over all owned leaves with the exchange behind it on the compute stream (post(..., in_line)): at that size the boundary chain
+	// (boundary kernel -> pack -> transfer -> unpack, each a latency-bound launch, plus two cross-stream event edges) is longer than the interior kernel it was meant to hide
+	// under. Large ranks (a 256^3 slab: 32,768 leaves) keep the boundary / interior split on two streams. A rank decides for itself: the messages are the same either way.
+	bool in_line_rank() const {
+		return !d->single_stream && (d->comm || d->loopback || d->ipc) && options().dist_unsplit.load() != 0 && d->nB + d->nI <= 16384;
+	}
+
 	bool split_blocked() const {
 		if (d->k < 2 || options().dist_block.load() == 0) return false;
 		for (hns_grid* g : {d->gB, d->gI}) {
@@ -1695,16 +1753,23 @@ struct Step {
 	int sor_block_exchanged(int b) {
 		hns_dist* D = d;
 		typedef std::vector<std::pair<float*, int>> Fields;
-		if (b == 0) {
-			it = 0, src = d->p_a, dst = d->p_b;  // never warm-started (reference HNanoSolver.cu:113): the first sweep reads no p
-			if (d->timing && d->tev_used + 2 <= d->tev.size()) HNS_HIP(hipEventRecord(d->tev[d->tev_used], st));
-		}
+		if (b == 0) it = 0, src = d->p_a, dst = d->p_b;  // never warm-started (reference HNanoSolver.cu:113): the first sweep reads no p
 		const int n = std::min(d->k, iterations - it);
+		// what the previous phase posted: in full in front of the first block (the divergence's ghosts) and wherever this block starts with sweeps over the ghost leaves;
+		// between blocks that sweep owned leaves only, the boundary kernel alone (complete_boundary_only)
+		// the one launch over all owned leaves that packs its own messages (below) where the owned range is swept in 16^3 blocks and the plan has pack tables for both region types
+		const bool unsplit = n >= 2 && in_line_rank() && d->pack_ok[X_P] && d->pack_ok[X_D1] && options().dist_pack.load() != 0 && options().dist_block.load() != 0 &&
+		                     hns_rbgs_block_packable(d->gO);
+		{
+			const int tail_ = (unsplit || (n >= 2 && split_blocked())) ? 2 : 1;
+			if (b == 0 || n > tail_ || !complete_boundary_only(d, st)) HNS_TRY(complete(d, st));
+		}
+		if (b == 0 && d->timing && d->tev_used + 2 <= d->tev.size()) HNS_HIP(hipEventRecord(d->tev[d->tev_used], st));
 		// Round 4: the sweeps of the block that the exchange follows are TWO iterations in one temporally blocked launch per range
 		// (hns_sorblock.hip over a launch range: the ghost leaves are tile sources, 2K = 4 voxels deep, and are not swept; the X_P region
 		// of a plan with k >= 2 reaches 2k >= 4 voxels, its div region 2k - 1 >= 3), where the library's plan for the ranges says so.
 		// With k = 2 that is the whole pressure loop: no sweep ever touches a ghost leaf.
-		const int tail = (n >= 2 && split_blocked()) ? 2 : 1;
+		const int tail = (unsplit || (n >= 2 && split_blocked())) ? 2 : 1;
 		if (n > tail) {  // the sweeps over owned + ghost leaves as ONE solve of n - tail iterations: the library picks the form (two iterations per launch where that pays)
 			int in_b = 0;
 			HNS_TRY(hns_rbgs_iterate(d->gA, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), n - tail, &in_b, st, it == 0));
@@ -1718,6 +1783,25 @@ struct Step {
 			return g->n_active ? hns_rbgs_iterate(g, D->div, s0, d0, vs, omega_compute(vs), tail, nullptr, s, zero) : (int)HNS_OK;
 		};
 		const int xt = last ? X_D1 : X_P;
+		// Round 6: ONE launch over all owned leaves that packs the peers' messages as it stores (PackMirror), then the transfer and the unpack behind it on the compute stream.
+		// The boundary / interior split (below) buys overlap of the transfer with the interior sweep, and pays for it: a 16^3 block that straddles the boundary layer is swept by
+		// both launches (config 5, rank 4 of 8: 14 + 14 us against 19 for the one launch), two cross-stream event edges per exchange, and twice the runtime calls -- traced, the
+		// split loop's chain boundary sweep -> transfer -> unpack -> next boundary sweep alone took longer than this whole sequence (profiles/r06_dist_exchanged_notes.txt).
+		if (unsplit) {
+			HNS_TRY(post(d, xt, Fields{{dst, 1}}, st, [=](hipStream_t s) -> int {
+				PackMirror m = D->pack_type[xt];
+				for (size_t pi = 0; pi < D->peers.size(); ++pi) m.msg[pi] = D->peers[pi].sbuf[D->pending.parity];
+				bool done = false;
+				HNS_TRY(hns_rbgs_block_pack_launch(D->gO, D->div, s0, d0, vs, omega_compute(vs), zero, &m, s, &done));
+				if (!done) return fail(HNS_ERR_RUNTIME, "hns_dist: the owned range is not swept in 16^3 blocks after all");
+				D->pending.prepacked = true;
+				return HNS_OK;
+			}, [](hipStream_t) { return (int)HNS_OK; }, true));
+			std::swap(src, dst);
+			it += tail;
+			if (last) d->p_result = src;
+			return HNS_OK;
+		}
 		HNS_TRY(post(d, xt, Fields{{dst, 1}}, st, [=](hipStream_t s) -> int {
 			// two iterations in one blocked launch: the boundary sweep writes the peers' messages as it stores (PackMirror; option "dist_pack")
 			if (tail == 2 && D->pack_ok[xt] && options().dist_pack.load() != 0) {
@@ -1731,8 +1815,7 @@ struct Step {
 				}
 			}
 			return part(D->gB, s);
-		}));
-		HNS_TRY(part(d->gI, st));
+		}, [=](hipStream_t s) { return part(D->gI, s); }));
 		std::swap(src, dst);
 		it += tail;
 		if (last) d->p_result = src;
@@ -1763,20 +1846,23 @@ struct Step {
 			if (f.empty()) return HNS_OK;
 			return post(d, X_ADV, f, st, nothing);
 		}
-		HNS_TRY(complete(d, st));
+		{  // (the blocks of the exchanged pressure loop complete what is in flight themselves: sor_block_exchanged)
+			const int qb = ph - 1 - (coll ? 1 : 0) - (vort ? 2 : 1) - 2;
+			if (!(qb >= 0 && qb < blocks)) HNS_TRY(complete(d, st));
+		}
 		if (coll && ph == 1) {  // enforceCollisionBoundaries (HNanoSolver.cu:153-157) reads the ghost voxels of the SDF (its normal): they have arrived now
 			HNS_TRY(hns_dev_enforce_collision_boundaries(d->gO, d->u, sd, d->voxel_size, st));
 			return post(d, X_ADV, Fields{{d->u, 3}}, st, nothing);
 		}
 		int q = ph - 1 - (coll ? 1 : 0);
 		if (q == 0) {  // advect_vector (:162-170); vorticity confinement reads it up to factor_scale + 1 voxels away: whole leaves travel then
-			HNS_TRY(post(d, vort ? X_ADV : X_D1, Fields{{d->adv, 3}}, st, [=](hipStream_t s) { return hns_dev_advect_vector(D->gB, D->u, D->adv, sd, cl, dtv, inv_dx, s); }));
-			return hns_dev_advect_vector(d->gI, d->u, d->adv, sd, cl, dt, inv_dx, st);
+			return post(d, vort ? X_ADV : X_D1, Fields{{d->adv, 3}}, st, [=](hipStream_t s) { return hns_dev_advect_vector(D->gB, D->u, D->adv, sd, cl, dtv, inv_dx, s); },
+			            [=](hipStream_t s) { return hns_dev_advect_vector(D->gI, D->u, D->adv, sd, cl, dtv, inv_dx, s); });
 		}
 		if (vort && q == 1) {  // :172-176, out of place (the reference's in-place launch races)
 			const float scale = prm->vorticityScale, fs = prm->factorScale;
-			HNS_TRY(post(d, X_D1, Fields{{d->tmp, 3}}, st, [=](hipStream_t s) { return hns_dev_vorticity_confinement(D->gB, D->adv, D->tmp, dtv, inv_dx, scale, fs, s); }));
-			HNS_TRY(hns_dev_vorticity_confinement(d->gI, d->adv, d->tmp, dt, inv_dx, scale, fs, st));
+			HNS_TRY(post(d, X_D1, Fields{{d->tmp, 3}}, st, [=](hipStream_t s) { return hns_dev_vorticity_confinement(D->gB, D->adv, D->tmp, dtv, inv_dx, scale, fs, s); },
+			             [=](hipStream_t s) { return hns_dev_vorticity_confinement(D->gI, D->adv, D->tmp, dtv, inv_dx, scale, fs, s); }));
 			std::swap(d->adv, d->tmp);
 			return HNS_OK;
 		}
@@ -1859,7 +1945,7 @@ struct Step {
 			if (f.empty()) return HNS_OK;
 			return post(d, X_ADV, f, st, nothing);
 		}
-		HNS_TRY(complete(d, st));
+		if (!(ph >= 3 && ph < 3 + blocks && !d->mirror)) HNS_TRY(complete(d, st));  // (the blocks of the exchanged pressure loop do it themselves: sor_block_exchanged)
 		if (ph == 1) {
 			if (d->chain) {
 				const PhaseMirror m = phase_args(d, X_D1, Outs{{d->adv, 3}});
@@ -1872,16 +1958,17 @@ struct Step {
 				}, true);
 			}
 			const float dtv = dt;
-			HNS_TRY(post(d, X_D1, Fields{{d->adv, 3}}, st, [=](hipStream_t s) { return hns_dev_advect_vector(D->gB, D->u, D->adv, nullptr, 0, dtv, inv_dx, s); }));
-			return hns_dev_advect_vector(d->gI, d->u, d->adv, nullptr, 0, dt, inv_dx, st);
+			return post(d, X_D1, Fields{{d->adv, 3}}, st, [=](hipStream_t s) { return hns_dev_advect_vector(D->gB, D->u, D->adv, nullptr, 0, dtv, inv_dx, s); },
+			            [=](hipStream_t s) { return hns_dev_advect_vector(D->gI, D->u, D->adv, nullptr, 0, dtv, inv_dx, s); });
 		}
 		if (ph == 2) {
 			if (d->chain) {
 				const PhaseMirror m = phase_args(d, X_DIV, Outs{{d->div, 1}});
 				return chained(m, [&] { return hns_chain_divergence(d->gO, d->adv, d->div, inv_dx, &m, st); });
 			}
-			HNS_TRY(post(d, X_DIV, Fields{{d->div, 1}}, st, [=](hipStream_t s) { return hns_dev_divergence(D->gB, D->adv, D->div, inv_dx, s); }));
-			return hns_dev_divergence(d->gI, d->adv, d->div, inv_dx, st);
+			if (in_line_rank()) return post(d, X_DIV, Fields{{d->div, 1}}, st, [=](hipStream_t s) { return hns_dev_divergence(D->gO, D->adv, D->div, inv_dx, s); }, nothing, true);
+			return post(d, X_DIV, Fields{{d->div, 1}}, st, [=](hipStream_t s) { return hns_dev_divergence(D->gB, D->adv, D->div, inv_dx, s); },
+			            [=](hipStream_t s) { return hns_dev_divergence(D->gI, D->adv, D->div, inv_dx, s); });
 		}
 		if (ph < 3 + blocks) {  // one block of up to k sweeps; all but the last sweep the ghost leaves too
 			const int b = ph - 3;
@@ -1932,9 +2019,10 @@ struct Step {
 				const PhaseMirror m = phase_args(d, X_ADV, Outs{{d->u, 3}});
 				return chained(m, [&] { return hns_chain_subtract_pressure_gradient(d->gO, d->adv, d->p_result, d->u, inv_dx, &m, st); });
 			}
-			HNS_TRY(post(d, X_ADV, Fields{{d->u, 3}}, st,
-			             [=](hipStream_t s) { return hns_dev_subtract_pressure_gradient(D->gB, D->adv, D->p_result, D->u, nullptr, 0, inv_dx, s); }));
-			return hns_dev_subtract_pressure_gradient(d->gI, d->adv, d->p_result, d->u, nullptr, 0, inv_dx, st);
+			if (in_line_rank())
+				return post(d, X_ADV, Fields{{d->u, 3}}, st, [=](hipStream_t s) { return hns_dev_subtract_pressure_gradient(D->gO, D->adv, D->p_result, D->u, nullptr, 0, inv_dx, s); }, nothing, true);
+			return post(d, X_ADV, Fields{{d->u, 3}}, st, [=](hipStream_t s) { return hns_dev_subtract_pressure_gradient(D->gB, D->adv, D->p_result, D->u, nullptr, 0, inv_dx, s); },
+			            [=](hipStream_t s) { return hns_dev_subtract_pressure_gradient(D->gI, D->adv, D->p_result, D->u, nullptr, 0, inv_dx, s); });
 		}
 		// last phase: advect the scalars, and already post them for the advection that opens the next substep
 		d->u_ghosts_fresh = true;
@@ -1959,8 +2047,8 @@ struct Step {
 		}
 		Fields f;
 		for (float* p : d->phi_next) f.emplace_back(p, 1);  // the boundary leaves' new values travel while the interior is advected
-		if (d->n_scalars) HNS_TRY(post(d, X_ADV, f, st, [=](hipStream_t s) { return advect_scalars(D->gB, inv_dx, s); }));
-		HNS_TRY(advect_scalars(d->gI, inv_dx, st));
+		const Step self = *this;  // (the scalars' arrays as they are now: they are swapped below)
+		if (d->n_scalars) HNS_TRY(post(d, X_ADV, f, st, [=](hipStream_t s) { return self.advect_scalars(D->gB, inv_dx, s); }, [=](hipStream_t s) { return self.advect_scalars(D->gI, inv_dx, s); }));
 		std::swap(d->phi, d->phi_next);
 		d->phi_in_flight = d->n_scalars > 0 && d->world > 1;
 		return HNS_OK;

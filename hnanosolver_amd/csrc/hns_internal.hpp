@@ -41,6 +41,8 @@ struct Options {
 	std::atomic<int> dist_mirror{1};           // "dist_mirror": multi-GPU pressure loop with sweeps_per_exchange = 1 over the ipc / local transport delivers its halo inside the sweep kernel
 	std::atomic<int> dist_chain{1};            // "dist_chain": with dist_mirror, EVERY kernel of the substep of such a rank is one launch that delivers its own halo (read when the ranks connect)
 	std::atomic<int> divergence_form{0};       // "divergence": 0 auto (by size) | 1 row | 2 coalesced (own leaf fetched in memory order, handed to the row owners through LDS)
+	std::atomic<int> dist_pipeline{1};         // "dist_pipeline": between blocks of the exchanged pressure loop the compute stream waits for the boundary KERNEL of the posted exchange only, not for its messages (hns_dist.hip: complete_boundary_only)
+	std::atomic<int> dist_unsplit{1};          // "dist_unsplit": the exchanged pressure loop sweeps ALL owned leaves in one launch that packs its own messages, then exchanges and unpacks on the same stream (no boundary / interior split, no events)
 	std::atomic<int> dist_pack{1};             // "dist_pack": the blocked boundary sweep of an exchanged pressure loop writes the peers' messages itself (no pack launch per exchange)
 	std::atomic<int> dist_block{1};            // "dist_block": a rank with sweeps_per_exchange >= 2 sweeps its launch ranges two iterations per launch (hns_sorblock.hip over a range)
 	std::atomic<int> dist_spread{1};           // "dist_spread": the owned launch range of a sweeps_per_exchange = 1 rank deals its boundary leaves out to all XCDs (read at hns_dist_create)
@@ -181,6 +183,7 @@ extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_iterate(hns_grid* 
 namespace hns { struct PhaseMirror; struct PackMirror; }
 extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_block_pack_launch(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero,
                                                                                  const hns::PackMirror* m, void* stream, bool* done);  // hns_sorblock.hip: the boundary sweep that packs its own messages
+extern "C" __attribute__((visibility("hidden"))) bool hns_rbgs_block_packable(hns_grid* g);  // hns_sorblock.hip: would hns_rbgs_block_pack_launch launch on this grid's range?
 extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_mirror_sweep(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero,
                                                                            const hns::PhaseMirror* m, void* stream, bool backwards);
 extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_block_mirror_launch(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero,

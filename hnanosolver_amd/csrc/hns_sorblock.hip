@@ -1171,14 +1171,20 @@ int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const fl
 	return HNS_OK;
 }
 
-// The boundary sweep of an exchanged pressure loop that packs its own messages (hns_flags.hpp: PackMirror), two iterations per launch over the grid's launch range (the rank's
-// boundary leaves); *done = false and nothing launched where that range is not swept in 16^3 blocks by the XY form.
+// is the grid's launch range swept two iterations per launch in 16^3 blocks by the XY form (the one form that can pack a rank's messages as it stores)?
+extern "C" __attribute__((visibility("hidden"))) bool hns_rbgs_block_packable(hns_grid* g) {
+	int k = 0;
+	const int lw = options().sor_block_lean.load();
+	return g && g->n_active && (lw == 0 || lw == 4) && hns_rbgs_block_shape(g, &k) == 2 && k == 2 && hns_rbgs_block_lean(g, 2, 2);
+}
+
+// The sweep of an exchanged pressure loop that packs its own messages (hns_flags.hpp: PackMirror), two iterations per launch over the grid's launch range (the rank's
+// boundary leaves, or -- round 6 -- all of its owned leaves); *done = false and nothing launched where that range is not swept in 16^3 blocks by the XY form.
 extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_block_pack_launch(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero,
                                                                                  const hns::PackMirror* m, void* stream, bool* done) {
 	*done = false;
-	int k = 0;
-	const int lw = options().sor_block_lean.load();
-	if ((lw != 0 && lw != 4) || hns_rbgs_block_shape(g, &k) != 2 || k != 2 || !hns_rbgs_block_lean(g, 2, 2)) return HNS_OK;
+	if (!hns_rbgs_block_packable(g)) return HNS_OK;
+	if (int rc = hns_grid_build_blocks(g)) return rc;  // (the records of THIS launch range under the current options: ADVICE r5 -- not whatever table a previous launch left)
 	const unsigned bytes = (unsigned)((size_t)g->topo.n_leaves * 2048u);
 	const int* tab;
 	uint64_t n_sb;

@@ -163,6 +163,8 @@ const OptionDesc kOptions[] = {
     {"dist_pack", &Options::dist_pack, kWordsBool},
     {"dist_chain", &Options::dist_chain, kWordsBool},
     {"fuse", &Options::fuse_pointwise, kWordsBool},
+    {"dist_pipeline", &Options::dist_pipeline, kWordsBool},
+    {"dist_unsplit", &Options::dist_unsplit, kWordsBool},
 };
 const Options kDefaults;
 }  // namespace

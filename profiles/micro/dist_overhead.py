@@ -49,13 +49,23 @@ if lone_only:
     glob = origins if partition else HD.slab_domain(origins, R, world)
     lone_rank = pick[0] if pick else (0 if world < 3 else world // 2)
     lone = HD.DistRank(glob, world, lone_rank, vs, n_scalars=1, sweeps_per_exchange=k, leaf_order=leaf_order)
-    lone.connect_loopback()
+    lone.connect_loopback(rccl="--rccl" in sys.argv)  # (--rccl: every message through a one-rank RCCL communicator instead of a device copy)
     own = glob[lone.owned_ids].copy()
     if not partition:
         own[:, 0] %= R
     g = fields.synthetic_fields(own, R)
     lone.upload(g["vel"], [g["density"]])
-    print(json.dumps({"config": config, "world": world, "rank": lone_rank, "one_rank_loopback_substep_ms": round(timed(lambda: lone.core_substep(iters, dt, st), n=20), 3), "info": {x: lone.info()[x] for x in ("boundary_leaves", "interior_leaves", "ghost_leaves", "peers", "halo_peers")}}))
+    # (the loopback transports answer every message with the rank's own payload: the fields drift into nonsense over tens of substeps and kernel times with them -- the
+    # advection's back-traces grow; profiles/r06_dist_exchanged_notes.txt. Every repetition therefore starts from freshly uploaded fields: 2 warm-up + 8 timed substeps)
+    def rep():
+        lone.upload(g["vel"], [g["density"]])
+        return round(timed(lambda: lone.core_substep(iters, dt, st), n=8, warm=2), 3)  # (substeps 3 .. 10 behind the upload: the drift starts around the tenth)
+
+    reps = [rep() for _ in range(3 if "--three" in sys.argv else 1)]
+    print(json.dumps({"config": config, "world": world, "rank": lone_rank, "one_rank_loopback_substep_ms": reps[0] if len(reps) == 1 else reps, "rccl": "--rccl" in sys.argv,
+                      "info": {x: lone.info()[x] for x in ("boundary_leaves", "interior_leaves", "ghost_leaves", "peers", "halo_peers", "sweeps_per_exchange", "exchanges", "packed_exchanges", "messages_sent")}}))
+    if "--no-plain" in sys.argv:
+        sys.exit(0)
     # the same leaves (owned only) as a plain single-GPU grid: what the rank's work costs without being a rank
     f = fields.synthetic_fields(own, R)
     grid = api.create_grid_from_leaves(own, vs)

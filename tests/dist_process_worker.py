@@ -45,6 +45,9 @@ def main():
     # every rank of this test sits on cuda:0: in-kernel waits of several processes can fill the device's wave slots and starve the
     # process they wait for (hns_dist.hip: "guarded" puts ONE waiting wave in front of every chained launch instead)
     H.set_option("dist_mirror", "guarded")
+    case, *opts = case.split("@")  # "<case>@option=value@...": library options for this run
+    for o in opts:
+        H.set_option(*o.split("=", 1))
     try:
         origins, R = case_leaves(case)
         names = ["density", "temperature"]

@@ -59,3 +59,30 @@ def test_one_sided_sweeps_per_exchange_by_rank_size():
     assert SlabBench._one_sided_k(65944, 8) == 2  # BASELINE config 5 in 8 ranges: the temporally blocked chained sweep
     assert SlabBench._one_sided_k(2 * 32768, 2) == 2
     assert SlabBench._one_sided_k(512, 2) == 1 and SlabBench._one_sided_k(4800, 8) == 1  # 600 leaves per rank and fewer: one-leaf blocks, one iteration per chained launch
+
+
+def test_watchdog_cuts_a_call_that_blocks_in_c():
+    """the strong-scaling records of `bench.py --gpus N` are guarded by a watchdog THREAD, because a hung collective blocks the main thread inside C where no Python
+    signal handler runs. Emulated without a GPU: libc's sleep() through ctypes (GIL released, never returns to the bytecode loop in time). The watchdog's last words come
+    out, the process exits 0 at once, and what follows the blocked call never runs."""
+    import time
+
+    code = (
+        "import sys, ctypes\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "def last_words():\n"
+        "    sys.stdout.write('{\"abandoned\": true}\\n'); sys.stdout.flush()\n"
+        "dog = bench.Watchdog(1.0, last_words)\n"
+        "ctypes.CDLL(None).sleep(60)\n"
+        "dog.cancel()\n"
+        "print('not reached')\n"
+    )
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=50)
+    assert p.returncode == 0 and p.stdout.strip() == '{"abandoned": true}', p.stdout + p.stderr
+    assert time.time() - t0 < 30
+    # and a record that completes in time is not disturbed
+    code2 = f"import sys\nsys.path.insert(0, {ROOT!r})\nimport bench, time\ndog = bench.Watchdog(5.0, lambda: print('fired'))\ntime.sleep(0.1)\ndog.cancel()\nprint('done')\n"
+    p = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, cwd=ROOT, timeout=50)
+    assert p.returncode == 0 and p.stdout.strip() == "done", p.stdout + p.stderr

@@ -313,7 +313,11 @@ def _run_processes(world, case, k, iters, substeps, tmp_path, timeout=420):
     return [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
 
 
-@pytest.mark.parametrize("case,world,k,iters", [("plume", 3, 2, 7), ("plume12", 4, 3, 9), ("dense64", 2, 0, 50), ("dense64", 2, 1, 50), ("plume12", 4, 1, 9), ("dense64", 2, 2, 50), ("dense64", 3, 2, 7)])
+@pytest.mark.parametrize("case,world,k,iters", [("plume", 3, 2, 7), ("plume12", 4, 3, 9), ("dense64", 2, 0, 50), ("dense64", 2, 1, 50), ("plume12", 4, 1, 9), ("dense64", 2, 2, 50), ("dense64", 3, 2, 7),
+                                                # round 6, ranks of 2,048 / 1,365 leaves on the EXCHANGED path (dist_mirror = 0: what RCCL ranks run): the pressure loop as one launch over all owned
+                                                # leaves that packs its own messages, transfer and unpack behind it on the compute stream; divergence and gradient in line too; and the split form
+                                                ("128@dist_mirror=0", 2, 2, 9), ("128@dist_mirror=0", 2, 0, 10), ("128@dist_mirror=0", 3, 2, 7), ("128@dist_mirror=0@dist_unsplit=0", 2, 2, 9),
+                                                ("128@dist_mirror=0@dist_unsplit=0@dist_pipeline=0", 2, 0, 10)])
 def test_one_process_per_rank_over_mapped_peer_memory(case, world, k, iters, tmp_path):
     """The multi-process path for real: `world` PROCESSES (here sharing the one GPU), each a rank with its own streams, the
     halos put into the peer's memory through hipIpc mappings and the ranks meeting through device-side flags while their
@@ -323,7 +327,7 @@ def test_one_process_per_rank_over_mapped_peer_memory(case, world, k, iters, tmp
     waiting wave shares the device with nobody it waits for.)"""
     from dist_process_worker import case_leaves
 
-    origins, R = case_leaves(case)
+    origins, R = case_leaves(case.split("@")[0])
     names, substeps = ["density", "temperature"], 2
     _, want = single_grid(origins, R, names, iters, substeps)
     got = _run_processes(world, case, k, iters, substeps, tmp_path)
