@@ -37,7 +37,7 @@ class hns_dist_stats(C.Structure):
     _fields_ = [("world", C.c_int), ("rank", C.c_int), ("peers", C.c_int), ("sweeps_per_exchange", C.c_int),
                 ("boundary_leaves", C.c_uint64), ("interior_leaves", C.c_uint64), ("ghost_leaves", C.c_uint64),
                 ("region_voxels_sent", C.c_uint64 * 4), ("bytes_sent", C.c_uint64 * 4), ("messages_sent", C.c_uint64), ("exchanges", C.c_uint64),
-                ("halo_peers", C.c_uint64), ("packed_exchanges", C.c_uint64)]
+                ("halo_peers", C.c_uint64), ("packed_exchanges", C.c_uint64), ("chained", C.c_uint64)]
 
 
 HNS_DIST_IPC_BLOB_BYTES = 2048
@@ -77,8 +77,7 @@ SIGNATURES = {
     "hns_grid_release_cache": (_i, [_vp]),
     "hns_grid_matches": (_i, [_vp, _vp, _u64, C.c_uint]),
     "hns_grid_export_nanovdb": (_i, [_vp, _vp, _u64, _vp]),
-    "hns_grid_launch_tables": (_i, [_vp, _vp, _vp, _vp, _vp]),
-    "hns_grid_tile_tables": (_i, [_vp, _vp, _vp, _vp, _vp, _ip, _ip]),
+    "hns_grid_launch_tables": (_i, [_vp, _vp]),
     "hns_gather_leaves": (_i, [_vp, _u64, _vp, _u64, _vp, _i, _i, _vp]),
     "hns_scatter_leaves": (_i, [_vp, _u64, _i, C.POINTER(C.c_void_p)]),
     "hns_dilate_leaves": (_i, [_vp, _u64, _vp, _i, _vp, _u64, C.POINTER(C.c_uint64)]),

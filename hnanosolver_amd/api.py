@@ -169,15 +169,6 @@ class IndexGridHandle:
         _raise(lib.hns_grid_coords(self._ptr, out.ctypes.data))
         return out
 
-    def tile_tables(self):
-        """(groups [n_groups, tile_y*tile_z], rest [n_rest], (tile_y, tile_z)): the blocked SOR kernel's record groups"""
-        ng, nr, ty, tz = C.c_uint64(0), C.c_uint64(0), C.c_int(0), C.c_int(0)
-        _raise(lib.hns_grid_tile_tables(self._ptr, None, None, C.byref(ng), C.byref(nr), C.byref(ty), C.byref(tz)))
-        groups = np.zeros((ng.value, ty.value * tz.value), dtype=np.int32)
-        rest = np.zeros(nr.value, dtype=np.int32)
-        _raise(lib.hns_grid_tile_tables(self._ptr, groups.ctypes.data, rest.ctypes.data, None, None, None, None))
-        return groups, rest, (ty.value, tz.value)
-
     def set_active_leaves(self, n: int) -> None:
         _raise(lib.hns_grid_set_active_leaves(self._ptr, int(n)))
 
@@ -202,14 +193,11 @@ class IndexGridHandle:
     def active_leaves(self) -> int:
         return int(lib.hns_grid_active_leaves(self._ptr)) if self._ptr else 0
 
-    def launch_tables(self):
-        """(sched, wave_records, n_lone): copies of the device-built launch order (inspection / tests)."""
-        nw, nl = C.c_uint64(0), C.c_uint64(0)
-        _raise(lib.hns_grid_launch_tables(self._ptr, None, None, C.byref(nw), C.byref(nl)))
+    def launch_order(self) -> np.ndarray:
+        """sched: the leaf each workgroup of a one-workgroup-per-leaf kernel works on, in launch order (a copy of the device-built table; inspection / tests)."""
         sched = np.zeros((self.active_leaves(),), dtype=np.int32)
-        recs = np.zeros((nw.value, 56), dtype=np.int32)
-        _raise(lib.hns_grid_launch_tables(self._ptr, sched.ctypes.data, recs.ctypes.data, None, None))
-        return sched, recs, int(nl.value)
+        _raise(lib.hns_grid_launch_tables(self._ptr, sched.ctypes.data))
+        return sched
 
     def set_outside_element(self, element_index: int) -> None:
         _raise(lib.hns_grid_set_outside_element(self._ptr, int(element_index)))

@@ -836,7 +836,7 @@ int hns_dev_advect_scalars(hns_grid* g, const float* vel3, const float* const* i
 			GridDev gd = g->dev();
 			// backwards: the gradient kernel has just written the velocity front to back; starting on its cached tail also
 			// leaves the head cached for the next substep's advect_vector (256^3: -1 % here, -4 % there). Option "rev" = 0: forwards.
-			gd.rev = options().rev.load();
+			gd.rev = 1;
 			hipLaunchKernelGGL(k_advect_scalars_n<false>, grid, block, 0, (hipStream_t)stream, gd, vel3, P, scaled_dt);
 		}
 		else
@@ -866,7 +866,7 @@ int hns_advect_scalars_q4(hns_grid* g, const float* vel3, const float* q4, float
 		NULLCHK(s < n && (!P.in[s] || !P.out[s]), "hns_advect_scalars_q4");
 	}
 	GridDev gd = g->dev();
-	gd.rev = options().rev.load();  // (as hns_dev_advect_scalars)
+	gd.rev = 1;  // (as hns_dev_advect_scalars)
 	hipLaunchKernelGGL(k_advect_scalars_n<true>, dim3((unsigned)g->n_active), dim3(512), 0, (hipStream_t)stream, gd, vel3, P, dt * inv_dx);
 	return launch_status("hns_advect_scalars_q4");
 }

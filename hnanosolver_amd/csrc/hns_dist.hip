@@ -431,7 +431,6 @@ struct hns_dist {
 		const int2* entry = nullptr;
 		const unsigned char* mask = nullptr;  // null: whole leaves
 	} mir_type[4];
-	unsigned n_boundary_records = 0;
 	// the blocked boundary sweep of the exchanged pressure loop packs its own messages (hns_flags.hpp: PackMirror): tables per region type (X_D1, X_P), one allocation
 	void* pack_tables = nullptr;
 	PackMirror pack_type[4];
@@ -736,8 +735,6 @@ int setup_mirror(hns_dist* d, const std::vector<std::vector<int>> (&remote_leaf)
 		q += pad256(n);
 		return r;
 	};
-	unsigned* scratch = (unsigned*)q;
-	q += 256;
 	for (int t = 0; t < X_COUNT; ++t) {
 		d->mir_type[t].first = (const int*)put(first[t].data(), sizeof(int) * first[t].size());
 		d->mir_type[t].entry = (const int2*)put(entry[t].data(), sizeof(int2) * entry[t].size());
@@ -753,14 +750,10 @@ int setup_mirror(hns_dist* d, const std::vector<std::vector<int>> (&remote_leaf)
 		m.peer_rank[i] = d->peers[i].rank;
 	}
 	m.my_flags = d->ipc_flags, m.status = d->ipc_status;
-	unsigned counted[2] = {0, 0};
-	HNS_TRY(hns_rbgs_count_boundary_records(d->gO, nB, scratch, counted, nullptr));
-	d->n_boundary_records = counted[0];
-	m.head_records = std::min<unsigned>((counted[1] + 7u) & ~7u, (unsigned)d->gO->n_pairs & ~7u);
 	d->mirror = true;
 	// every kernel of the substep in one launch each (32-bit addressed advection kernels: fields below 4 GiB)
 	// (decided from what every rank knows alike: all ranks must take the same path)
-	d->chain = options().dist_chain.load() != 0 && (uint64_t)d->n_global * 6144u <= 0xFFFF0000ull;
+	d->chain = (uint64_t)d->n_global * 6144u <= 0xFFFF0000ull;
 	return HNS_OK;
 }
 
@@ -784,10 +777,11 @@ PhaseMirror phase_args(hns_dist* d, int t, const std::vector<std::pair<const flo
 // as they are NOW: hns_dist_create asks once and stores the answer (hns_dist::blocked), which is what create, connect and the substep use -- an option
 // changed between create and connect no longer leaves a rank on two paths at once.
 bool blocked_mirror_rule(int k, int world, int64_t n_global) {
-	return k == 2 && options().dist_block.load() != 0 && options().sor_block_lb.load() != 1 && world > 0 && n_global / world > 600 && n_global <= 2000000;
+	return k == 2 && options().sor_block_lb.load() != 1 && world > 0 && n_global / world > 600 && n_global <= 2000000;
 }
 bool blocked_mirror(const hns_dist* d) { return d->blocked; }
-bool mirror_wanted(const hns_dist* d) { return (d->k == 1 || blocked_mirror(d)) && d->world > 1 && options().dist_mirror.load() != 0; }
+// (rounds 2-5 also chained ranks of one-leaf blocks, sweeps_per_exchange = 1, through a mirroring one-iteration kernel; such ranks -- 600 leaves and fewer -- take the exchanged path now)
+bool mirror_wanted(const hns_dist* d) { return blocked_mirror(d) && d->world > 1 && options().dist_mirror.load() != 0; }
 
 }  // namespace
 
@@ -949,7 +943,7 @@ hns_dist* hns_dist_create(const int32_t* global_leaf_origins_xyz, uint64_t n_lea
 		if (!*gs[i]) return bail(rc);
 		// the owned range deals the boundary leaves out to all eight XCDs first (the mirroring pressure loop sweeps this range: its
 		// boundary waves poll, store twice and signal, and as the head of XCD 0's chunk they made that XCD the last to finish)
-		if (i == 2 && (sweeps_per_exchange == 1 || blocked_mirror(d)) && options().dist_spread.load() != 0) (*gs[i])->sched_prefix = (uint64_t)d->nB;
+		if (i == 2 && (sweeps_per_exchange == 1 || blocked_mirror(d))) (*gs[i])->sched_prefix = (uint64_t)d->nB;
 		// the chained blocked sweep (hns_sorblock.hip) must know which leaves of the owned range are boundary leaves whatever the launch order is
 		if (i == 2 || i == 0) (*gs[i])->chain_boundary = (uint64_t)d->nB;  // (the boundary range too: its blocked sweep may pack the peers' messages, build_pack_tables)
 		if ((rc = hns_grid_set_active_range(*gs[i], first[i], count[i])) != HNS_OK) return bail(rc);
@@ -1319,6 +1313,7 @@ int hns_dist_info(const hns_dist* d, hns_dist_stats* out) {
 		for (const Peer& p : d->peers) out->region_voxels_sent[t] += (uint64_t)p.send[t].voxels;
 	}
 	out->messages_sent = d->messages_sent, out->exchanges = d->exchanges, out->packed_exchanges = d->packed_exchanges;
+	out->chained = d->mirror && d->chain ? 1 : 0;
 	for (const Peer& p : d->peers) {
 		bool halo = false;
 		for (int t = 1; t < X_COUNT; ++t) halo = halo || p.send[t].voxels || p.recv[t].voxels;
@@ -1662,7 +1657,7 @@ int complete(hns_dist* d, hipStream_t st) {
 bool complete_boundary_only(hns_dist* d, hipStream_t st) {
 	Pending& x = d->pending;
 	if (!x.active) return true;
-	if (d->single_stream || !(d->comm || d->loopback || d->ipc) || options().dist_pipeline.load() == 0) return false;
+	if (d->single_stream || !(d->comm || d->loopback || d->ipc)) return false;
 	if (hipStreamWaitEvent(st, d->ev_bdone[x.parity], 0) != hipSuccess) return false;
 	x.active = false;
 	return true;
@@ -1707,17 +1702,13 @@ struct Step {
 	}
 
 	bool split_blocked() const {
-		if (d->k < 2 || options().dist_block.load() == 0) return false;
+		if (d->k < 2) return false;
 		for (hns_grid* g : {d->gB, d->gI}) {
 			if (!g->n_active) continue;
 			int launches = 0, per = 0;
 			if (hns_grid_rbgs_plan(g, 2, nullptr, 0, &launches, &per) != HNS_OK || launches != 1) return false;
 		}
 		return true;
-	}
-
-	int sweep(hns_grid* g, bool from_zero, hipStream_t s) const {
-		return hns_rbgs_iterate(g, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), 1, nullptr, s, from_zero);
 	}
 
 	int advect_scalars(hns_grid* g, float inv_dx, hipStream_t s) const {
@@ -1758,18 +1749,14 @@ struct Step {
 		// what the previous phase posted: in full in front of the first block (the divergence's ghosts) and wherever this block starts with sweeps over the ghost leaves;
 		// between blocks that sweep owned leaves only, the boundary kernel alone (complete_boundary_only)
 		// the one launch over all owned leaves that packs its own messages (below) where the owned range is swept in 16^3 blocks and the plan has pack tables for both region types
-		const bool unsplit = n >= 2 && in_line_rank() && d->pack_ok[X_P] && d->pack_ok[X_D1] && options().dist_pack.load() != 0 && options().dist_block.load() != 0 &&
-		                     hns_rbgs_block_packable(d->gO);
-		{
-			const int tail_ = (unsplit || (n >= 2 && split_blocked())) ? 2 : 1;
-			if (b == 0 || n > tail_ || !complete_boundary_only(d, st)) HNS_TRY(complete(d, st));
-		}
+		const bool unsplit = in_line_rank() && d->pack_ok[X_P] && d->pack_ok[X_D1] && hns_rbgs_block_packable(d->gO);
+		const int tail = unsplit ? std::min(n, 2) : ((n >= 2 && split_blocked()) ? 2 : 1);
+		if (b == 0 || n > tail || !complete_boundary_only(d, st)) HNS_TRY(complete(d, st));
 		if (b == 0 && d->timing && d->tev_used + 2 <= d->tev.size()) HNS_HIP(hipEventRecord(d->tev[d->tev_used], st));
 		// Round 4: the sweeps of the block that the exchange follows are TWO iterations in one temporally blocked launch per range
 		// (hns_sorblock.hip over a launch range: the ghost leaves are tile sources, 2K = 4 voxels deep, and are not swept; the X_P region
 		// of a plan with k >= 2 reaches 2k >= 4 voxels, its div region 2k - 1 >= 3), where the library's plan for the ranges says so.
 		// With k = 2 that is the whole pressure loop: no sweep ever touches a ghost leaf.
-		const int tail = (unsplit || (n >= 2 && split_blocked())) ? 2 : 1;
 		if (n > tail) {  // the sweeps over owned + ghost leaves as ONE solve of n - tail iterations: the library picks the form (two iterations per launch where that pays)
 			int in_b = 0;
 			HNS_TRY(hns_rbgs_iterate(d->gA, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), n - tail, &in_b, st, it == 0));
@@ -1792,7 +1779,7 @@ struct Step {
 				PackMirror m = D->pack_type[xt];
 				for (size_t pi = 0; pi < D->peers.size(); ++pi) m.msg[pi] = D->peers[pi].sbuf[D->pending.parity];
 				bool done = false;
-				HNS_TRY(hns_rbgs_block_pack_launch(D->gO, D->div, s0, d0, vs, omega_compute(vs), zero, &m, s, &done));
+				HNS_TRY(hns_rbgs_block_pack_launch(D->gO, D->div, s0, d0, vs, omega_compute(vs), zero, &m, s, &done, tail));
 				if (!done) return fail(HNS_ERR_RUNTIME, "hns_dist: the owned range is not swept in 16^3 blocks after all");
 				D->pending.prepacked = true;
 				return HNS_OK;
@@ -1804,11 +1791,11 @@ struct Step {
 		}
 		HNS_TRY(post(d, xt, Fields{{dst, 1}}, st, [=](hipStream_t s) -> int {
 			// two iterations in one blocked launch: the boundary sweep writes the peers' messages as it stores (PackMirror; option "dist_pack")
-			if (tail == 2 && D->pack_ok[xt] && options().dist_pack.load() != 0) {
+			if (tail == 2 && D->pack_ok[xt]) {
 				PackMirror m = D->pack_type[xt];
 				for (size_t pi = 0; pi < D->peers.size(); ++pi) m.msg[pi] = D->peers[pi].sbuf[D->pending.parity];
 				bool done = false;
-				HNS_TRY(hns_rbgs_block_pack_launch(D->gB, D->div, s0, d0, vs, omega_compute(vs), zero, &m, s, &done));
+				HNS_TRY(hns_rbgs_block_pack_launch(D->gB, D->div, s0, d0, vs, omega_compute(vs), zero, &m, s, &done, 2));
 				if (done) {
 					D->pending.prepacked = true;
 					return HNS_OK;
@@ -1977,29 +1964,15 @@ struct Step {
 				it = 0, src = d->p_a, dst = d->p_b;  // never warm-started (reference HNanoSolver.cu:113): the first sweep reads no p
 				if (d->timing && d->tev_used + 2 <= d->tev.size()) HNS_HIP(hipEventRecord(d->tev[d->tev_used], st));
 			}
-			if (d->k == 2 && iterations - it >= 2) {  // two iterations in ONE chained launch of the temporally blocked form (every rank alike: blocked_mirror)
+			{  // ONE chained launch of the temporally blocked form: two iterations, or the odd one left over (every rank alike: blocked_mirror)
+				const int its = std::min(2, iterations - it);
 				const PhaseMirror m = phase_args(d, X_P, Outs{{dst, 1}});
 				const bool zero = it == 0;
-				HNS_TRY(chained(m, [&] { return hns_rbgs_block_mirror_launch(d->gO, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), zero, &m, st); }));
+				HNS_TRY(chained(m, [&] { return hns_rbgs_block_mirror_launch(d->gO, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), zero, &m, st, its); }));
 				std::swap(src, dst);
-				it += 2;
+				it += its;
 				if (it == iterations) d->p_result = src;
 				return launch_status("hns_dist: blocked mirror sweep");
-			}
-			{  // the sweep delivers its boundary rows itself (k_rbgs_pair_mirror): no exchange, no second stream
-				const PhaseMirror m = phase_args(d, X_P, Outs{{dst, 1}});
-				const bool zero = it == 0, backwards = options().alternate.load() != 0 && (it & 1);
-				if (d->n_boundary_records || d->gO->n_active == 0) {
-					HNS_TRY(chained(m, [&] { return hns_rbgs_mirror_sweep(d->gO, d->div, src, dst, d->voxel_size, omega_compute(d->voxel_size), zero, &m, st, backwards); }));
-				} else {  // (a rank nobody mirrors: the plain sweep, and its flag from a kernel of its own)
-					HNS_TRY(sweep(d->gO, zero, st));
-					if (m.n_peers) hipLaunchKernelGGL(k_sweep_signal, dim3(1), dim3(64), 0, st, m);
-				}
-				const bool last_sweep = it + 1 == iterations;
-				std::swap(src, dst);
-				++it;
-				if (last_sweep) d->p_result = src;
-				return launch_status("hns_dist: mirror sweep");
 			}
 		}
 		if (ph == 3 + blocks) {

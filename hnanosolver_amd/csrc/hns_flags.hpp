@@ -78,7 +78,6 @@ struct PhaseMirror {
 	int* status;
 	uint32_t seq;               // number of this launch (all ranks count alike); boundary workgroups wait for the peers' seq - 1
 	int out_unit[8];            // which unit of the field memory each output array of this launch starts at
-	unsigned head_records;      // SOR sweeps: a multiple of 8, the wave records before it keep their place when a sweep walks backwards
 };
 struct NoMirror {};  // the same kernels on a single GPU: every chain_* call below compiles to nothing
 

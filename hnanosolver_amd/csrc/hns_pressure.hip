@@ -71,672 +71,6 @@ __global__ __launch_bounds__(256) void k_rbgs_color(const GridDev g, const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// red-black SOR, fused form (one launch = one full (red, black) iteration, p_in -> p_out), ONE WAVE PER LEAF
-// ---------------------------------------------------------------------------------------------------------------
-//
-// The wave updates the 256 red voxels of its leaf AND the 6*32 red voxels directly across each face (where that neighbour
-// leaf exists; outside the domain p stays 0) -- a halo red voxel (x=-1,y,z) needs p at (-2,y,z), (0,y,z), (-1,y+-1,z),
-// (-1,y,z+-1): face layers two deep and edge lines, never corners -- then the 256 black voxels from the new reds. The
-// recomputed halo reds see the same inputs as the neighbouring wave's own update, so the result is bit-identical to the
-// two-launch form (k_rbgs_color). Organised for the CDNA4 wave: the 64 lanes
-// of one wave own the 64 z-rows of a leaf (lane = x*8+y, the memory order, so the 2 KB payload is read and written as
-// two 16-byte accesses per lane, fully coalesced) and keep their row in registers. No workgroup barrier exists: the
-// wave's private LDS tile only carries rows between lanes. Work per lane:
-//   * own row: p[-2..9] (z halo from the +-z neighbour leaves) and div[0..7] in registers; lateral neighbours are the
-//     rows of lanes x+-1 / y+-1 (or of the face-neighbour leaves), read from LDS as 2 x ds_read_b128 each;
-//   * one z-halo red voxel: (x,y,-1) if x+y is odd, else (x,y,8);
-//   * lanes 0..31 additionally recompute the red voxels of one face-adjacent halo row each (4 faces x 8 rows); the
-//     depth-2 row behind it sits in a side area of the tile so that all four lateral reads have the same shape.
-// Every candidate is evaluated for all 8 z of a row and accepted by colour, which keeps the code free of
-// lane-dependent register indexing; rejected candidates never reach memory, so the result is bit-identical to
-// the two-launch form.
-//
-// LDS tile: rows (x',y') in [-1,8]^2 -> R = (x'+1)*10 + (y'+1), plus rows 100..131 for the depth-2 rows.
-// Row R occupies floats [4+12R-1, 4+12R+8]: z = -1 .. 8 (z=0 is 16-byte aligned; 48-byte row stride).
-
-#define W_OFF(R, z) (4 + (R) * 12 + (z))
-#define W_ROW(xp, yp) (((xp) + 1) * 10 + ((yp) + 1))
-#define W_FLOATS (4 + 132 * 12)
-
-struct Row8 {
-	float v[8];
-};
-
-__device__ __forceinline__ Row8 lds_row(const float* T, int R) {
-	const float4 a = *reinterpret_cast<const float4*>(T + W_OFF(R, 0));
-	const float4 b = *reinterpret_cast<const float4*>(T + W_OFF(R, 4));
-	Row8 r = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
-	return r;
-}
-
-__device__ __forceinline__ void lds_put_row(float* T, int R, const float (&v)[8]) {
-	*reinterpret_cast<float4*>(T + W_OFF(R, 0)) = make_float4(v[0], v[1], v[2], v[3]);
-	*reinterpret_cast<float4*>(T + W_OFF(R, 4)) = make_float4(v[4], v[5], v[6], v[7]);
-}
-
-__device__ __forceinline__ Row8 glb_row(const float* __restrict__ f, int leaf, int row) {
-	Row8 r;
-	if (leaf < 0) {
-#pragma unroll
-		for (int z = 0; z < 8; ++z) r.v[z] = 0.0f;
-		return r;
-	}
-	const float4* q = reinterpret_cast<const float4*>(f + (size_t)leaf * 512 + row * 8);
-	const float4 a = q[0], b = q[1];
-	r.v[0] = a.x, r.v[1] = a.y, r.v[2] = a.z, r.v[3] = a.w, r.v[4] = b.x, r.v[5] = b.y, r.v[6] = b.z, r.v[7] = b.w;
-	return r;
-}
-
-// SOR candidates of a whole z-row: c[z+1] = centre row z = -1..8 (10 values), lateral rows xp/xm/yp/ym, d = div row
-__device__ __forceinline__ void row_candidates(const Row8& xp, const Row8& xm, const Row8& yp, const Row8& ym, const float (&c)[10],
-                                               const float (&d)[8], float dx2, float omega, float (&cand)[8]) {
-#pragma unroll
-	for (int z = 0; z < 8; ++z) cand[z] = sor_update(xp.v[z], xm.v[z], yp.v[z], ym.v[z], c[z + 2], c[z], d[z], c[z + 1], dx2, omega);
-}
-
-// M = NoMirror, or PhaseMirror for a chained multi-GPU rank (hns_flags.hpp): the form for small ragged ranks (see rbgs_form)
-template <class M>
-__global__ __launch_bounds__(64) void k_rbgs_wave(const GridDev g, const float* __restrict__ div, const float* __restrict__ p_in,
-                                                  float* __restrict__ p_out, const float dx2, const float omega, const M m) {
-	__shared__ __attribute__((aligned(16))) float T[W_FLOATS];
-	const int l = threadIdx.x;
-	// per-block record {leaf, nbr27[27]} in launch order: one dependent scalar fetch instead of sched -> nbr27
-	const int* __restrict__ rec = g.blk + (size_t)blockIdx.x * 28;
-	const int leaf = __builtin_amdgcn_readfirstlane(rec[0]);
-	chain_begin(m, leaf);
-	const int n_xm = __builtin_amdgcn_readfirstlane(rec[1 + 4]), n_xp = __builtin_amdgcn_readfirstlane(rec[1 + 22]);
-	const int n_ym = __builtin_amdgcn_readfirstlane(rec[1 + 10]), n_yp = __builtin_amdgcn_readfirstlane(rec[1 + 16]);
-	const int n_zm = __builtin_amdgcn_readfirstlane(rec[1 + 12]), n_zp = __builtin_amdgcn_readfirstlane(rec[1 + 14]);
-
-	const int x = l >> 3, y = l & 7;
-	const int par = (x + y) & 1;  // 0: even z are red; 1: odd z are red
-
-	// ---- issue every global load up front ----
-	const Row8 P = glb_row(p_in, leaf, l);
-	const Row8 D = glb_row(div, leaf, l);
-	float2 zlo = make_float2(0.0f, 0.0f), zhi = make_float2(0.0f, 0.0f);  // p(x,y,-2..-1), p(x,y,8..9)
-	if (n_zm >= 0) zlo = *reinterpret_cast<const float2*>(p_in + (size_t)n_zm * 512 + l * 8 + 6);
-	if (n_zp >= 0) zhi = *reinterpret_cast<const float2*>(p_in + (size_t)n_zp * 512 + l * 8);
-	const int n_zh = par ? n_zm : n_zp;  // leaf of this lane's z-halo red voxel: (x,y,-1) if par else (x,y,8)
-	float d_zh = 0.0f;
-	if (n_zh >= 0) d_zh = div[(size_t)n_zh * 512 + l * 8 + (par ? 7 : 0)];
-
-	// halo rows (lanes 0..31): face f, row i. A = adjacent row (recomputed), B = the row behind it
-	const int f = (l >> 3) & 3, i = l & 7;
-	const int n_f = f == 0 ? n_xm : (f == 1 ? n_xp : (f == 2 ? n_ym : n_yp));
-	const int srcA = f == 0 ? 56 + i : (f == 1 ? i : (f == 2 ? i * 8 + 7 : i * 8));
-	const int srcB = f == 0 ? 48 + i : (f == 1 ? 8 + i : (f == 2 ? i * 8 + 6 : i * 8 + 1));
-	const int ax = f == 0 ? -1 : (f == 1 ? 8 : i), ay = f == 2 ? -1 : (f == 3 ? 8 : i);
-	const bool halo_lane = l < 32;
-	const int n_h = halo_lane ? n_f : -1;
-	const Row8 HA = glb_row(p_in, n_h, srcA);
-	const Row8 HB = glb_row(p_in, n_h, srcB);
-	const Row8 HD = glb_row(div, n_h, srcA);
-
-	// edge rows along z: tile rows (-1,-1), (-1,8), (8,-1), (8,8) (lanes 32..35)
-	const int ea = (l >> 1) & 1, eb = l & 1;
-	const bool erow_lane = (l >> 2) == 8;
-	const int n_er = erow_lane ? rec[1 + (ea ? 2 : 0) * 9 + (eb ? 2 : 0) * 3 + 1] : -1;
-	const Row8 ER = glb_row(p_in, n_er, (ea ? 0 : 7) * 8 + (eb ? 0 : 7));
-
-	// edge singles: lines 0..3 = (x,z) edges along y, lines 4..7 = (y,z) edges along x; one voxel per lane
-	const int ln = l >> 3, sa = (ln >> 1) & 1, sb = ln & 1;
-	const int ta = sa ? 8 : -1, tb = sb ? 8 : -1;  // tile coordinates of the line
-	const int ca = sa ? 0 : 7, cb = sb ? 0 : 7;    // coordinates inside the neighbour leaf
-	const int e_slot = ln < 4 ? (sa ? 2 : 0) * 9 + 3 + (sb ? 2 : 0) : 9 + (sa ? 2 : 0) * 3 + (sb ? 2 : 0);
-	const int e_src = ln < 4 ? ca * 64 + i * 8 + cb : i * 64 + ca * 8 + cb;
-	const int e_row = ln < 4 ? W_ROW(ta, i) : W_ROW(i, ta);
-	const int n_e = rec[1 + e_slot];
-	float e_val = 0.0f;
-	if (n_e >= 0) e_val = p_in[(size_t)n_e * 512 + e_src];
-
-	// ---- stage rows in LDS ----
-	const int R_own = W_ROW(x, y);
-	lds_put_row(T, R_own, P.v);
-	T[W_OFF(R_own, -1)] = zlo.y;
-	T[W_OFF(R_own, 8)] = zhi.x;
-	const int R_A = W_ROW(ax, ay), R_B = 100 + l;
-	if (halo_lane) {
-		lds_put_row(T, R_A, HA.v);
-		lds_put_row(T, R_B, HB.v);
-	}
-	if (erow_lane) lds_put_row(T, W_ROW(ea ? 8 : -1, eb ? 8 : -1), ER.v);
-	T[W_OFF(e_row, tb)] = e_val;
-	__syncthreads();  // single-wave workgroup: orders the LDS traffic, no cross-wave rendezvous
-
-	// ---- phase R ----
-	// (a) halo rows
-	float hnew[8];
-	if (halo_lane) {
-		const Row8 hxm = lds_row(T, f == 0 ? R_B : W_ROW(ax - 1, ay));
-		const Row8 hxp = lds_row(T, f == 1 ? R_B : W_ROW(ax + 1, ay));
-		const Row8 hym = lds_row(T, f == 2 ? R_B : W_ROW(ax, ay - 1));
-		const Row8 hyp = lds_row(T, f == 3 ? R_B : W_ROW(ax, ay + 1));
-		const float hc[10] = {T[W_OFF(R_A, -1)], HA.v[0], HA.v[1], HA.v[2], HA.v[3], HA.v[4], HA.v[5], HA.v[6], HA.v[7], T[W_OFF(R_A, 8)]};
-		float cand[8];
-		row_candidates(hxp, hxm, hyp, hym, hc, HD.v, dx2, omega, cand);
-		const int hpar = (ax + ay) & 1;
-#pragma unroll
-		for (int z = 0; z < 8; ++z) hnew[z] = (((hpar + z) & 1) == 0 && n_h >= 0) ? cand[z] : HA.v[z];
-	}
-	// (b) own row + z-halo voxel
-	const int R_xm = W_ROW(x - 1, y), R_xp = W_ROW(x + 1, y), R_ym = W_ROW(x, y - 1), R_yp = W_ROW(x, y + 1);
-	float c[10] = {zlo.y, P.v[0], P.v[1], P.v[2], P.v[3], P.v[4], P.v[5], P.v[6], P.v[7], zhi.x};  // z = -1..8
-	{
-		const Row8 xm = lds_row(T, R_xm), xp = lds_row(T, R_xp), ym = lds_row(T, R_ym), yp = lds_row(T, R_yp);
-		float cand[8];
-		row_candidates(xp, xm, yp, ym, c, D.v, dx2, omega, cand);
-		// z-halo red voxel at zh = par ? -1 : 8
-		const int zh = par ? -1 : 8;
-		const float zc = sor_update(T[W_OFF(R_xp, zh)], T[W_OFF(R_xm, zh)], T[W_OFF(R_yp, zh)], T[W_OFF(R_ym, zh)], par ? P.v[0] : zhi.y,
-		                            par ? zlo.x : P.v[7], d_zh, par ? zlo.y : zhi.x, dx2, omega);
-#pragma unroll
-		for (int z = 0; z < 8; ++z) c[z + 1] = (((par + z) & 1) == 0) ? cand[z] : c[z + 1];
-		if (n_zh >= 0) {
-			if (par) c[0] = zc;
-			else c[9] = zc;
-		}
-	}
-	__syncthreads();  // all phase-R reads done before the tile is overwritten with the new reds
-	{
-		const float own[8] = {c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]};
-		lds_put_row(T, R_own, own);
-		if (halo_lane) lds_put_row(T, R_A, hnew);
-	}
-	__syncthreads();
-
-	// ---- phase B ----
-	{
-		const Row8 xm = lds_row(T, R_xm), xp = lds_row(T, R_xp), ym = lds_row(T, R_ym), yp = lds_row(T, R_yp);
-		float cand[8];
-		row_candidates(xp, xm, yp, ym, c, D.v, dx2, omega, cand);
-		float4 o0, o1;
-		o0.x = par ? cand[0] : c[1];
-		o0.y = par ? c[2] : cand[1];
-		o0.z = par ? cand[2] : c[3];
-		o0.w = par ? c[4] : cand[3];
-		o1.x = par ? cand[4] : c[5];
-		o1.y = par ? c[6] : cand[5];
-		o1.z = par ? cand[6] : c[7];
-		o1.w = par ? c[8] : cand[7];
-		float4* q = reinterpret_cast<float4*>(p_out + (size_t)leaf * 512 + l * 8);
-		q[0] = o0;
-		q[1] = o1;
-		chain_store_row(m, 0, leaf, l, o0, o1);
-	}
-	chain_end(m, leaf);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// red-black SOR, fused form, one wave per PAIR of z-adjacent leaves (the production kernel for paired leaves)
-// ---------------------------------------------------------------------------------------------------------------
-//
-// z is the fastest-varying index of the leaf payload, so the +-z faces are the expensive halo: 8-byte pieces at a
-// 32-byte stride (16 cache lines for 512 useful bytes). k_rbgs_wave spends most of its time in the texture addresser /
-// L1 on exactly those accesses (profiles/r01_v2_*). Here one wave owns two leaves stacked along z: the face between
-// them never leaves the registers, the strided z-halo loads are halved, and the recomputation of the face-adjacent
-// halo rows (32 rows per leaf) is spread over all 64 lanes (lanes 0-31: lower leaf, 32-63: upper leaf).
-// Arithmetic per voxel is sor_update(), exactly as in the other forms.
-//
-// LDS rows are kept as separate 16-byte halves LO (z 0..3) / HI (z 4..7) indexed by a row number chosen so that the
-// lateral-neighbour reads of the 64 lanes are linear in the lane id (conflict-free ds_read_b128):
-//   (x', y') x' in -1..8, y' in 0..7 -> 8*(x'+1) + y'          (x'=-1 / 8 are the -x / +x face rows)
-//   (x', -1) -> 87 + 8*x'      (== row (x',0) - 1   mod 16), except x' = 7 -> 86 (see below)
-//   (x',  8) -> 80 + 8*x'      (== row (x',7) + 1   mod 16)
-//   edge rows (-1,-1) (-1,8) (8,-1) (8,8) -> 81..84; depth-2 rows of halo lane h -> 89 + 8*(h/6) + h%6
-// ZM / ZP hold the z=-1 values of the lower tile and the z=8 values of the upper tile (core rows and face rows).
-// 137 rows = 9,864 bytes per wave: 16 waves per CU fit in the 160 KB of LDS (a 153-row numbering that kept row (7,-1)
-// conflict-free too needed 11,016 bytes = 14 waves, i.e. 4.6 rounds of waves per launch at 256^3 instead of 4.0).
-
-#define PR_ROWS 137
-__host__ __device__ constexpr int pr_row_ym(int x) { return x == 7 ? 86 : 87 + 8 * x; }  // tile row (x, -1)
-__host__ __device__ constexpr int pr_row_yp(int x) { return 80 + 8 * x; }                 // tile row (x, 8)
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef int v4i __attribute__((ext_vector_type(4)));
-
-// a z-row as four (even z, odd z) pairs: the SOR arithmetic below is written on pairs so that it compiles to packed
-// v_pk_add_f32 / v_pk_mul_f32 (two voxels per VALU instruction); -ffp-contract=off keeps every operation separate
-struct RowP {
-	v2f q[4];
-};
-
-struct PairTile {
-	float4 LO[2][PR_ROWS];
-	float4 HI[2][PR_ROWS];
-	float ZM[PR_ROWS];
-	float ZP[PR_ROWS];
-};
-
-__device__ __forceinline__ RowP pt_row(const PairTile& S, int k, int R) {
-	const float4 a = S.LO[k][R], b = S.HI[k][R];
-	RowP r;
-	r.q[0] = v2f{a.x, a.y}, r.q[1] = v2f{a.z, a.w}, r.q[2] = v2f{b.x, b.y}, r.q[3] = v2f{b.z, b.w};
-	return r;
-}
-__device__ __forceinline__ void pt_put(PairTile& S, int k, int R, const RowP& r) {
-	S.LO[k][R] = make_float4(r.q[0].x, r.q[0].y, r.q[1].x, r.q[1].y);
-	S.HI[k][R] = make_float4(r.q[2].x, r.q[2].y, r.q[3].x, r.q[3].y);
-}
-
-// Row `row` of leaf `leaf` (-1 = absent -> zeros). Branch-free: an absent leaf reads leaf 0 and discards the data.
-__device__ __forceinline__ RowP glb_rowp(const float* __restrict__ f, int leaf, int row) {
-	const float4* q = reinterpret_cast<const float4*>(f + (size_t)(leaf < 0 ? 0 : leaf) * 512 + row * 8);
-	const float4 a = q[0], b = q[1];
-	const bool ok = leaf >= 0;
-	RowP r;
-	r.q[0] = v2f{ok ? a.x : 0.0f, ok ? a.y : 0.0f};
-	r.q[1] = v2f{ok ? a.z : 0.0f, ok ? a.w : 0.0f};
-	r.q[2] = v2f{ok ? b.x : 0.0f, ok ? b.y : 0.0f};
-	r.q[3] = v2f{ok ? b.z : 0.0f, ok ? b.w : 0.0f};
-	return r;
-}
-
-// sor_update() on two voxels at once; same operation order per element (Kernel.cu:621-622)
-__device__ __forceinline__ v2f sor2(v2f pxp, v2f pxm, v2f pyp, v2f pym, v2f pzp, v2f pzm, v2f d, v2f pold, float dx2, float omega) {
-	constexpr float inv6 = 0.166666667f;
-	const v2f pGS = ((pxp + pxm + pyp + pym + pzp + pzm) - d * dx2) * inv6;
-	return pold + omega * (pGS - pold);
-}
-
-// One colour of a whole z-row: candidates for all 8 voxels, then keep the even-z ones (take_even) or the odd-z ones.
-// c = the row itself, below / above = its z=-1 / z=8 neighbours. `valid` false leaves the row untouched.
-__device__ __forceinline__ RowP row_sweep(const RowP& xp, const RowP& xm, const RowP& yp, const RowP& ym, const RowP& c, float below, float above,
-                                          const RowP& d, float dx2, float omega, bool take_even, bool valid) {
-	RowP out;
-#pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		const v2f zp = v2f{c.q[j].y, j < 3 ? c.q[j < 3 ? j + 1 : 3].x : above};
-		const v2f zm = v2f{j > 0 ? c.q[j > 0 ? j - 1 : 0].y : below, c.q[j].x};
-		const v2f cand = sor2(xp.q[j], xm.q[j], yp.q[j], ym.q[j], zp, zm, d.q[j], c.q[j], dx2, omega);
-		out.q[j].x = (valid && take_even) ? cand.x : c.q[j].x;
-		out.q[j].y = (valid && !take_even) ? cand.y : c.q[j].y;
-	}
-	return out;
-}
-
-// Per-lane constants of k_rbgs_pair (halo-row duty of lane l), generated at compile time so that the kernel reads them
-// with two 16-byte loads instead of ~100 instructions of lane-dependent index arithmetic.
-// LDS row numbers of lane l's halo-row duty, packed 8 bits each into two dwords (one 8-byte load per lane):
-//   lo = RA | RB<<8 | H_xm<<16 | H_xp<<24,   hi = H_ym | H_yp<<8 | hpar<<16
-struct PairLaneTab {
-	unsigned t[64][2];
-};
-constexpr PairLaneTab make_pair_lane_tab() {
-	PairLaneTab T{};
-	for (int l = 0; l < 64; ++l) {
-		const int h = l & 31, f = h >> 3, i = h & 7;
-		const int RA = f == 0 ? i : (f == 1 ? 72 + i : (f == 2 ? pr_row_ym(i) : pr_row_yp(i)));
-		const int RB = 89 + 8 * (h / 6) + (h % 6);
-		const int H_xm = f == 0 ? RB : (f == 1 ? 64 + i : (i == 0 ? (f == 2 ? 81 : 82) : (f == 2 ? pr_row_ym(i - 1) : pr_row_yp(i - 1))));
-		const int H_xp = f == 1 ? RB : (f == 0 ? 8 + i : (i == 7 ? (f == 2 ? 83 : 84) : (f == 2 ? pr_row_ym(i + 1) : pr_row_yp(i + 1))));
-		const int H_ym = f == 2 ? RB : (f == 3 ? 8 * (i + 1) + 7 : (i == 0 ? (f == 0 ? 81 : 83) : (f == 0 ? i - 1 : 72 + i - 1)));
-		const int H_yp = f == 3 ? RB : (f == 2 ? 8 * (i + 1) : (i == 7 ? (f == 0 ? 82 : 84) : (f == 0 ? i + 1 : 72 + i + 1)));
-		const int hpar = (i + ((f & 1) ? 0 : 1)) & 1;  // parity of the halo row's x+y: faces -x,-y sit at coordinate -1
-		T.t[l][0] = (unsigned)RA | ((unsigned)RB << 8) | ((unsigned)H_xm << 16) | ((unsigned)H_xp << 24);
-		T.t[l][1] = (unsigned)H_ym | ((unsigned)H_yp << 8) | ((unsigned)hpar << 16);
-	}
-	return T;
-}
-__device__ const PairLaneTab g_pair_lane_tab = make_pair_lane_tab();
-
-// everything one wave reads from global memory for one leaf pair
-struct PairIn {
-	int leaf0, leaf1;  // leaf1 < 0: an unpaired leaf travelling alone (its +z neighbour, if any, belongs to another wave)
-	RowP P0, P1, D0, D1;  // own rows of p and div
-	float2 zlo, zhi;      // p(x,y,-2..-1) below leaf0, p(x,y,8..9) above leaf1
-	float d_zh;           // div at this lane's z-halo red voxel
-	bool zh_ok;           // ... and whether that voxel's leaf exists
-	RowP HA, HB, HD;      // halo-row duty: adjacent row, the row behind it, div of the adjacent row
-	bool f_ok;            // the face neighbour leaf exists
-	float e_val;          // the halo row's z-neighbour outside the pair
-	RowP ER;              // edge row (lanes 0..7)
-};
-
-// per-lane constants (do not depend on the pair)
-struct PairLaneCtx {
-	int l, x, y, w, I, R_xm, R_xp, R_ym, R_yp;
-	bool par;
-	int RA, RB, H_xm, H_xp, H_ym, H_yp;
-	bool hpar;
-	int ew, ea, eb;
-};
-
-__device__ __forceinline__ PairLaneCtx pair_lane_ctx(int lane) {
-	PairLaneCtx c;
-	c.l = lane;
-	c.x = c.l >> 3, c.y = c.l & 7;
-	c.par = (c.x + c.y) & 1;  // false: even z red, true: odd z red (both leaves: their z origins differ by 8)
-	c.w = c.l >> 5;
-	const uint2 lt = *reinterpret_cast<const uint2*>(&g_pair_lane_tab.t[c.l][0]);
-	c.RA = lt.x & 255, c.RB = (lt.x >> 8) & 255, c.H_xm = (lt.x >> 16) & 255, c.H_xp = lt.x >> 24;
-	c.H_ym = lt.y & 255, c.H_yp = (lt.y >> 8) & 255;
-	c.hpar = (lt.y >> 16) & 1;
-	c.ew = (c.l >> 2) & 1, c.ea = (c.l >> 1) & 1, c.eb = c.l & 1;
-	c.I = 8 * (c.x + 1) + c.y;
-	c.R_xm = c.I - 8, c.R_xp = c.I + 8, c.R_ym = c.y == 0 ? pr_row_ym(c.x) : c.I - 1, c.R_yp = c.y == 7 ? pr_row_yp(c.x) : c.I + 1;
-	return c;
-}
-
-// Blocked form (k_rbgs_tile): which faces of this wave's record belong to another wave of the same workgroup (its index in
-// the workgroup, -1 = nobody: the halo comes from memory as in the one-wave form). Wave-uniform.
-struct TileNbr {
-	int ym, yp, zm, zp;
-	bool zm_single;  // the wave below carries a lone leaf: its top leaf is its tile 0
-};
-
-// issue every global load of one pair (no waits here: the values are consumed in pair_compute).
-// ZERO: p_in is known to be 0 everywhere (first iteration of a solve, which is never warm-started: HNanoSolver.cu:113),
-// so none of it is read; only div is. TILED: faces listed in `nb` are not loaded at all.
-template <bool ZERO, bool TILED>
-__device__ __forceinline__ PairIn pair_load(const PairLaneCtx& c, const int* __restrict__ rec, const float* __restrict__ div,
-                                            const float* __restrict__ p_in, const TileNbr& nb) {
-	PairIn in;
-	// record: {leaf0, nbr27 of leaf0, leaf1, nbr27 of leaf1}; leaf1 is the +z neighbour of leaf0
-	in.leaf0 = __builtin_amdgcn_readfirstlane(rec[0]);
-	in.leaf1 = __builtin_amdgcn_readfirstlane(rec[28]);
-	const bool single = in.leaf1 < 0;
-	// below the lower leaf / above the top leaf (the top leaf is leaf0 itself when it travels alone)
-	// (TILED: a face shared inside the workgroup counts as absent here -- the loads stay branch-free, hit the always-hot
-	// leaf 0 and are discarded; the real values arrive through LDS in pair_compute)
-	const int n_zm = (TILED && nb.zm >= 0) ? -1 : __builtin_amdgcn_readfirstlane(rec[1 + 12]);
-	const int n_zp = (TILED && nb.zp >= 0) ? -1 : __builtin_amdgcn_readfirstlane(single ? rec[1 + 14] : rec[28 + 1 + 14]);
-	const int l = c.l;
-	const RowP zero_row = {{v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}}};
-	in.D0 = glb_rowp(div, in.leaf0, l), in.D1 = glb_rowp(div, in.leaf1, l);
-	if (ZERO) {
-		in.P0 = in.P1 = zero_row;
-		in.zlo = in.zhi = make_float2(0.0f, 0.0f);
-	} else {
-		in.P0 = glb_rowp(p_in, in.leaf0, l), in.P1 = glb_rowp(p_in, in.leaf1, l);
-		in.zlo = *reinterpret_cast<const float2*>(p_in + (size_t)(n_zm < 0 ? 0 : n_zm) * 512 + l * 8 + 6);
-		in.zhi = *reinterpret_cast<const float2*>(p_in + (size_t)(n_zp < 0 ? 0 : n_zp) * 512 + l * 8);
-		if (n_zm < 0) in.zlo = make_float2(0.0f, 0.0f);
-		if (n_zp < 0) in.zhi = make_float2(0.0f, 0.0f);
-	}
-	const int n_zh = c.par ? n_zm : n_zp;  // this lane's z-halo red voxel: below leaf0 if par, else above leaf1
-	in.zh_ok = n_zh >= 0;
-	in.d_zh = div[(size_t)(n_zh < 0 ? 0 : n_zh) * 512 + l * 8 + (c.par ? 7 : 0)];
-	// halo-row duty: lanes 0..31 -> leaf0, 32..63 -> leaf1; 4 faces x 8 rows each. For a leaf travelling alone lanes 32..63
-	// have no rows to recompute; they only fetch the z=8 neighbours of leaf0's halo rows (the face neighbour one leaf up).
-	// The neighbour ids are wave-uniform: they come from scalar loads of the record and are picked per lane with selects,
-	// so that no vector load sits between the record and the halo loads (one dependent memory level instead of three).
-	const int f = (l >> 3) & 3, i = l & 7;
-	const int* __restrict__ r0 = rec + 1;                      // neighbour table of leaf0
-	const int* __restrict__ r1 = rec + (single ? 1 : 29);      // ... of the leaf whose halo rows lanes 32..63 serve
-	const int a0 = r0[4], a1 = r0[22], a2 = r0[10], a3 = r0[16];    // faces -x,+x,-y,+y of leaf0
-	const int b0 = r1[4], b1 = r1[22], b2 = r1[10], b3 = r1[16];
-	const int c0 = r0[3], c1 = r0[21], c2 = r0[9], c3 = r0[15];     // the same faces one leaf down (dz = -1)
-	const int d0 = r1[5], d1 = r1[23], d2 = r1[11], d3 = r1[17];    // ... one leaf up (dz = +1)
-	const int nf0 = f == 0 ? a0 : (f == 1 ? a1 : (f == 2 ? a2 : a3));
-	const int nf1 = f == 0 ? b0 : (f == 1 ? b1 : (f == 2 ? b2 : b3));
-	const int ne0 = f == 0 ? c0 : (f == 1 ? c1 : (f == 2 ? c2 : c3));
-	const int ne1 = f == 0 ? d0 : (f == 1 ? d1 : (f == 2 ? d2 : d3));
-	// a y-face row of a neighbour inside the workgroup is that wave's own row: nothing to load or recompute (absent, as above)
-	const bool shared_duty = TILED && ((f == 2 && nb.ym >= 0) || (f == 3 && nb.yp >= 0));
-	const int n_f = shared_duty ? -1 : (c.w ? (single ? -1 : nf1) : nf0);
-	const int n_f_p = n_f, n_f_d = n_f;
-	const int srcA = f == 0 ? 56 + i : (f == 1 ? i : (f == 2 ? i * 8 + 7 : i * 8));
-	const int srcB = f == 0 ? 48 + i : (f == 1 ? 8 + i : (f == 2 ? i * 8 + 6 : i * 8 + 1));
-	in.f_ok = n_f >= 0;
-	in.HD = glb_rowp(div, n_f_d, srcA);
-	if (ZERO) {
-		in.HA = in.HB = in.ER = zero_row;
-		in.e_val = 0.0f;
-		return in;
-	}
-	in.HA = glb_rowp(p_in, n_f_p, srcA);
-	in.HB = glb_rowp(p_in, n_f_p, srcB);
-	// the halo row's own z-neighbour outside the pair: z=-1 for the lower leaf, z=8 for the upper leaf
-	const int n_e = shared_duty ? -1 : (c.w ? ne1 : ne0);
-	const float ev = p_in[(size_t)(n_e < 0 ? 0 : n_e) * 512 + srcA * 8 + (c.w ? 0 : 7)];
-	in.e_val = n_e < 0 ? 0.0f : ev;
-	// edge rows along z (lanes 0..7): tile rows (-1,-1), (-1,8), (8,-1), (8,8) of each leaf
-	const int n_er = (single && c.ew) ? -1 : rec[28 * c.ew + 1 + (c.ea ? 2 : 0) * 9 + (c.eb ? 2 : 0) * 3 + 1];
-	if (l < 8) in.ER = glb_rowp(p_in, n_er, (c.ea ? 0 : 7) * 8 + (c.eb ? 0 : 7));
-	return in;
-}
-
-// stage, red sweep, black sweep, store: one full iteration for one pair from registers `in`.
-// TILED (k_rbgs_tile): `tiles` holds one tile per wave of the workgroup, S = tiles[own]. A face listed in `nb` is read out
-// of the neighbouring wave's tile -- its staged rows before the red sweep, its updated rows after it -- instead of being
-// loaded and recomputed here: the same values (a wave's recomputed halo reds ARE the neighbour's own reds), so the same bits.
-// Out: where the swept rows go -- StorePlain (16-byte stores to p_out), or StoreMirror for a multi-GPU rank (below).
-struct StorePlain {
-	float* __restrict__ p_out;
-	__device__ __forceinline__ void operator()(int leaf, int k, int l, const RowP& o) const {
-		(void)k;
-		float4* q = reinterpret_cast<float4*>(p_out + (size_t)leaf * 512 + l * 8);
-		q[0] = make_float4(o.q[0].x, o.q[0].y, o.q[1].x, o.q[1].y);
-		q[1] = make_float4(o.q[2].x, o.q[2].y, o.q[3].x, o.q[3].y);
-	}
-};
-
-template <bool TILED, class Out>
-__device__ __forceinline__ void pair_compute(PairTile* tiles, PairTile& S, const PairLaneCtx& c, PairIn in, const TileNbr& nb, const Out& out,
-                                             const float dx2, const float omega) {
-	const int l = c.l, w = c.w, I = c.I;
-	const bool par = c.par;
-	const bool single = in.leaf1 < 0;  // wave-uniform
-	// lateral -y / +y rows of the own rows: the neighbouring wave's rows (x,7) / (x,0) where that face is shared
-	const bool red_ym = TILED && c.y == 0 && nb.ym >= 0, red_yp = TILED && c.y == 7 && nb.yp >= 0;
-	const PairTile& Tym = red_ym ? tiles[nb.ym] : S;
-	const PairTile& Typ = red_yp ? tiles[nb.yp] : S;
-	const int R_ym = red_ym ? I + 7 : c.R_ym, R_yp = red_yp ? I - 7 : c.R_yp;
-	// ---- stage ----
-	pt_put(S, 0, I, in.P0);
-	pt_put(S, 1, I, in.P1);
-	// p just below / above the pair, per row: from memory, or written here by the wave below / above when that face is shared
-	if (!TILED || nb.zm < 0) S.ZM[I] = in.zlo.y;
-	if (!TILED || nb.zp < 0) S.ZP[I] = in.zhi.x;
-	if (TILED && nb.zp >= 0) tiles[nb.zp].ZM[I] = single ? in.P0.q[3].y : in.P1.q[3].y;
-	if (TILED && nb.zm >= 0) tiles[nb.zm].ZP[I] = in.P0.q[0].x;
-	pt_put(S, w, c.RA, in.HA);
-	pt_put(S, w, c.RB, in.HB);
-	(w ? S.ZP : S.ZM)[c.RA] = in.e_val;
-	if (l < 8) pt_put(S, c.ew, 81 + c.ea * 2 + c.eb, in.ER);
-	__syncthreads();
-	if (TILED) {  // p just outside the pair along z, from the waves below / above
-		if (nb.zm >= 0) {
-			const float4 t = tiles[nb.zm].HI[nb.zm_single ? 0 : 1][I];
-			in.zlo = make_float2(t.z, t.w);
-		}
-		if (nb.zp >= 0) {
-			const float4 t = tiles[nb.zp].LO[0][I];
-			in.zhi = make_float2(t.x, t.y);
-		}
-	}
-
-	// ---- phase R ----
-	RowP hnew, c0, c1;
-	float zc;
-	{
-		const RowP hxm = pt_row(S, w, c.H_xm), hxp = pt_row(S, w, c.H_xp), hym = pt_row(S, w, c.H_ym), hyp = pt_row(S, w, c.H_yp);
-		const float other_lo = S.HI[0][c.RA].w, other_hi = single ? S.ZP[c.RA] : S.LO[1][c.RA].x;
-		const float below = w ? other_lo : in.e_val;  // z=-1 of this halo row
-		const float above = w ? in.e_val : other_hi;  // z=8
-		hnew = row_sweep(hxp, hxm, hyp, hym, in.HA, below, above, in.HD, dx2, omega, !c.hpar, in.f_ok);
-	}
-	{
-		const RowP xm = pt_row(S, 0, c.R_xm), xp = pt_row(S, 0, c.R_xp), ym = pt_row(Tym, 0, R_ym), yp = pt_row(Typ, 0, R_yp);
-		c0 = row_sweep(xp, xm, yp, ym, in.P0, in.zlo.y, single ? in.zhi.x : in.P1.q[0].x, in.D0, dx2, omega, !par, true);
-	}
-	{
-		const RowP xm = pt_row(S, 1, c.R_xm), xp = pt_row(S, 1, c.R_xp), ym = pt_row(Tym, 1, R_ym), yp = pt_row(Typ, 1, R_yp);
-		c1 = row_sweep(xp, xm, yp, ym, in.P1, in.P0.q[3].y, in.zhi.x, in.D1, dx2, omega, !par, !single);
-	}
-	{
-		// z-halo red voxel: (x,y,-1) under leaf0 when par, else (x,y,8) over leaf1
-		const float* ZA = par ? S.ZM : S.ZP;
-		const float zyp = (par ? Typ.ZM : Typ.ZP)[R_yp], zym = (par ? Tym.ZM : Tym.ZP)[R_ym];  // (the neighbouring wave's row across a shared y face)
-		zc = sor_update(ZA[c.R_xp], ZA[c.R_xm], zyp, zym, par ? in.P0.q[0].x : in.zhi.y, par ? in.zlo.x : (single ? in.P0.q[3].y : in.P1.q[3].y), in.d_zh,
-		                par ? in.zlo.y : in.zhi.x, dx2, omega);
-	}
-	// values just outside each row after the red sweep
-	float below0 = (par && in.zh_ok) ? zc : in.zlo.y;
-	float above1 = (!par && in.zh_ok) ? zc : in.zhi.x;
-	__syncthreads();  // phase-R reads complete before the rows are overwritten
-	pt_put(S, 0, I, c0);
-	pt_put(S, 1, I, c1);
-	pt_put(S, w, c.RA, hnew);
-	__syncthreads();
-	if (TILED) {  // ... which inside the workgroup are the neighbouring waves' freshly swept rows
-		if (nb.zm >= 0) below0 = tiles[nb.zm].HI[nb.zm_single ? 0 : 1][I].w;
-		if (nb.zp >= 0) above1 = tiles[nb.zp].LO[0][I].x;
-	}
-
-	// ---- phase B ----
-	{
-		const RowP xm = pt_row(S, 0, c.R_xm), xp = pt_row(S, 0, c.R_xp), ym = pt_row(Tym, 0, R_ym), yp = pt_row(Typ, 0, R_yp);
-		const RowP o = row_sweep(xp, xm, yp, ym, c0, below0, single ? above1 : c1.q[0].x, in.D0, dx2, omega, par, true);
-		out(in.leaf0, 0, l, o);
-	}
-	if (!single) {
-		const RowP xm = pt_row(S, 1, c.R_xm), xp = pt_row(S, 1, c.R_xp), ym = pt_row(Tym, 1, R_ym), yp = pt_row(Typ, 1, R_yp);
-		const RowP o = row_sweep(xp, xm, yp, ym, c1, c0.q[3].y, above1, in.D1, dx2, omega, par, true);
-		out(in.leaf1, 1, l, o);
-	}
-}
-
-// `last`: index of the last record when this sweep walks the list backwards (odd sweeps of a solve), else -1. Beyond the
-// Infinity Cache a sweep ends with the tail of the arrays cached; the next one starts there.
-// `list` (optional): the records to sweep, by index (the records the blocked kernel leaves over); null = all, in order.
-template <bool ZERO>
-__global__ __launch_bounds__(64) void k_rbgs_pair(const int* __restrict__ pairs, const int* __restrict__ list, const float* __restrict__ div,
-                                                  const float* __restrict__ p_in, float* __restrict__ p_out, const float dx2, const float omega, const int last) {
-	__shared__ __attribute__((aligned(16))) PairTile S;
-	const PairLaneCtx c = pair_lane_ctx(threadIdx.x);
-	// backwards = rows of eight records in reverse order, the position inside a row kept: workgroup b still lands on XCD
-	// b % 8, whose L2 holds that chunk's leaves from the previous sweep when the grid is small enough (128^3: all of it)
-	unsigned rec = blockIdx.x;
-	if (last >= 0) {
-		const unsigned rows = ((unsigned)last + 1u) >> 3;
-		if ((rec >> 3) < rows) rec = ((rows - 1u - (rec >> 3)) << 3) | (rec & 7u);
-	}
-	if (list) rec = (unsigned)list[rec];
-	const TileNbr nb = {-1, -1, -1, -1, false};
-	const PairIn in = pair_load<ZERO, false>(c, pairs + (size_t)rec * 56, div, p_in, nb);
-	pair_compute<false>(&S, S, c, in, nb, StorePlain{p_out}, dx2, omega);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// red-black SOR of one rank of a multi-GPU run, the halo exchange inside the sweep (hns_dist.hip, "mirror" pressure loop)
-// ---------------------------------------------------------------------------------------------------------------
-//
-// The boundary leaves are first in the local leaf order and their waves run first: a boundary wave waits until every peer
-// has completed the boundary part of its previous sweep (flag; raised early in that sweep, so long true by now): the peer's
-// boundary rows of that sweep are then in this rank's ghost voxels, and the peer no longer reads the ghost voxels of the
-// buffer this sweep writes. It then sweeps like any other wave and stores its rows twice: into p_out, and the voxels a peer
-// can read during ITS next sweep (reach 2) into that peer's ghost copy of the leaf, through the peer's memory mapped here,
-// and waits for those stores before it ends. The rank's "sweep complete" flag goes up on every peer when its NEXT launch
-// starts (first workgroup). No second stream, no pack / transfer / unpack kernels, no ghost sweeps; the arithmetic is
-// k_rbgs_pair's.
-struct StoreMirror {
-	float* __restrict__ p_out;
-	const PhaseMirror* m;
-	__device__ __forceinline__ void operator()(int leaf, int k, int l, const RowP& o) const {
-		(void)k;
-		float4* q = reinterpret_cast<float4*>(p_out + (size_t)leaf * 512 + l * 8);
-		const float4 lo = make_float4(o.q[0].x, o.q[0].y, o.q[1].x, o.q[1].y), hi = make_float4(o.q[2].x, o.q[2].y, o.q[3].x, o.q[3].y);
-		q[0] = lo;
-		q[1] = hi;
-		chain_store_row(*m, 0, leaf, l, lo, hi);
-	}
-};
-
-template <bool ZERO>
-__global__ __launch_bounds__(64) void k_rbgs_pair_mirror(const int* __restrict__ pairs, const float* __restrict__ div, const float* __restrict__ p_in,
-                                                         float* __restrict__ p_out, const float dx2, const float omega, const int last, const PhaseMirror m) {
-	__shared__ __attribute__((aligned(16))) PairTile S;
-	const PairLaneCtx c = pair_lane_ctx(threadIdx.x);
-	unsigned rec = blockIdx.x;
-	if (last >= 0 && rec >= m.head_records) {  // odd sweeps walk the records behind the boundary part backwards (see hns_rbgs_iterate: "alternate")
-		const unsigned rows = ((unsigned)last + 1u - m.head_records) >> 3;
-		unsigned t = rec - m.head_records;
-		if ((t >> 3) < rows) t = ((rows - 1u - (t >> 3)) << 3) | (t & 7u);
-		rec = m.head_records + t;
-	}
-	const int* __restrict__ r = pairs + (size_t)rec * 56;
-	const int leaf0 = __builtin_amdgcn_readfirstlane(r[0]), leaf1 = __builtin_amdgcn_readfirstlane(r[28]);
-	const int lowest = ((unsigned)leaf1 < (unsigned)leaf0) ? leaf1 : leaf0;  // a boundary record: either leaf below n_boundary (leaf1 may be -1)
-	chain_begin(m, lowest);
-	const TileNbr nb = {-1, -1, -1, -1, false};
-	const PairIn in = pair_load<ZERO, false>(c, r, div, p_in, nb);
-	pair_compute<false>(&S, S, c, in, nb, StoreMirror{p_out, &m}, dx2, omega);
-	// (Counting the boundary waves and raising the flag from the last one -- inside the same launch, so that the peers never wait
-	// -- cost 1.6 us per sweep: every boundary wave held its slot for an atomic round trip.)
-	chain_end(m, lowest);
-}
-
-// out[0] = number of records that touch a boundary leaf, out[1] = 1 + index of the last of them
-__global__ void k_count_boundary_records(const int* __restrict__ pairs, unsigned n_records, int n_boundary, unsigned* out) {
-	const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n_records) return;
-	const int l0 = pairs[(size_t)i * 56], l1 = pairs[(size_t)i * 56 + 28];
-	if (l0 < n_boundary || (unsigned)l1 < (unsigned)n_boundary) {
-		atomicAdd(out, 1u);
-		atomicMax(out + 1, i + 1u);
-	}
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// red-black SOR, blocked form: kTileY x kTileZ wave records per workgroup, shared faces through LDS
-// ---------------------------------------------------------------------------------------------------------------
-//
-// What bounds k_rbgs_pair once the sweep arrays leave the Infinity Cache is not the 12 B/voxel it must move but the halo: the
-// y faces (64-byte pieces) and z faces (8-byte pieces at a 32-byte stride, i.e. every line of the neighbouring leaf) of
-// leaves whose own wave runs elsewhere on the chip (measured with the halo sources switched off one by one,
-// profiles/micro/exp: 512^3 433 us -> 377 without the y faces, 361 without the z faces, 275 without any halo). Here the
-// wave records that are each other's y / z neighbours form one workgroup (groups built on the device, hns_gridbuild.hip:
-// k_group_assign) and a face between two of them never touches memory: before the red sweep a wave reads the neighbour's
-// staged rows out of its LDS tile, after it the neighbour's updated rows -- exactly the values it would otherwise load and
-// recompute. Outer faces of the group, and all x faces (contiguous 256-byte rows, cheap), work as in the one-wave form.
-template <bool ZERO>
-__global__ __launch_bounds__(64 * kTileY * kTileZ) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_rbgs_tile(const int* __restrict__ pairs, const int* __restrict__ groups, const float* __restrict__ div,
-                                                                    const float* __restrict__ p_in, float* __restrict__ p_out, const float dx2, const float omega,
-                                                                    const int last) {
-	constexpr int W = kTileY * kTileZ;
-	__shared__ __attribute__((aligned(16))) PairTile S[W];
-	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // slot a * kTileZ + c of this wave in the group
-	const PairLaneCtx c = pair_lane_ctx(threadIdx.x & 63);
-	unsigned grp = blockIdx.x;
-	if (last >= 0) {
-		const unsigned rows = ((unsigned)last + 1u) >> 3;
-		if ((grp >> 3) < rows) grp = ((rows - 1u - (grp >> 3)) << 3) | (grp & 7u);
-	}
-	const int* __restrict__ members = groups + (size_t)grp * W;
-	const int* __restrict__ rec = pairs + (size_t)members[wv] * 56;
-	const int a = wv / kTileZ, cz = wv % kTileZ;
-	const int leaf1 = rec[28];
-	const bool single = leaf1 < 0;
-	// a face is shared only if the slot next door holds exactly the neighbouring leaves (the grouping goes by coordinates
-	// alone: z-runs that pair up differently, or a lone leaf beside a pair, sit in the right slots without being neighbours)
-	TileNbr nb = {-1, -1, -1, -1, false};
-	if (a > 0) {
-		const int* q = pairs + (size_t)members[wv - kTileZ] * 56;
-		if (q[0] == rec[1 + 10] && (single ? q[28] < 0 : q[28] == rec[29 + 10])) nb.ym = wv - kTileZ;
-	}
-	if (a + 1 < kTileY) {
-		const int* q = pairs + (size_t)members[wv + kTileZ] * 56;
-		if (q[0] == rec[1 + 16] && (single ? q[28] < 0 : q[28] == rec[29 + 16])) nb.yp = wv + kTileZ;
-	}
-	if (cz > 0) {
-		const int* q = pairs + (size_t)members[wv - 1] * 56;
-		const int top = q[28] < 0 ? q[0] : q[28];
-		if (top == rec[1 + 12]) nb.zm = wv - 1, nb.zm_single = q[28] < 0;
-	}
-	if (cz + 1 < kTileZ) {
-		const int* q = pairs + (size_t)members[wv + 1] * 56;
-		if (q[0] == (single ? rec[1 + 14] : rec[29 + 14])) nb.zp = wv + 1;
-	}
-	nb.ym = __builtin_amdgcn_readfirstlane(nb.ym), nb.yp = __builtin_amdgcn_readfirstlane(nb.yp);
-	nb.zm = __builtin_amdgcn_readfirstlane(nb.zm), nb.zp = __builtin_amdgcn_readfirstlane(nb.zp);
-	const PairIn in = pair_load<ZERO, true>(c, rec, div, p_in, nb);
-	pair_compute<true>(S, S[wv], c, in, nb, StorePlain{p_out}, dx2, omega);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // subtractPressureGradient (reference Kernel.cu:765-829 / :694-762)
 // ---------------------------------------------------------------------------------------------------------------
 
@@ -1082,7 +416,7 @@ int hns_dev_divergence(hns_grid* g, const float* vel3, float* div, float inv_dx,
 		GridDev gd = g->dev();
 		// backwards: advect_vector has just written the velocity front to back, so its tail is what the Infinity Cache holds
 		// (256^3: 74 -> 66 us). Option "rev" = 0 walks every kernel forwards.
-		gd.rev = options().rev.load();
+		gd.rev = 1;
 		// option "divergence" = auto | row | coalesced: by size (k_divergence_row's COAL form from 16k leaves; loses below, see the kernel)
 		const int form = options().divergence_form.load();
 		if (form == 2 || (form == 0 && g->n_active >= 16384))
@@ -1103,7 +437,7 @@ int hns_divergence_combust_buoyancy(hns_grid* g, const float* vel3, float* div, 
 	if (g->n_active == 0) return HNS_OK;
 	if (!g->d_blk) return fail(HNS_ERR_RUNTIME, "hns_divergence_combust_buoyancy: the grid has no launch tables");
 	GridDev gd = g->dev();
-	gd.rev = options().rev.load();
+	gd.rev = 1;
 	const CombustFuse fz{fuel, waste, temperature, flame, reinterpret_cast<float4*>(q4), vel3_out, temp_gain, expansion, dt, ambient, strength};
 	const int form = options().divergence_form.load();
 	if (form == 2 || (form == 0 && g->n_active >= 16384))
@@ -1119,7 +453,7 @@ int hns_chain_divergence(hns_grid* g, const float* vel3, float* div, float inv_d
 	if (int rc = check_grid(g, "hns_chain_divergence")) return rc;
 	if (g->n_active == 0 || !g->d_blk) return fail(HNS_ERR_RUNTIME, "hns_chain_divergence: empty launch range");
 	GridDev gd = g->dev();
-	gd.rev = options().rev.load();  // (as hns_dev_divergence; walked backwards the boundary leaves come last, which the chain does not mind)
+	gd.rev = 1;  // (as hns_dev_divergence; walked backwards the boundary leaves come last, which the chain does not mind)
 	hipLaunchKernelGGL(k_divergence_row<PhaseMirror>, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, vel3, div, inv_dx, *m);
 	return launch_status("hns_chain_divergence");
 }
@@ -1139,68 +473,14 @@ int hns_dev_rbgs_color(hns_grid* g, const float* div, float* p, float dx, float 
 	return launch_status("hns_dev_rbgs_color");
 }
 
-// Which form sweeps this grid (option "rbgs"): the pair kernel, unless the option or the shape of the grid says otherwise.
-// One leaf per wave is the better choice for SMALL IRREGULAR grids, which are latency-bound (twice as many, shorter waves;
-// no half-empty pair waves): measured on the 3.9k-leaf plume 9.0 vs 11.9 us per iteration; and for grids of a few hundred
-// leaves, which cannot fill 256 CUs with one wave per pair.
-static int rbgs_form(hns_grid* g, int opt) {
-	if (opt == kRbgsColor || opt == kRbgsWave) return opt;
-	if (!g->d_pairs) return kRbgsWave;
-	if (opt == kRbgsPair) return kRbgsPair;
-	if (opt == kRbgsTile) return (hns_grid_build_tiles(g) == HNS_OK && g->d_tile_groups) ? kRbgsTile : kRbgsPair;
-	// (<= 2048: also the boundary range of a multi-GPU rank, a few thousand leaves swept next to the interior launch)
-	if (g->n_active <= 2048 || (g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs)) return kRbgsWave;
-	// far beyond the Infinity Cache the halo of leaves swept elsewhere on the chip is what costs: blocked form where most
-	// records sit in complete groups (512^3: 428 -> 379 us per sweep; no gain on the ragged 66k-leaf plume, none in cache)
-	if (g->n_active > 100000 && hns_grid_build_tiles(g) == HNS_OK && g->d_tile_groups && g->n_tile_groups * (uint64_t)(kTileY * kTileZ) * 10 >= g->n_pairs * 9)
-		return kRbgsTile;
-	return kRbgsPair;
-}
-
-// Grids the temporally blocked form sweeps by default (option "rbgs" = auto)
-// (measured, profiles/r03_sor_forms.txt, us per iteration one-iteration form -> blocked: 64 leaves 3.7 -> 2.1, 512 4.0 -> 3.0, 4,096 7.9 -> 6.5,
-// 13,824 19.0 -> 17.8, 32,768 39.2 -> 37.1, 64,000 98 -> 88, 262,144 394 -> 349: every size; the one-iteration forms remain for
-// launch ranges -- the ranks of a multi-GPU run -- and for an odd iteration left over)
-static bool rbgs_auto_block(const hns_grid* g) {
-	(void)g;
-	return true;
-}
-
-// one full (red, black) iteration src -> dst. src_is_zero (pair form only): the caller vouches that src is 0 on every
-// leaf (first iteration of a solve) and the kernel skips reading it.
-static int launch_rbgs_iteration(hns_grid* g, const GridDev& gd, const float* div, const float* src, float* dst, float dx2, float omega, int form,
-                                 hipStream_t st, bool src_is_zero = false, bool backwards = false) {
-	const int last = backwards ? (int)g->n_pairs - 1 : -1;
-	if (form == kRbgsColor) {
-		// the reference's own decomposition, kept as the independent cross-check: copy, then one launch per colour in place
-		HNS_HIP(hipMemcpyAsync(dst, src, sizeof(float) * 512 * (size_t)g->topo.n_leaves, hipMemcpyDeviceToDevice, st));
-		hipLaunchKernelGGL(k_rbgs_color, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, dst, dx2, omega, 0);
-		hipLaunchKernelGGL(k_rbgs_color, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, dst, dx2, omega, 1);
-	} else if (form == kRbgsWave) {
-		hipLaunchKernelGGL(k_rbgs_wave<NoMirror>, dim3((unsigned)g->n_active), dim3(64), 0, st, gd, div, src, dst, dx2, omega, NoMirror{});
-	} else if (form == kRbgsTile) {
-		// complete groups through the blocked kernel, the records outside them through the one-wave kernel (disjoint leaves, both
-		// read src and write dst: any order)
-		const dim3 tb(64 * kTileY * kTileZ);
-		const int* recs = (const int*)g->d_pairs;
-		const int glast = backwards ? (int)g->n_tile_groups - 1 : -1, rlast = backwards ? (int)g->n_tile_rest - 1 : -1;
-		if (src_is_zero) {
-			if (g->n_tile_groups) hipLaunchKernelGGL(k_rbgs_tile<true>, dim3((unsigned)g->n_tile_groups), tb, 0, st, recs, (const int*)g->d_tile_groups, div, src, dst, dx2, omega, glast);
-			if (g->n_tile_rest) hipLaunchKernelGGL(k_rbgs_pair<true>, dim3((unsigned)g->n_tile_rest), dim3(64), 0, st, recs, (const int*)g->d_tile_rest, div, src, dst, dx2, omega, rlast);
-		} else {
-			if (g->n_tile_groups) hipLaunchKernelGGL(k_rbgs_tile<false>, dim3((unsigned)g->n_tile_groups), tb, 0, st, recs, (const int*)g->d_tile_groups, div, src, dst, dx2, omega, glast);
-			if (g->n_tile_rest) hipLaunchKernelGGL(k_rbgs_pair<false>, dim3((unsigned)g->n_tile_rest), dim3(64), 0, st, recs, (const int*)g->d_tile_rest, div, src, dst, dx2, omega, rlast);
-		}
-	} else if (src_is_zero) {
-		hipLaunchKernelGGL(k_rbgs_pair<true>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, (const int*)nullptr, div, src, dst, dx2, omega, last);
-	} else {
-		// one launch: the record list holds the z-adjacent pairs and, as {leaf, nbr27, -1, ...}, the leaves that found no partner
-		hipLaunchKernelGGL(k_rbgs_pair<false>, dim3((unsigned)g->n_pairs), dim3(64), 0, st, (const int*)g->d_pairs, (const int*)nullptr, div, src, dst, dx2, omega, last);
-	}
+// One full (red, black) iteration src -> dst in the reference's own decomposition: copy, then one launch per colour in place (k_rbgs_color). The independent
+// cross-check of the temporally blocked kernels (option "rbgs" = color), and what sweeps a grid they cannot (more than 2 M leaves).
+static int launch_color_iteration(hns_grid* g, const GridDev& gd, const float* div, const float* src, float* dst, float dx2, float omega, hipStream_t st) {
+	HNS_HIP(hipMemcpyAsync(dst, src, sizeof(float) * 512 * (size_t)g->topo.n_leaves, hipMemcpyDeviceToDevice, st));
+	hipLaunchKernelGGL(k_rbgs_color, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, dst, dx2, omega, 0);
+	hipLaunchKernelGGL(k_rbgs_color, dim3((unsigned)g->n_active), dim3(256), 0, st, gd, div, dst, dx2, omega, 1);
 	return HNS_OK;
 }
-
-static inline float dx2_of(float dx) { return dx * dx; }  // Kernel.cu:608
 
 int hns_dev_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int* result_in_b,
                          void* stream) {
@@ -1208,7 +488,7 @@ int hns_dev_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, 
 }
 
 // from_zero: the solve starts from p = 0 (the reference never warm-starts, HNanoSolver.cu:113 / PressureProjection.cu:35) and
-// p_a's content is irrelevant: the first sweep does not read it, so the caller need not clear it either.
+// p_a's content is irrelevant: the first blocked launch does not read it, so the caller need not clear it either.
 int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int* result_in_b, void* stream,
                      bool from_zero) {
 	if (int rc = check_grid(g, "hns_dev_rbgs_iterate")) return rc;
@@ -1216,123 +496,66 @@ int hns_rbgs_iterate(hns_grid* g, const float* div, float* p_a, float* p_b, floa
 	if (p_a == p_b) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dev_rbgs_iterate: p_a and p_b must be distinct buffers");
 	if (iterations < 0) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_dev_rbgs_iterate: negative iteration count");
 	if (result_in_b) *result_in_b = iterations & 1;
+	hipStream_t st = (hipStream_t)stream;
 	if (g->n_active == 0 || iterations == 0) {
-		if (from_zero) HNS_HIP(hipMemsetAsync(p_a, 0, sizeof(float) * 512 * (size_t)g->topo.n_leaves, (hipStream_t)stream));  // the result is p_a = 0
+		if (from_zero) HNS_HIP(hipMemsetAsync(p_a, 0, sizeof(float) * 512 * (size_t)g->topo.n_leaves, st));  // the result is p_a = 0
 		return HNS_OK;
 	}
 	const float dx2 = dx * dx;  // Kernel.cu:608
 	const GridDev gd = g->dev();
-	// Temporally blocked form (hns_sorblock.hip): k iterations per launch, p read and written once per launch. An odd iteration
-	// left over goes through the one-iteration form below.
-	{
-		const int opt = options().rbgs.load();
-		int k_max = 0;
-		const int lb = (iterations >= 2 && (opt == kRbgsBlock || (opt == kRbgsAuto && rbgs_auto_block(g)))) ? hns_rbgs_block_shape(g, &k_max) : 0;
-		if (lb) {
-			float* src = p_a;
-			float* dst = p_b;
-			int left = iterations, launches = 0;
-			bool zero = from_zero;
-			while (left >= 2) {
-				const int k = (k_max >= 4 && left >= 4) ? 4 : 2;
-				if (int rc = hns_rbgs_block_launch(g, lb, k, zero, div, src, dst, dx2, omega, stream)) return rc;
-				std::swap(src, dst);
-				left -= k, ++launches, zero = false;
-			}
-			if (left) {
-				if (int rc = launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, rbgs_form(g, kRbgsAuto), (hipStream_t)stream)) return rc;
-				++launches;
-			}
-			if (result_in_b) *result_in_b = launches & 1;
-			return launch_status("hns_dev_rbgs_iterate");
-		}
-	}
-	const int form = rbgs_form(g, options().rbgs.load());
-	if (from_zero && form != kRbgsPair && form != kRbgsTile) {  // the other forms read their input: give them the zeros
-		HNS_HIP(hipMemsetAsync(p_a, 0, sizeof(float) * 512 * (size_t)g->topo.n_leaves, (hipStream_t)stream));
-		from_zero = false;
-	}
-	// Odd sweeps walk the record list backwards: a sweep ends with the tail of p / div in the Infinity Cache and the next one
-	// begins there. Nothing below the cache size, -11 % at 288^3 (287 MB of sweep arrays against 256 MB of cache), -6 % at
-	// 320^3, -1.4 % at 512^3 (profiles/micro/sor_schedule.py). The result does not depend on the order. Option "alternate" = 0: off.
-	// (Replaying the loop as a hipGraph was measured neutral at every size -- 64^3 4.11 vs 4.14 us per sweep, 256^3 39.2 vs 39.1: the
-	// eager loop is never launch-bound -- and removed in round 3.)
-	const bool alternate = options().alternate.load() != 0;
+	// Temporally blocked (hns_sorblock.hip): k iterations per launch, p read and written once per launch -- 16^3 blocks two at a time, one-leaf blocks (small grids) two
+	// or four; an odd iteration left over is one more launch of the same kernel with two colour sweeps. (A launch range -- a multi-GPU rank's boundary / interior leaves --
+	// must never go through the two-launch form below: its copy of the whole field would undo what the launch over the neighbouring range has stored.)
+	int k_max = 0;
+	const int lb = options().rbgs.load() == kRbgsColor ? 0 : hns_rbgs_block_shape(g, &k_max);
 	float* src = p_a;
 	float* dst = p_b;
-	for (int it = 0; it < iterations; ++it) {
-		if (int rc = launch_rbgs_iteration(g, gd, div, src, dst, dx2, omega, form, (hipStream_t)stream, from_zero && it == 0, alternate && (it & 1))) return rc;
-		float* tmp = src;
-		src = dst;
-		dst = tmp;
+	int left = iterations, launches = 0;
+	bool zero = from_zero;
+	while (lb && left >= 2) {
+		const int k = (k_max >= 4 && left >= 4) ? 4 : 2;
+		if (int rc = hns_rbgs_block_launch(g, lb, k, zero, div, src, dst, dx2, omega, stream)) return rc;
+		std::swap(src, dst);
+		left -= k, ++launches, zero = false;
 	}
+	if (lb && left) {
+		if (int rc = hns_rbgs_block_launch(g, lb, 1, zero, div, src, dst, dx2, omega, stream)) return rc;
+		std::swap(src, dst);
+		--left, ++launches, zero = false;
+	}
+	if (left && zero) {  // the two-launch form reads its input: give it the zeros
+		HNS_HIP(hipMemsetAsync(src, 0, sizeof(float) * 512 * (size_t)g->topo.n_leaves, st));
+		zero = false;
+	}
+	for (; left; --left, ++launches) {
+		if (int rc = launch_color_iteration(g, gd, div, src, dst, dx2, omega, st)) return rc;
+		std::swap(src, dst);
+	}
+	if (result_in_b) *result_in_b = launches & 1;
 	return launch_status("hns_dev_rbgs_iterate");
 }
 
 int hns_grid_rbgs_plan(hns_grid* g, int iterations, char* description, uint64_t description_bytes, int* launches, int* iterations_per_launch) {
 	if (int rc = check_grid(g, "hns_grid_rbgs_plan")) return rc;
 	if (iterations < 0) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_grid_rbgs_plan: negative iteration count");
-	const int opt = options().rbgs.load();
 	int k_max = 0;
-	const int lb = (iterations >= 2 && (opt == kRbgsBlock || (opt == kRbgsAuto && rbgs_auto_block(g)))) ? hns_rbgs_block_shape(g, &k_max) : 0;
+	const int lb = (iterations >= 1 && options().rbgs.load() != kRbgsColor) ? hns_rbgs_block_shape(g, &k_max) : 0;
 	char buf[256];
-	int n = iterations, k = 1;
+	int n = 0, k = 1, left = iterations;
 	if (lb) {
-		n = 0;
-		int left = iterations;
 		while (left >= 2) left -= (k_max >= 4 && left >= 4) ? 4 : 2, ++n;
-		n += left;
-		k = k_max;
-		const bool lean = hns_rbgs_block_lean(g, lb, k_max), xy = lean && (options().sor_block_lean.load() & ~4) == 0;  // (auto | xy)
-		snprintf(buf, sizeof(buf), "k_rbgs_block%s<%d,%d>: %d red+black iterations per launch on %s blocks with a %d-voxel halo, p read and written once per launch%s", xy ? "_xy" : "", lb, k_max, k_max,
-		         lb == 1 ? "one-leaf (8^3-voxel)" : "16^3-voxel", 2 * k_max,
-		         !lean ? "" : (xy ? " (XY form: rows in LDS, three workgroups per CU, the sweep threads fetch their own rows)" : " (lean form: rows in LDS, three workgroups per CU, waves sorted by parity)"));
+		if (left) --left, ++n;  // (an odd iteration left over: the same kernel, one iteration)
+		k = iterations >= 2 ? k_max : 1;
+		snprintf(buf, sizeof(buf), "k_rbgs_block%s<%d,%d>: %d red+black iterations per launch on %s blocks with a %d-voxel halo, p read and written once per launch%s", lb == 2 ? "_xy" : "", lb, k_max, k_max,
+		         lb == 1 ? "one-leaf (8^3-voxel)" : "16^3-voxel", 2 * k_max, lb == 2 ? " (rows in LDS, three workgroups per CU, the sweep threads fetch their own rows)" : "");
 	} else {
-		const int form = rbgs_form(g, opt == kRbgsBlock ? kRbgsAuto : opt);
-		const char* names[] = {"?", "k_rbgs_color: two launches per iteration, in place (the reference's decomposition)", "k_rbgs_wave: one launch = one red+black iteration, one wave per leaf",
-		                       "k_rbgs_pair: one launch = one red+black iteration, one wave per z-adjacent leaf pair", "k_rbgs_tile: one launch = one red+black iteration, 2 x 2 wave records per workgroup"};
-		snprintf(buf, sizeof(buf), "%s", names[form >= 0 && form <= 4 ? form : 0]);
-		if (form == kRbgsColor) n = 2 * iterations;
+		snprintf(buf, sizeof(buf), "k_rbgs_color: two launches per iteration, in place (the reference's decomposition)");
 	}
+	n += 2 * left;  // (what is left goes through the two-launch form)
 	if (description && description_bytes) snprintf(description, description_bytes, "%s", buf);
 	if (launches) *launches = n;
 	if (iterations_per_launch) *iterations_per_launch = k;
 	return HNS_OK;
-}
-
-// ---- the mirroring sweep of a multi-GPU rank (see k_rbgs_pair_mirror) ----
-int hns_rbgs_count_boundary_records(hns_grid* g, int n_boundary, unsigned* d_scratch, unsigned* out2, void* stream) {
-	if (int rc = check_grid(g, "hns_rbgs_count_boundary_records")) return rc;
-	if (!g->d_pairs) return fail(HNS_ERR_RUNTIME, "hns_rbgs_count_boundary_records: the grid has no wave records");
-	hipStream_t st = (hipStream_t)stream;
-	HNS_HIP(hipMemsetAsync(d_scratch, 0, 2 * sizeof(unsigned), st));
-	if (g->n_pairs) hipLaunchKernelGGL(k_count_boundary_records, dim3((unsigned)((g->n_pairs + 255) / 256)), dim3(256), 0, st, (const int*)g->d_pairs, (unsigned)g->n_pairs, n_boundary, d_scratch);
-	HNS_HIP(hipMemcpyAsync(out2, d_scratch, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-	HNS_HIP(hipStreamSynchronize(st));
-	HNS_HIP(hipMemsetAsync(d_scratch, 0, 2 * sizeof(unsigned), st));
-	return HNS_OK;
-}
-
-int hns_rbgs_mirror_sweep(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero, const hns::PhaseMirror* m, void* stream, bool backwards) {
-	if (int rc = check_grid(g, "hns_rbgs_mirror_sweep")) return rc;
-	if (!g->d_pairs || g->n_pairs == 0) return fail(HNS_ERR_RUNTIME, "hns_rbgs_mirror_sweep: the grid has no wave records");
-	// small ragged ranks: one leaf per wave, as on a single GPU (rbgs_form; the 66k-leaf plume in 8 ranges: 22 -> 17 us per sweep)
-	const int opt = options().rbgs.load();
-	if (opt == kRbgsWave || (opt == kRbgsAuto && g->d_blk && (g->n_active <= 2048 || (g->n_active <= 16384 && g->n_singles * 20 > g->n_pairs)))) {
-		if (src_is_zero) HNS_HIP(hipMemsetAsync(const_cast<float*>(src), 0, sizeof(float) * 512 * (size_t)g->topo.n_leaves, (hipStream_t)stream));  // this form reads its input
-		hipLaunchKernelGGL(k_rbgs_wave<PhaseMirror>, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, g->dev(), div, src, dst, dx2_of(dx), omega, *m);
-		return launch_status("hns_rbgs_mirror_sweep");
-	}
-	// The boundary leaves come first in the local leaf order and their waves always run at the START of the launch, next to
-	// everything else (walked backwards they were a tail of slow waves: 69 us per sweep instead of 38), so a rank's "sweep
-	// complete" flag goes up long before its sweep ends and the peers' next sweep never waits for it. `backwards` reverses
-	// only the records behind them (what "alternate" does for the single-GPU loop: the sweep starts where the last one ended).
-	const int last = backwards ? (int)g->n_pairs - 1 : -1;
-	if (src_is_zero)
-		hipLaunchKernelGGL(k_rbgs_pair_mirror<true>, dim3((unsigned)g->n_pairs), dim3(64), 0, (hipStream_t)stream, (const int*)g->d_pairs, div, src, dst, dx2_of(dx), omega, last, *m);
-	else
-		hipLaunchKernelGGL(k_rbgs_pair_mirror<false>, dim3((unsigned)g->n_pairs), dim3(64), 0, (hipStream_t)stream, (const int*)g->d_pairs, div, src, dst, dx2_of(dx), omega, last, *m);
-	return launch_status("hns_rbgs_mirror_sweep");
 }
 
 int hns_dev_time_rbgs(hns_grid* g, const float* div, float* p_a, float* p_b, float dx, float omega, int iterations, int reps, float* ms_per_launch,

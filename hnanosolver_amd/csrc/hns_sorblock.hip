@@ -23,12 +23,12 @@
 // Voxels of absent leaves load as 0 (hardware bounds check of a buffer descriptor), are never updated, and their stores
 // are dropped by the same check: "outside the domain p = 0" (Stencils.hpp:83) without a branch.
 //
-// Two forms of the kernel. The one described above (sb_body / sb_sweep: rows in registers) serves one-leaf blocks. 16^3 blocks
-// use the LEAN form (sb_body_lean / sb_sweep_lean, further down): the row state stays in LDS, where the neighbours need it
-// anyway, the thread keeps only div * dx^2; three workgroups fit a CU; LDS rows are numbered densely (no bank conflicts); p is
-// fetched and the block stored in memory order by whichever thread that makes coalesced; and only the part of the tile that
-// can reach the block in 2K sweeps is fetched and computed. DESIGN.md section 4 and profiles/r03_sorblock_notes.txt 10-12
-// have the measurements behind each of these.
+// Two kernels. The one described above (k_rbgs_block<1, K>: sb_body / sb_sweep, rows in registers) serves one-leaf blocks -- grids of up to
+// 600 leaves, which cannot fill the chip with larger ones. 16^3 blocks are swept by k_rbgs_block_xy (further down): the row state stays
+// in LDS, where the neighbours need it anyway, the thread keeps only div * dx^2; three workgroups fit a CU; the thread that sweeps a
+// row fetches it; the block is stored in memory order; and only the part of the tile that can reach the block in 2K sweeps is fetched
+// and computed. How it got there (the 16^3 rows-in-registers form, the parity-sorted "lean" form and its LDS-DMA variant, each with its
+// measurements): DESIGN_HISTORY.md, profiles/r03_sorblock_notes.txt 10-12, profiles/r05_sorblock_notes.txt.
 #include "hns_device.hpp"
 #include "hns_flags.hpp"
 
@@ -69,20 +69,11 @@ struct SbGeo {
 	// 24-voxel tiles: the row state (p of both colours) stays in LDS, where the neighbours need it anyway, and only div * dx^2 is kept
 	// in registers -- 24 instead of 48 registers of state, <= 80 in all, which with the overlapped LDS arrays below lets THREE workgroups
 	// onto a CU instead of two (16-voxel tiles are small-grid, latency-bound launches: they keep the rows in registers)
-	static constexpr bool CAN_LEAN = T == 24;
 	static_assert(H % 4 == 0 && H <= 8, "rows must start on a 16-byte piece and stay within the neighbouring leaf");
 	static_assert(NQ <= HS4 && NT <= 1024 && RIM <= CROWS, "tile too large");
 };
 
 constexpr float kInv6 = 0.166666667f;  // Kernel.cu:609
-
-// Launch-start stagger (speed only; any value of the registers read below gives the same results). Two workgroups fit a CU and the
-// dispatcher starts both at once: they then load their tiles at the same time (each at half the CU's L1 fill rate) and sweep at
-// the same time (each with half the VALU), phase after phase. One counter per CU (XCC id + the SE / SH / CU bits of HW_ID) hands the
-// first round of workgroups alternating numbers; the odd ones wait `stagger` x 1,024 cycles, about half a workgroup period, so that
-// one loads while the other sweeps: 256^3 39.2 -> 36.4 us per iteration at 8, 38.0 at 4, 38.4 at 12 (profiles/r03_sorblock_notes.txt).
-__device__ unsigned g_sb_slots[4096];
-
 
 // a thread's z-row for the length of the launch, split by colour (static indexing only: the arrays live in registers)
 template <int HALF, int C>
@@ -109,7 +100,7 @@ struct SbLds {
 
 // One colour sweep S (1-based; odd = red = colour 0, Kernel.cu:601) of the whole tile, for the rows with parity PAR of x+y.
 // i = LDS number of the row among the rows of its parity, x * HALF + (y >> 1); b = y & 1.
-template <int LB, int K, int S, bool PAR, bool MASKED, class Row>
+template <int LB, int K, int S, int NS, bool PAR, bool MASKED, class Row>
 __device__ __forceinline__ void sb_sweep(Row& r, SbLds<LB, K>& L, const int i, const int b, const int dist, const float omega) {
 	using G = SbGeo<LB, K>;
 	constexpr int H = G::H, HALF = G::HALF, HS4 = G::HS4;
@@ -156,7 +147,7 @@ __device__ __forceinline__ void sb_sweep(Row& r, SbLds<LB, K>& L, const int i, c
 			}
 			__builtin_amdgcn_sched_barrier(0);
 		}
-		if (S < 2 * K) {
+		if (S < NS) {
 #pragma unroll
 			for (int q = qlo; q < qhi; ++q) {
 				const int j = 4 * q;
@@ -165,20 +156,21 @@ __device__ __forceinline__ void sb_sweep(Row& r, SbLds<LB, K>& L, const int i, c
 			}
 		}
 	}
-	if (S < 2 * K) __syncthreads();
+	if (S < NS) __syncthreads();
 }
 
-template <int LB, int K, int S, bool PAR, bool MASKED>
+// NS colour sweeps: 2K = K iterations; K = 2 with NS = 2 is ONE iteration on the tile of two (an odd iteration left over: SbSweepsXY, which see)
+template <int LB, int K, int S, int NS, bool PAR, bool MASKED>
 struct SbSweeps {
 	template <class Row>
 	static __device__ __forceinline__ void run(Row& r, SbLds<LB, K>& L, const int i, const int b, const int dist, const float omega) {
-		sb_sweep<LB, K, S, PAR, MASKED>(r, L, i, b, dist, omega);
-		if constexpr (S < 2 * K) SbSweeps<LB, K, S + 1, PAR, MASKED>::run(r, L, i, b, dist, omega);
+		sb_sweep<LB, K, S, NS, PAR, MASKED>(r, L, i, b, dist, omega);
+		if constexpr (S < NS) SbSweeps<LB, K, S + 1, NS, PAR, MASKED>::run(r, L, i, b, dist, omega);
 	}
 };
 
 // everything one thread does, for a row with parity PAR of x+y (wave-uniform)
-template <int LB, int K, bool ZERO, bool PAR>
+template <int LB, int K, bool ZERO, bool PAR, int NS>
 __device__ __forceinline__ void sb_body(SbLds<LB, K>& L, const int t, const int* __restrict__ recs, const float* __restrict__ div, const float* __restrict__ p_in,
                                         float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega) {
 	using G = SbGeo<LB, K>;
@@ -265,9 +257,9 @@ __device__ __forceinline__ void sb_body(SbLds<LB, K>& L, const int t, const int*
 	for (int cz = 0; cz < C; ++cz) mine = mine && (r.ok[cz] != 0u || !valid);
 	const bool all_present = __syncthreads_and(mine) != 0;
 	if (all_present)
-		SbSweeps<LB, K, 1, PAR, false>::run(r, L, i, b, dist, omega);
+		SbSweeps<LB, K, 1, NS, PAR, false>::run(r, L, i, b, dist, omega);
 	else
-		SbSweeps<LB, K, 1, PAR, true>::run(r, L, i, b, dist, omega);
+		SbSweeps<LB, K, 1, NS, PAR, true>::run(r, L, i, b, dist, omega);
 	if (dist >= H) {  // the rows of the block itself
 #pragma unroll
 		for (int j = H / 4; j < NCH - H / 4; ++j) {
@@ -280,101 +272,11 @@ __device__ __forceinline__ void sb_body(SbLds<LB, K>& L, const int t, const int*
 	}
 }
 
-// LDS of the lean form. Rows are numbered DENSELY in the order of the threads that sweep them: row (x, y) of parity P, y = 1 + d + 2k with
-// d = (x + 1 + P) & 1 = (y + 1) & 1 and k = 0..HC-1, has number x * HC + k -- a wave's 64 rows are 64 consecutive numbers and a 16-byte
-// access at the 48-byte row stride is free of bank conflicts (SbLds numbers them x * HALF + (y >> 1): one unused number per plane, which
-// puts two lanes of every 16 onto the same banks -- a third of the LDS cycles of the sweeps were conflicts). The rim rows y = 0 / y = T-1,
-// one per plane and parity, follow the T * HC dense rows of a BLACK array (only the black values of a rim row are ever read: a black
-// update happens at distance >= 2 from the rim). A RED array has the planes 1 .. T-2 only and starts HC rows before its first row would
-// lie: [black 0: T*HC + T rows][red 0: (T-2)*HC rows][black 1][red 1] -- nobody may write a red value of plane 0 or T-1 or of a rim row.
-template <int LB, int K>
-struct SbLdsDense {
-	using G = SbGeo<LB, K>;
-	static constexpr int HC = G::HC, T = G::T, HS4 = G::HS4;
-	static constexpr int NB = (T * HC + T) * HS4, NR = (T - 2) * HC * HS4, ROFF = NB - HC * HS4, PSTR = NB + NR;
-	float4 a[2 * PSTR];
-	__device__ __forceinline__ float4* arr(int par, int colour) { return a + par * PSTR + (colour ? 0 : ROFF); }
-	static __device__ __forceinline__ int row(int x, int y) { return x * HC + ((y - 1 - ((y + 1) & 1)) >> 1); }  // dense number of an interior-y row
-	static __device__ __forceinline__ int rim_row(int x) { return T * HC + x; }                                // the y-rim row of plane x
-};
-
-// ---- the lean form (SbGeo::LEAN): the same sweeps with the thread's own row read from and written to its LDS entry ----
-
+// a thread's z-row in the 16^3-block (XY) form: the row's p lives in LDS, where the neighbours need it anyway; the thread keeps div * dx^2
 template <int C, int HALF>
 struct SbLeanRow {
 	float dR[HALF], dB[HALF];  // div * dx^2 of the row's red / black voxels
 	unsigned ok[C];            // per leaf cell along z: all ones if the leaf exists, else 0
-};
-
-template <int LB, int K, int S, bool PAR, bool MASKED, class Row>
-__device__ __forceinline__ void sb_sweep_lean(Row& r, SbLdsDense<LB, K>& L, const int i, const int ep, const int em, const int dist, const float omega) {
-	using G = SbGeo<LB, K>;
-	constexpr int H = G::H, HALF = G::HALF, HS4 = G::HS4, NQ = G::NQ;
-	static_assert(NQ * 4 == HALF, "colour arrays are whole 16-byte pieces");
-	constexpr bool red = (S & 1) != 0;
-	const float(&dX)[HALF] = red ? r.dR : r.dB;
-	const float4* LY = L.arr(PAR ? 0 : 1, red ? 1 : 0);           // lateral neighbours: rows of the other parity, the other colour
-	float4* LXo = L.arr(PAR ? 1 : 0, red ? 0 : 1) + i * HS4;        // this row, the colour being updated (nobody else touches it in this sweep)
-	const float4* LYo = L.arr(PAR ? 1 : 0, red ? 1 : 0) + i * HS4;  // this row, the other colour: the z neighbours
-	constexpr bool up = red ? PAR : !PAR;  // as sb_sweep
-	// Voxels closer than S to the tile's rim along z are stale at this sweep and beyond anyone's reach afterwards: they are not computed
-	// (38 instead of 48 updates per row over the four sweeps). X[j] sits at z' = 2j + (up ? 1 : 0). The LDS accesses stay whole 16-byte
-	// pieces -- pinned below, or the compiler narrows them to the elements used and the narrower accesses collide in the banks.
-	constexpr int zo = up ? 1 : 0;
-	constexpr int jlo = (S - zo + 1) / 2, jhi = (G::T - 1 - S - zo) / 2 + 1;  // updated: jlo <= j < jhi
-	constexpr int qlo = jlo / 4, qhi = (jhi + 3) / 4;
-	if (dist >= S) {
-		float Y[HALF];
-		const sb4f* LYo4 = reinterpret_cast<const sb4f*>(LYo);
-#pragma unroll
-		for (int q = 0; q < NQ; ++q) {
-			const sb4f y4 = LYo4[q];
-			Y[4 * q] = y4.x, Y[4 * q + 1] = y4.y, Y[4 * q + 2] = y4.z, Y[4 * q + 3] = y4.w;
-		}
-		const sb4f* pxp = reinterpret_cast<const sb4f*>(LY + (i + G::HC) * HS4);  // rows (x+1, y), (x-1, y): same k, the planes next door
-		const sb4f* pxm = reinterpret_cast<const sb4f*>(LY + (i - G::HC) * HS4);
-		const sb4f* pyp = reinterpret_cast<const sb4f*>(LY + ep * HS4);           // rows (x, y+1), (x, y-1): numbers from the body (a rim row at the ends of a plane)
-		const sb4f* pym = reinterpret_cast<const sb4f*>(LY + em * HS4);
-		sb4f* LXo4 = reinterpret_cast<sb4f*>(LXo);
-#pragma unroll
-		for (int q = qlo; q < qhi; ++q) {
-			sb4f x4 = LXo4[q], xp4 = pxp[q], xm4 = pxm[q], yp4 = pyp[q], ym4 = pym[q];
-			if (4 * q < jlo || 4 * q + 4 > jhi) {  // a piece only part of which is updated: keep its accesses whole
-				asm volatile("" : "+v"(x4));
-				asm volatile("" : "+v"(xp4));
-				asm volatile("" : "+v"(xm4));
-				asm volatile("" : "+v"(yp4));
-				asm volatile("" : "+v"(ym4));
-			}
-			float X[4] = {x4.x, x4.y, x4.z, x4.w};
-			const float xp[4] = {xp4.x, xp4.y, xp4.z, xp4.w}, xm[4] = {xm4.x, xm4.y, xm4.z, xm4.w}, yp[4] = {yp4.x, yp4.y, yp4.z, yp4.w}, ym[4] = {ym4.x, ym4.y, ym4.z, ym4.w};
-#pragma unroll
-			for (int e = 0; e < 4; ++e) {
-				const int j = 4 * q + e;
-				if (j < jlo || j >= jhi) continue;
-				const float below = j > 0 ? Y[j > 0 ? j - 1 : 0] : 0.0f, above = j + 1 < HALF ? Y[j + 1 < HALF ? j + 1 : 0] : 0.0f;
-				const float zm = up ? Y[j] : below, zp = up ? above : Y[j];
-				const float pGS = ((xp[e] + xm[e] + yp[e] + ym[e] + zp + zm) - dX[j]) * kInv6;  // Kernel.cu:621 (dX = div * dx^2)
-				const float cand = X[e] + omega * (pGS - X[e]);                                   // Kernel.cu:622
-				const int cz = (2 * j - H + 8) >> 3;
-				X[e] = MASKED ? __uint_as_float(__float_as_uint(cand) & r.ok[cz]) : cand;
-			}
-			sb4f o4 = sb4f{X[0], X[1], X[2], X[3]};
-			if (4 * q < jlo || 4 * q + 4 > jhi) asm volatile("" : "+v"(o4));
-			LXo4[q] = o4;
-			__builtin_amdgcn_sched_barrier(0);
-		}
-	}
-	if (S < 2 * K) __syncthreads();
-}
-
-template <int LB, int K, int S, bool PAR, bool MASKED>
-struct SbSweepsLean {
-	template <class Row>
-	static __device__ __forceinline__ void run(Row& r, SbLdsDense<LB, K>& L, const int i, const int ep, const int em, const int dist, const float omega) {
-		sb_sweep_lean<LB, K, S, PAR, MASKED>(r, L, i, ep, em, dist, omega);
-		if constexpr (S < 2 * K) SbSweepsLean<LB, K, S + 1, PAR, MASKED>::run(r, L, i, ep, em, dist, omega);
-	}
 };
 
 // 16 bytes (z = 4 * half .. 4 * half + 3 of z-row `row`) of boundary leaf `leaf` into the ghost copies the peers keep of it: the chained
@@ -415,244 +317,11 @@ __device__ __forceinline__ void chain_store_piece(const PackMirror& m, int leaf,
 	}
 }
 
-template <int LB, int K, bool ZERO, bool PAR, class M = NoMirror, bool DD = false>
-__device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, const int t, const int* __restrict__ recs, const int* __restrict__ any_absent, const float* __restrict__ div,
-                                             const float* __restrict__ p_in, float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega, const M& m = M{}) {
-	using G = SbGeo<LB, K>;
-	constexpr int H = G::H, T = G::T, C = G::C, HALF = G::HALF, NQ = G::NQ, NCH = G::NCH, HS4 = G::HS4;
-	static_assert(NCH == 2 * NQ, "two 16-byte pieces of a row in memory make one piece of each colour array");
-	const bool valid = t < G::CROWS;
-	const int xq = valid ? t / G::HC : 0;
-	const int kk = valid ? t - xq * G::HC : 0, dl = (xq + (PAR ? 1 : 0)) & 1;  // (dl = (x + 1 + PAR) & 1)
-	const int x = 1 + xq, y = valid ? 1 + dl + 2 * kk : 1;
-	const int i = x * G::HC + kk;  // the row's dense LDS number (= t + HC)
-	// the rows (x, y+1), (x, y-1) of the other parity: k + dl and k + dl - 1 in the same plane, or the plane's rim row beyond its ends
-	const int ep = (dl == 1 && kk == G::HC - 1) ? SbLdsDense<LB, K>::rim_row(x) : i + dl;
-	const int em = (dl == 0 && kk == 0) ? SbLdsDense<LB, K>::rim_row(x) : i + dl - 1;
-	const int dist = valid ? min(min(x, T - 1 - x), min(y, T - 1 - y)) : -1;
-	const int cx = (x - H + 8) >> 3, cy = (y - H + 8) >> 3;
-	const unsigned row_bytes = (unsigned)(((((x - H) & 7) << 3) | ((y - H) & 7)) * 32);
-	static_assert(LB == 2 && K == 2, "the store phase below is written for 16^3 blocks with a 4-voxel halo");
-	// (every id fetch below is UNCONDITIONAL -- lanes without a row / piece read entry 0 of the record and discard it: a conditional load is a branch with a
-	// wait for the loaded value at its end, and three of those in a row were three dependent memory round trips in front of the tile loads)
-	const int rec_word = recs[(size_t)blockIdx.x * G::REC + (t & 63)];  // the block record for the store phase: into LDS behind the tile loads' issue
-	const int* __restrict__ rec = recs + (size_t)blockIdx.x * G::REC + (LB == 1 ? 1 : 0) + (cx * C + cy) * C;
-	// The three id fetches -- the four leaf ids along z under the row this thread sweeps, those under the row (x2, y2) whose p it fetches (memory-order mapping, below)
-	// and the id under its rim piece -- are each issued as soon as their address is known and in front of everything that uses any of them (the scheduling barriers keep
-	// the order: left alone, the scheduler gathers the three behind ALL the address arithmetic, or pulls a use and its wait between them). Round 5 found them as three
-	// dependent round trips in front of the tile loads; now they are one.
-	static_assert(C == 4 && LB == 2, "the four ids along z are one aligned 16-byte piece of the record");
-	const int* brec = recs + (size_t)blockIdx.x * G::REC;
-	const int4 q4 = *reinterpret_cast<const int4*>(valid ? rec : brec);
-	__builtin_amdgcn_sched_barrier(0);
-	const int tid = t + (PAR ? G::SEC : 0);
-	const bool valid2 = tid < 2 * G::CROWS;
-	const int x2 = valid2 ? 1 + tid / G::TC : 1, y2 = valid2 ? 1 + tid - (x2 - 1) * G::TC : 1;
-	const int cx2 = (x2 - H + 8) >> 3, cy2 = (y2 - H + 8) >> 3;
-	const unsigned rb2 = (unsigned)(((((x2 - H) & 7) << 3) | ((y2 - H) & 7)) * 32);
-	const bool want2 = (DD || !ZERO) && valid2;
-	const int4 q2raw = *reinterpret_cast<const int4*>(brec + (want2 ? (cx2 * C + cy2) * C : 0));
-	__builtin_amdgcn_sched_barrier(0);
-	// Rim duty: the RIM rim rows of this parity (nobody updates them: the black values of p only, straight into LDS) as 16-byte pieces
-	// dealt over the section's threads. Side 0: x = 0, 1: x = T-1, 2: y = 0, 3: y = T-1; the m-th row of the right parity along the side.
-	// Only the pieces j = 1 .. NCH-2 are fetched: a rim row is H voxels from the block in x or y, so what it holds within H of the
-	// tile's z ends is more than H steps from every block voxel and never reaches one in 2K sweeps; those two pieces are zeroed.
-	// The piece's leaf id is fetched together with the row's own ids: one memory round trip for ids, one for data.
-	constexpr int NJ = 1, RJ = NCH - 2;
-	static_assert(G::RIM * RJ <= G::SEC && RJ == 4, "one rim piece per thread");
-	bool rim_on[NJ];
-	int rim_lds[NJ];       // float2 index of the piece in a colour array
-	unsigned rim_off[NJ];  // byte offset of the piece inside its leaf
-	int rim_id[NJ], rim_at[NJ];  // (the piece's leaf id; where in the record it stands)
-	bool rim_want[NJ];
-	int rim_zero = 0;      // float2 offset of the end piece this thread zeroes (0: none)
-	{
-		constexpr int n = 0;
-		const int q = t;
-		rim_on[n] = q < G::RIM * RJ;
-		const int mr = rim_on[n] ? q >> 2 : 0, j = 1 + (q & 3);
-		const int side = mr / G::HC, m = mr - side * G::HC;
-		const int along = 2 * m + (((side & 1) != 0) == PAR ? 2 : 1);  // sides 0, 2: along + 0 has parity PAR; sides 1, 3: along + T-1 (odd)
-		const int rx = side == 0 ? 0 : (side == 1 ? T - 1 : along), ry = side == 2 ? 0 : (side == 3 ? T - 1 : along);
-		const int rcx = (rx - H + 8) >> 3, rcy = (ry - H + 8) >> 3, rcz = (4 * j - H + 8) >> 3;
-		rim_off[n] = (unsigned)(((((rx - H) & 7) << 3) | ((ry - H) & 7)) * 32 + ((4 * j - H) & 7) * 4);
-		rim_lds[n] = (side >= 2 ? SbLdsDense<LB, K>::rim_row(rx) : SbLdsDense<LB, K>::row(rx, ry)) * HS4 * 2 + j;
-		// (a rim row off the block's own range in its other coordinate is more than H steps from every block voxel: it reads as 0)
-		const bool reach = along >= H && along < T - H;
-		rim_want[n] = !ZERO && rim_on[n] && reach;
-		rim_at[n] = rim_want[n] ? (LB == 1 ? 1 : 0) + (rcx * C + rcy) * C + rcz : 0;
-		rim_zero = j == 1 ? -1 : (j == RJ ? 1 : 0);
-	}
-#pragma unroll
-	for (int n = 0; n < NJ; ++n) rim_id[n] = brec[rim_at[n]];
-	__builtin_amdgcn_sched_barrier(0);
-	unsigned base[C];
-	SbLeanRow<C, HALF> r;
-	int ids[C];
-	ids[0] = valid ? q4.x : -1, ids[1] = valid ? q4.y : -1, ids[2] = valid ? q4.z : -1, ids[C - 1] = valid ? q4.w : -1;
-#pragma unroll
-	for (int cz = 0; cz < C; ++cz) {
-		r.ok[cz] = ids[cz] >= 0 ? 0xFFFFFFFFu : 0u;
-		base[cz] = (unsigned)ids[cz] * 2048u + row_bytes;
-	}
-	// What can reach the block in 2K sweeps lies within 2K steps of it (p) and 2K - 1 (div, used when a voxel is updated), steps counted
-	// along the axes: a row e = ex + ey steps from the block in x and y needs its middle pieces (within the block's z range) only if
-	// e <= 2K - 1 and its two end pieces (at least one step beyond it) only if e <= 2K - 2. The rest is not fetched (an offset beyond the
-	// field reads 0): 10 % of the tile's div, 3 % of its p. The end pieces are the only users of the first and last leaf cell along z.
-	static_assert(C == 4 && NCH == 6, "end pieces = cells 0 and C-1");
-	constexpr unsigned kBeyond = 0xFFFFF000u;
-	{
-		const int e = max(0, max(H - x, x - (T - 1 - H))) + max(0, max(H - y, y - (T - 1 - H)));
-		if (e > H - 2) base[0] = base[C - 1] = kBeyond;
-		if (e > H - 1) base[1] = base[2] = kBeyond;
-	}
-	const sb4i rp = sb_rsrc(p_in, field_bytes), rd = sb_rsrc(div, field_bytes), ro = sb_rsrc(p_out, field_bytes);
-	sb4f rimv[NJ], pc[NCH], dc[NCH];
-	// p is fetched by a DIFFERENT thread than the one that sweeps the row: it only has to reach the row's LDS entry, so the interior rows
-	// are dealt over all threads in the order x, y -- both parities in one wave: its lanes are 32 bytes apart in memory and touch half
-	// the cache lines the parity-sorted sweep mapping would (256^3: 29.7 -> 26.5 us per iteration measured on the loads alone).
-	{
-		const int4 q2 = want2 ? q2raw : make_int4(-1, -1, -1, -1);
-		const int e2 = max(0, max(H - x2, x2 - (T - 1 - H))) + max(0, max(H - y2, y2 - (T - 1 - H)));  // (as for div above, one step further)
-		const unsigned base2[4] = {e2 > H - 1 ? kBeyond : (unsigned)q2.x * 2048u + rb2, e2 > H ? kBeyond : (unsigned)q2.y * 2048u + rb2,
-		                           e2 > H ? kBeyond : (unsigned)q2.z * 2048u + rb2, e2 > H - 1 ? kBeyond : (unsigned)q2.w * 2048u + rb2};
-#pragma unroll
-		for (int j = 0; j < NCH; ++j) pc[j] = ZERO ? sb4f{0.0f, 0.0f, 0.0f, 0.0f} : sb_load4(rp, (int)(base2[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
-		// (the rim piece behind them: its id was the last of the three to be asked for, and loads return in order)
-		__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-		for (int n = 0; n < NJ; ++n) rimv[n] = ZERO ? sb4f{0.0f, 0.0f, 0.0f, 0.0f} : sb_load4(rp, (int)((unsigned)(rim_want[n] ? rim_id[n] : -1) * 2048u + rim_off[n]), 0, 0);  // (id -1: beyond the field, reads 0)
-		// DD (round 5; grids beyond 40k leaves, hns_rbgs_block_launch): div arrives in the memory-order mapping too -- the row (x2, y2) this
-		// thread fetches p of: lanes 32 bytes apart instead of 64, two thirds of the L1 accesses per instruction -- and WITHOUT passing through registers:
-		// buffer_load_dwordx4 ... lds drops piece j of thread tid at D[j * NT + tid] (a wave-instruction fills one contiguous KiB of LDS). The area D lies under the
-		// p arrays, which are staged only after every row owner has read its six pieces back: two more barriers in a workgroup's chain. Out of the cache the
-		// fewer accesses win (512^3 250 -> 238 us per iteration, the 66k-leaf plume 67.5 -> 65.2), in it the longer chain loses (256^3 +3 %, 128^3 +6 %): switched by size.
-		// div reaches one step less far than p. Issued BEHIND p's loads and waited for with vmcnt(0): issued in front of them with a counted wait (vmcnt(6)) it
-		// measured the same, and a wait for EVERYTHING cannot be invalidated by a load the compiler schedules differently one day.
-		if constexpr (DD) {
-			const unsigned dbase[4] = {e2 > H - 2 ? kBeyond : (unsigned)q2.x * 2048u + rb2, e2 > H - 1 ? kBeyond : (unsigned)q2.y * 2048u + rb2,
-			                           e2 > H - 1 ? kBeyond : (unsigned)q2.z * 2048u + rb2, e2 > H - 2 ? kBeyond : (unsigned)q2.w * 2048u + rb2};
-			const __amdgpu_buffer_rsrc_t rdd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(div), 0, (int)field_bytes, 0x00020000);
-			const int wave0 = __builtin_amdgcn_readfirstlane(tid & ~63);
-#pragma unroll
-			for (int j = 0; j < NCH; ++j)
-				__builtin_amdgcn_raw_ptr_buffer_load_lds(rdd, (__attribute__((address_space(3))) void*)(L.a + j * G::NT + wave0), 16,
-				                                         (int)(dbase[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0, 0);
-		}
-	}
-	if constexpr (DD) {
-		__builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the DMA pieces have landed (and whatever was issued in front of them)
-		__syncthreads();
-		const int mrow = (x - 1) * G::TC + (y - 1);  // this row's number in the fetch order (x2, y2)
-		const sb4f* D = reinterpret_cast<const sb4f*>(L.a);
-#pragma unroll
-		for (int j = 0; j < NCH; ++j) dc[j] = valid ? D[j * G::NT + mrow] : sb4f{0.0f, 0.0f, 0.0f, 0.0f};
-		__syncthreads();  // (every row owner holds its div: the area may become the p arrays)
-	} else {
-#pragma unroll
-		for (int j = 0; j < NCH; ++j) dc[j] = sb_load4(rd, (int)(base[(4 * j - H + 8) >> 3] + (unsigned)(((4 * j - H) & 7) * 4)), 0, 0);
-	}
-	if (!PAR && t < 64) s_rec[t] = rec_word;  // (visible behind the staging barrier)
-#pragma unroll
-	for (int n = 0; n < NJ; ++n) {
-		if (rim_on[n]) {
-			const sb4f v = rimv[n];
-			float2* LK = reinterpret_cast<float2*>(L.arr(PAR ? 1 : 0, 1)) + rim_lds[n];  // (black only: nobody reads a rim row's red values)
-			*LK = PAR ? make_float2(v.x, v.z) : make_float2(v.y, v.w);
-			if (rim_zero) LK[rim_zero] = make_float2(0.0f, 0.0f);
-		}
-	}
-	// the fetched row's p, split by colour (even z of a row with even x+y are red: colour = (x + y + z) & 1, Kernel.cu:599-601), into that
-	// row's LDS entry: its even z go to the red array of its parity if x+y is even, to the black one if odd
-	if (valid2) {
-		const int par2 = (x2 + y2) & 1;
-		float4* base = L.a + par2 * SbLdsDense<LB, K>::PSTR + SbLdsDense<LB, K>::row(x2, y2) * HS4;
-		constexpr int ROFF = SbLdsDense<LB, K>::ROFF;  // a parity's red array behind its black one (SbLdsDense::arr)
-		float4* LE = base + (par2 ? 0 : ROFF);
-		float4* LO = base + (par2 ? ROFF : 0);
-#pragma unroll
-		for (int q = 0; q < NQ; ++q) {
-			const sb4f u = pc[2 * q], v = pc[2 * q + 1];
-			LE[q] = make_float4(u.x, u.z, v.x, v.z);
-			LO[q] = make_float4(u.y, u.w, v.y, v.w);
-		}
-	}
-#pragma unroll
-	for (int j = 0; j < NCH; ++j) {
-		const float d0 = dc[j].x * dx2, d1 = dc[j].y * dx2, d2 = dc[j].z * dx2, d3 = dc[j].w * dx2;  // Kernel.cu:621: divVal * dx2
-		r.dR[2 * j] = PAR ? d1 : d0, r.dB[2 * j] = PAR ? d0 : d1;
-		r.dR[2 * j + 1] = PAR ? d3 : d2, r.dB[2 * j + 1] = PAR ? d2 : d3;
-	}
-	// (the barrier behind the staging; whether a leaf under the tile is absent -- voxels need masking then -- is in the block table)
-	bool all_present;
-	int meta = 0xFF00;  // (bits 8..15: the block's leaves this launch stores -- all of them on a whole grid; see k_sb_table)
-	if (any_absent) {
-		meta = __builtin_amdgcn_readfirstlane(any_absent[blockIdx.x]);
-		all_present = (meta & 1) == 0;
-		__syncthreads();
-	} else {
-		bool mine = true;
-#pragma unroll
-		for (int cz = 0; cz < C; ++cz) mine = mine && (r.ok[cz] != 0u || !valid);
-		all_present = __syncthreads_and(mine) != 0;
-	}
-	if (all_present)
-		SbSweepsLean<LB, K, 1, PAR, false>::run(r, L, i, ep, em, dist, omega);
-	else
-		SbSweepsLean<LB, K, 1, PAR, true>::run(r, L, i, ep, em, dist, omega);
-	// Store phase: the block's 16 x 16 rows x four 16-byte pieces, dealt over ALL threads in memory order (piece = ((x * 2 + z half) * 16 + y)
-	// * 2 + piece of the leaf row): a wave writes eight whole 128-byte lines. Written by the row owners instead -- lanes 64 bytes apart,
-	// half of them idle -- the stores cost as much as all the div loads (a fifth of the launch at 256^3). The values come out of the rows'
-	// LDS entries (every thread wrote its last sweep there), the leaf ids out of the record's LDS copy.
-	__syncthreads();
-	{
-		int mirror_id[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // chained rank: the block's leaves this launch stores, as scalars (-1: not stored)
-		if constexpr (!std::is_same<M, NoMirror>::value) {
-			if (meta & 2) {
-#pragma unroll
-				for (int c = 0; c < 8; ++c)
-					mirror_id[c] = (meta >> (8 + c)) & 1 ? __builtin_amdgcn_readfirstlane(s_rec[((1 + (c >> 2)) * C + 1 + ((c >> 1) & 1)) * C + 1 + (c & 1)]) : -1;
-			}
-		}
-		const float2* A = reinterpret_cast<const float2*>(L.a);
-		constexpr int PSTR = SbLdsDense<LB, K>::PSTR * 2, ROFF = SbLdsDense<LB, K>::ROFF * 2;  // in float2: parity stride, offset of a red array
-#pragma unroll
-		for (int n = 0; n < 2; ++n) {
-			const int pq = tid + n * G::NT;
-			const int jz = pq & 1, yy = (pq >> 1) & 15, czb = (pq >> 5) & 1, xx = pq >> 6;
-			const int x = xx + H, y = yy + H, j = H / 4 + 2 * czb + jz;
-			const int par = (x + y) & 1;
-			const int e = par * PSTR + SbLdsDense<LB, K>::row(x, y) * HS4 * 2 + j;
-			const float2 rr = A[e + ROFF], bb = A[e];
-			const int cell = (((xx >> 3) << 1) | (yy >> 3)) << 1 | czb;
-			const int id = (meta >> (8 + cell)) & 1 ? s_rec[((1 + (xx >> 3)) * C + 1 + (yy >> 3)) * C + 1 + czb] : -1;  // (a leaf outside the launch range is a source only)
-			sb4f v;
-			v.x = par ? bb.x : rr.x, v.y = par ? rr.x : bb.x, v.z = par ? bb.y : rr.y, v.w = par ? rr.y : bb.y;
-			sb_store4(v, ro, (int)((unsigned)id * 2048u + (unsigned)((((xx & 7) << 3) | (yy & 7)) * 32 + jz * 16)), 0, 0);
-			if constexpr (!std::is_same<M, NoMirror>::value) {
-				// a chained multi-GPU rank: what the peers read of this block's boundary leaves (the plan's reach-2K region of p) goes into
-				// their ghost copies as well, write-through. Piece n of every thread lies in the block's x half n (NT = 512 pieces per half), so the
-				// walk covers that half's four leaves; it and the walk over a leaf's table entries are wave-uniform (leaf ids in scalar registers).
-				static_assert(G::NT == 512, "piece n of a thread lies in the x half n of the block");
-				if (meta & 2) {
-#pragma unroll
-					for (int cc = 0; cc < 4; ++cc) {
-						const int c = 4 * n + cc;
-						const int lc = mirror_id[c];
-						if (lc < 0 || lc >= m.n_boundary) continue;
-						chain_store_piece(m, lc, c == cell, ((xx & 7) << 3) | (yy & 7), jz, v);
-					}
-				}
-			}
-		}
-	}
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// The XY form of the lean kernel (round 5): the thread that SWEEPS a row is the thread that FETCHES it.
-// The lean form sorts the rows by the parity of x+y into two sections of waves so that the parity is a template parameter of the sweep code; the price is that a wave's rows lie
-// 64 bytes apart in memory (every other z-row of a leaf) -- ~40 L1 accesses per load instruction -- which is why p goes through a separate fetch mapping and div either pays the 40
-// or takes the LDS-DMA detour with its two barriers. Round 5 measured that instructions are not what this kernel waits for, and that div fetched at coalesced addresses WITHOUT a
+// 16^3 blocks (round 5, "XY form"): the thread that SWEEPS a row is the thread that FETCHES it.
+// Its predecessor sorted the rows by the parity of x+y into two sections of waves so that the parity was a template parameter of the sweep code; the price was that a wave's rows lay
+// 64 bytes apart in memory (every other z-row of a leaf) -- ~40 L1 accesses per load instruction. Round 5 measured that instructions are not what this kernel waits for, and that div
+// fetched at coalesced addresses WITHOUT a
 // hand-over would be worth 5.7 % at 256^3 (r05_sorblock_notes.txt 11). So here thread t owns the interior row (x, y) = (1 + t / 22, 1 + t % 22): consecutive lanes are consecutive z-rows
 // of a leaf (32 bytes apart: ~24 accesses per instruction for p AND div), the parity is a per-lane value (pointer selects at the staging, two selects per updated voxel for the z
 // neighbours), there is no fetch mapping, no hand-over and no section. LDS: the same 50,880 bytes, the rows of BOTH parities in one (x, y) order -- a wave's 64 rows are 64 consecutive
@@ -660,8 +329,8 @@ __device__ __forceinline__ void sb_body_lean(SbLdsDense<LB, K>& L, int* s_rec, c
 //   black array: planes x = 0 .. T-1, rows y = 1 .. T-2 (entry x * TC + y - 1), then the rim rows y = 0 / y = T-1 of every plane (entry T * TC + 2 x + (y != 0));
 //   red array:   planes x = 1 .. T-2 only (entry (x - 1) * TC + y - 1 = the row's black entry - TC): nobody reads a red value of plane 0 / T-1 or of a rim row.
 // A row's colour arrays hold its red / black values in ascending z (which z are red depends on the row's parity: even z if x+y is even); the four lateral neighbours of a voxel have the
-// other colour at the same index of their rows' arrays (sb_sweep_lean). Voxels within S of the tile's z rim are stale at sweep S: the j ranges below are the UNION over both parities of
-// what the lean form computes (40 instead of 38 updates per row; a stale value is only ever read by stale voxels).
+// other colour at the same index of their rows' arrays. Voxels within S of the tile's z rim are stale at sweep S: the j ranges below are the UNION over both parities of
+// what a parity-sorted sweep would compute (40 instead of 38 updates per row; a stale value is only ever read by stale voxels).
 // ---------------------------------------------------------------------------------------------------------------
 struct SbLdsXY {
 	using G = SbGeo<2, 2>;
@@ -673,13 +342,13 @@ struct SbLdsXY {
 	static __device__ __forceinline__ int brow(int x, int y) { return x * TC + y - 1; }            // black entry of an interior-y row of any plane
 	static __device__ __forceinline__ int brim(int x, int y) { return T * TC + 2 * x + (y != 0); }  // black entry of a rim row (y = 0 or T-1)
 };
-static_assert(sizeof(SbLdsXY) == sizeof(SbLdsDense<2, 2>), "the XY form must fit three workgroups per CU like the lean form");
+static_assert(sizeof(SbLdsXY) == 50880, "the XY form must fit three workgroups per CU (160 KB of LDS)");
 
 // one colour sweep S of the row this thread owns: entry `bi` in the black array, bi - TC in the red one; par = (x + y) & 1; yp / ym = black entries of the rows (x, y +- 1)
-template <int S, bool MASKED, class Row>
+template <int S, int NS, bool MASKED, class Row>
 __device__ __forceinline__ void sb_sweep_xy(Row& r, SbLdsXY& L, const int bi, const int ypb, const int ymb, const int par, const int dist, const float omega) {
 	using G = SbGeo<2, 2>;
-	constexpr int H = G::H, HALF = G::HALF, HS4 = G::HS4, NQ = G::NQ, TC = G::TC, K = 2;
+	constexpr int H = G::H, HALF = G::HALF, HS4 = G::HS4, NQ = G::NQ, TC = G::TC;
 	constexpr bool red = (S & 1) != 0;
 	const float(&dX)[HALF] = red ? r.dR : r.dB;
 	// the colour being updated at z' = 2j + zo: zo = 1 ("up") for the red voxels of an odd row and the black voxels of an even one
@@ -706,7 +375,7 @@ __device__ __forceinline__ void sb_sweep_xy(Row& r, SbLdsXY& L, const int bi, co
 #pragma unroll
 		for (int q = qlo; q < qhi; ++q) {
 			sb4f x4 = LXo4[q], xp4 = pxp[q], xm4 = pxm[q], yp4 = pyp[q], ym4 = pym[q];
-			if (4 * q < jlo || 4 * q + 4 > jhi) {  // a piece only part of which is updated: keep its accesses whole (sb_sweep_lean)
+			if (4 * q < jlo || 4 * q + 4 > jhi) {  // a piece only part of which is updated: keep its accesses whole (partial pieces make the compiler split the LDS accesses into narrower, conflicting ones)
 				asm volatile("" : "+v"(x4));
 				asm volatile("" : "+v"(xp4));
 				asm volatile("" : "+v"(xm4));
@@ -732,21 +401,24 @@ __device__ __forceinline__ void sb_sweep_xy(Row& r, SbLdsXY& L, const int bi, co
 			__builtin_amdgcn_sched_barrier(0);
 		}
 	}
-	if (S < 2 * K) __syncthreads();
+	if (S < NS) __syncthreads();
 }
 
-template <int S, bool MASKED>
+// NS colour sweeps: 4 = two (red, black) iterations, the form every solve runs; 2 = one iteration, for an odd one left over (round 6: this replaced the one-iteration
+// kernels of rounds 1-2 -- one wave per leaf / per leaf pair -- everywhere: single-GPU leftovers, launch ranges, the chained and the packing sweeps of multi-GPU ranks).
+// The tile, its 4-voxel halo and the fetch ranges are those of two iterations either way: after two sweeps the block is further inside the stale rim than it needs to be.
+template <int S, int NS, bool MASKED>
 struct SbSweepsXY {
 	template <class Row>
 	static __device__ __forceinline__ void run(Row& r, SbLdsXY& L, const int bi, const int ypb, const int ymb, const int par, const int dist, const float omega) {
-		sb_sweep_xy<S, MASKED>(r, L, bi, ypb, ymb, par, dist, omega);
-		if constexpr (S < 4) SbSweepsXY<S + 1, MASKED>::run(r, L, bi, ypb, ymb, par, dist, omega);
+		sb_sweep_xy<S, NS, MASKED>(r, L, bi, ypb, ymb, par, dist, omega);
+		if constexpr (S < NS) SbSweepsXY<S + 1, NS, MASKED>::run(r, L, bi, ypb, ymb, par, dist, omega);
 	}
 };
 
 // M = NoMirror, or PhaseMirror for the chained sweep of a multi-GPU rank (k_rbgs_block, which see: boundary workgroups wait for the peers' previous launch and store what the peers
 // read of their boundary leaves into the peers' ghost copies as well)
-template <bool ZERO, class M = NoMirror>
+template <bool ZERO, class M = NoMirror, int NS = 4>
 __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__((SbGeo<2, 2>::NT)) void k_rbgs_block_xy(const int* __restrict__ recs, const int* __restrict__ any_absent, const float* __restrict__ div, const float* __restrict__ p_in,
                                                                                                                 float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega, const M m = M{}) {
 	using G = SbGeo<2, 2>;
@@ -764,7 +436,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__((SbGeo<2
 	const int cx = (x - H + 8) >> 3, cy = (y - H + 8) >> 3;
 	const unsigned row_bytes = (unsigned)(((((x - H) & 7) << 3) | ((y - H) & 7)) * 32);
 	const int* brec = recs + (size_t)blockIdx.x * G::REC;
-	// (id fetches: unconditional, each issued as soon as its address is known, nothing that uses one between them -- see sb_body_lean)
+	// (id fetches: unconditional, each issued as soon as its address is known, nothing that uses one between them: dependent round trips at the head of the workgroup are what this kernel waits for)
 	const int rec_word = brec[t & 63];
 	const int4 q4 = *reinterpret_cast<const int4*>(brec + (valid ? (cx * C + cy) * C : 0));
 	__builtin_amdgcn_sched_barrier(0);
@@ -849,10 +521,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__((SbGeo<2
 	}
 	__syncthreads();
 	if ((meta & 1) == 0)
-		SbSweepsXY<1, false>::run(r, L, bi, ypb, ymb, par, dist, omega);
+		SbSweepsXY<1, NS, false>::run(r, L, bi, ypb, ymb, par, dist, omega);
 	else
-		SbSweepsXY<1, true>::run(r, L, bi, ypb, ymb, par, dist, omega);
-	// store phase (sb_body_lean): the block's 16 x 16 rows x four 16-byte pieces in memory order, values out of the rows' LDS entries, leaf ids out of the record's LDS copy
+		SbSweepsXY<1, NS, true>::run(r, L, bi, ypb, ymb, par, dist, omega);
+	// store phase: the block's 16 x 16 rows x four 16-byte pieces in memory order, values out of the rows' LDS entries, leaf ids out of the record's LDS copy
 	__syncthreads();
 	{
 		int mirror_id[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // chained rank: the block's leaves this launch stores, as scalars (-1: not stored)
@@ -879,7 +551,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__((SbGeo<2
 			v.x = sp ? bb.x : rr.x, v.y = sp ? rr.x : bb.x, v.z = sp ? bb.y : rr.y, v.w = sp ? rr.y : bb.y;
 			sb_store4(v, ro, (int)((unsigned)id * 2048u + (unsigned)((((xx & 7) << 3) | (yy & 7)) * 32 + jz * 16)), 0, 0);
 			if constexpr (!std::is_same<M, NoMirror>::value) {
-				// (sb_body_lean: piece n of every thread lies in the block's x half n, the walk over that half's four leaves and over a leaf's table entries is wave-uniform)
+				// (piece n of every thread lies in the block's x half n, the walk over that half's four leaves and over a leaf's table entries is wave-uniform)
 				if (meta & 2) {
 #pragma unroll
 					for (int cc = 0; cc < 4; ++cc) {
@@ -899,49 +571,17 @@ __global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__((SbGeo<2
 // under the tile, cell (cx, cy, cz) at (cx*4 + cy)*4 + cz, -1 = absent. ZERO: p_in is known to be 0 (first launch of a solve,
 // HNanoSolver.cu:113) and is not read. The first half of the workgroup's waves takes the rows with even x+y, the second half
 // those with odd x+y; both halves meet at the same number of barriers.
-// M = NoMirror, or PhaseMirror for the chained sweep of a multi-GPU rank (hns_flags.hpp; lean form only): the workgroups of blocks that
-// hold a boundary leaf (bit 1 of the block's meta word; first in the launch order) wait for the peers' previous launch before they read a
-// ghost voxel, and store what the peers read of their boundary leaves into the peers' ghost copies too.
-template <int LB, int K, bool ZERO, bool LEAN = false, class M = NoMirror, bool DD = false>
-__global__ __attribute__((amdgpu_waves_per_eu(LEAN ? 6 : 1, 8))) __launch_bounds__((SbGeo<LB, K>::NT)) void k_rbgs_block(const int* __restrict__ recs, const int* __restrict__ any_absent, const float* __restrict__ div, const float* __restrict__ p_in,
-                                                                float* __restrict__ p_out, const unsigned field_bytes, const float dx2, const float omega, const int stagger, const M m = M{}) {
+template <int LB, int K, bool ZERO, int NS = 2 * K>
+__global__ __launch_bounds__((SbGeo<LB, K>::NT)) void k_rbgs_block(const int* __restrict__ recs, const float* __restrict__ div, const float* __restrict__ p_in, float* __restrict__ p_out,
+                                                                   const unsigned field_bytes, const float dx2, const float omega) {
 	using G = SbGeo<LB, K>;
-	__shared__ typename std::conditional<LEAN, SbLdsDense<LB, K>, SbLds<LB, K>>::type L;
-	__shared__ int s_rec[LEAN ? 64 : 1];
+	static_assert(LB == 1, "rows in registers: one-leaf blocks (16^3 blocks are swept by k_rbgs_block_xy)");
+	__shared__ SbLds<LB, K> L;
 	const int t = threadIdx.x;
-	int chain_leaf = 0x7fffffff;  // (chain_begin / chain_end take a leaf number: below n_boundary = "this workgroup waits and mirrors")
-	if constexpr (!std::is_same<M, NoMirror>::value) {
-		static_assert(LEAN, "the chained form is the lean form");
-		if (__builtin_amdgcn_readfirstlane(any_absent[blockIdx.x]) & 2) chain_leaf = 0;
-		chain_begin(m, chain_leaf);
-		__syncthreads();
-	}
-	constexpr unsigned PER_CU = LEAN ? 3u : 2u;  // workgroups of this kernel a CU holds
-	if (stagger > 0 && blockIdx.x < 256 * PER_CU) {  // (the first round: PER_CU workgroups on each of 256 CUs)
-		__shared__ unsigned s_slot;
-		if (t == 0) {
-			unsigned hw, xcc;
-			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-			s_slot = atomicAdd(g_sb_slots + (((xcc & 15u) << 8) | ((hw >> 8) & 255u)), 1u);
-		}
-		__syncthreads();
-		const int wait = (int)(s_slot % PER_CU) * stagger;
-		for (int n = 0; n < wait; ++n) __builtin_amdgcn_s_sleep(16);
-	}
-	if constexpr (LEAN) {
-		static_assert(G::CAN_LEAN, "the lean form is written for 24-voxel tiles");
-		if (__builtin_amdgcn_readfirstlane(t >= G::SEC))
-			sb_body_lean<LB, K, ZERO, true, M, DD>(L, s_rec, t - G::SEC, recs, any_absent, div, p_in, p_out, field_bytes, dx2, omega, m);
-		else
-			sb_body_lean<LB, K, ZERO, false, M, DD>(L, s_rec, t, recs, any_absent, div, p_in, p_out, field_bytes, dx2, omega, m);
-		if constexpr (!std::is_same<M, NoMirror>::value) chain_end(m, chain_leaf);
-	} else {
-		if (__builtin_amdgcn_readfirstlane(t >= G::SEC))
-			sb_body<LB, K, ZERO, true>(L, t - G::SEC, recs, div, p_in, p_out, field_bytes, dx2, omega);
-		else
-			sb_body<LB, K, ZERO, false>(L, t, recs, div, p_in, p_out, field_bytes, dx2, omega);
-	}
+	if (__builtin_amdgcn_readfirstlane(t >= G::SEC))
+		sb_body<LB, K, ZERO, true, NS>(L, t - G::SEC, recs, div, p_in, p_out, field_bytes, dx2, omega);
+	else
+		sb_body<LB, K, ZERO, false, NS>(L, t, recs, div, p_in, p_out, field_bytes, dx2, omega);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1032,7 +672,7 @@ void hns_grid_retire_blocks(hns_grid* g);
 
 int hns_grid_build_blocks(hns_grid* g) {
 	std::lock_guard<std::mutex> lock(g->build_mutex);
-	const int seg = options().sor_block_seg.load();
+	const int seg = 0;  // (blocks per XCD segment of the launch order: one chunk per XCD; segments of N blocks were measured in round 4 and bought nothing)
 	if (g->sb_built && g->sb_seg == seg && g->sb_first == g->first_active && g->sb_count == g->n_active) return HNS_OK;
 	if (g->d_sb_tab) {
 		//  a grid whose launch range or segment option changes every frame would park one table per change until it is destroyed: beyond
@@ -1050,8 +690,8 @@ int hns_grid_build_blocks(hns_grid* g) {
 	g->sb_seg = seg;
 	g->sb_first = g->first_active, g->sb_count = g->n_active;
 	const int n = (int)g->topo.n_leaves;
-	if (n == 0 || g->n_active == 0 || !g->d_tile_mem) return HNS_OK;
-	int* flag = (int*)g->d_tile_mem;  // scratch shared with hns_grid_build_tiles (same lock): flag[n] | leaders[n] | total[2]
+	if (n == 0 || g->n_active == 0 || !g->d_scratch) return HNS_OK;
+	int* flag = (int*)g->d_scratch;  // flag[n] | leaders[n] | total[2]
 	int* leaders = flag + n;
 	int* total = leaders + n;
 	GridDev gd = g->dev();
@@ -1094,7 +734,7 @@ int hns_rbgs_block_shape(hns_grid* g, int* k_max) {
 	// whole grid: blocks that hold a leaf of the range, the other leaves of the grid as sources only (hns_grid_build_blocks). The CALLER
 	// vouches that p within 2K voxels of the range, and div within 2K - 1, are current in the leaves outside it (hns_dist.hip).
 	if (g->n_active == 0 || g->topo.n_leaves > 2000000) return 0;
-	int lb = options().sor_block_lb.load(), k = options().sor_block_k.load();
+	int lb = options().sor_block_lb.load(), k = 0;
 	// by size (profiles/r03_sor_forms.txt): one-leaf blocks while the grid cannot fill the chip with 16^3 blocks, four iterations per
 	// launch while even those leave most of it idle
 	if (lb == 0) lb = g->n_active <= 600 ? 1 : 2;  // (512 leaves: 2.97 against 3.36 us per iteration; 729: 3.65 against 3.49)
@@ -1107,24 +747,15 @@ int hns_rbgs_block_shape(hns_grid* g, int* k_max) {
 	return lb;
 }
 
-// 16^3 blocks are swept by the lean form (row state in LDS, three workgroups per CU, dense LDS rows, p fetched and stored in memory
-// order); the rows-in-registers form remains for one-leaf blocks and as a cross-check. us per iteration, registers -> lean: 512 leaves
-// in 64 blocks 3.70 -> 3.37, 128^3 6.57 -> 5.62, 4k-leaf plume 8.34 -> 6.64, 256^3 35.3 -> 27.2, 512^3 304 -> 273, 66k-leaf plume
-// 84.8 -> 74.2 (profiles/r03_sorblock_notes.txt 11-12). Option "sor_block_lean" = auto | 0 | 1 | dma | xy: auto = xy (k_rbgs_block_xy, round 5: the sweep threads fetch their own rows; a further
-// 128^3 5.57 -> 5.04, 256^3 25.4 -> 22.8, 66k-leaf plume 62.0 -> 59.3, 512^3 226 -> 220); 1 = the parity-sorted form, with div through LDS-DMA beyond 40k leaves (dma: at every size).
-bool hns_rbgs_block_lean(hns_grid* g, int lb, int k) {
-	if (lb != 2 || k != 2) return false;
-	if (g->first_active != 0 || g->n_active != (uint64_t)g->topo.n_leaves) return true;  // (only the lean form knows which leaves of a block a launch range stores)
-	return options().sor_block_lean.load() != 1;  // (stored: 0 = auto, 1 = "0", 2 = "1")
-}
+// 16^3 blocks are swept by the XY form (k_rbgs_block_xy: row state in LDS, three workgroups per CU, the thread that sweeps a row fetches it), one-leaf blocks by the
+// rows-in-registers form (k_rbgs_block<1, K>). The forms this replaced -- 16^3 blocks with the rows in registers, the parity-sorted lean form and its LDS-DMA variant -- are
+// history with their measurements: DESIGN_HISTORY.md, profiles/r03_sorblock_notes.txt, r05_sorblock_notes.txt.
+bool hns_rbgs_block_lean(hns_grid*, int lb, int k) { return lb == 2 && k == 2; }
 
 // one launch: k iterations src -> dst
 int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const float* div, const float* src, float* dst, float dx2, float omega, void* stream) {
 	hipStream_t st = (hipStream_t)stream;
 	const unsigned bytes = (unsigned)((size_t)g->topo.n_leaves * 2048u);
-	// (16^3 blocks only, and only launches that need a second round of workgroups -- 512 are resident at once; at 512 blocks and below the
-	// wait is pure loss: 128^3 6.58 -> 7.26 us per iteration, while 600 blocks gain 2.5 % and 1,000 blocks 4 %. Option
-	// "sor_block_stagger" = 0 switches it off, N sets the wait)
 	// (the records' address and count as ONE snapshot: another host thread sharing the grid may be rebuilding them -- an option changed --,
 	// and a superseded table stays valid until the grid goes, but its count must be its own)
 	const int* sb_tab;
@@ -1134,39 +765,29 @@ int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const fl
 		sb_tab = (const int*)g->d_sb_tab, n_sb = g->n_sb;
 	}
 	if (lb == 2 && (!sb_tab || !n_sb)) return fail(HNS_ERR_RUNTIME, "hns_rbgs_block_launch: no block records");
-	const int so = options().sor_block_stagger.load();
-	const int stag = (lb == 2 && n_sb >= 576) ? so : 0;
-	const bool lean = hns_rbgs_block_lean(g, lb, k);
-#define SB_LAUNCH(LB_, K_, recs, nblk)                                                                                                            \
-	do {                                                                                                                                           \
-		if (src_is_zero)                                                                                                                           \
-			hipLaunchKernelGGL((k_rbgs_block<LB_, K_, true>), dim3((unsigned)(nblk)), dim3(SbGeo<LB_, K_>::NT), 0, st, (const int*)(recs), (const int*)nullptr, div, src, dst, bytes, dx2, omega, stag); \
-		else                                                                                                                                       \
-			hipLaunchKernelGGL((k_rbgs_block<LB_, K_, false>), dim3((unsigned)(nblk)), dim3(SbGeo<LB_, K_>::NT), 0, st, (const int*)(recs), (const int*)nullptr, div, src, dst, bytes, dx2, omega, stag); \
+#define SB_LAUNCH(K_)                                                                                                                                                        \
+	do {                                                                                                                                                                      \
+		if (src_is_zero)                                                                                                                                                      \
+			hipLaunchKernelGGL((k_rbgs_block<1, K_, true>), dim3((unsigned)g->n_active), dim3(SbGeo<1, K_>::NT), 0, st, (const int*)g->d_blk, div, src, dst, bytes, dx2, omega);  \
+		else                                                                                                                                                                  \
+			hipLaunchKernelGGL((k_rbgs_block<1, K_, false>), dim3((unsigned)g->n_active), dim3(SbGeo<1, K_>::NT), 0, st, (const int*)g->d_blk, div, src, dst, bytes, dx2, omega); \
 	} while (0)
-	if (lb == 1 && k == 2) SB_LAUNCH(1, 2, g->d_blk, g->n_active);
-	else if (lb == 1 && k == 4) SB_LAUNCH(1, 4, g->d_blk, g->n_active);
-	else if (lb == 2 && k == 2 && lean) {
-		const int sl = 0;  // (a launch-start stagger buys the lean form nothing: three workgroups per CU drift apart by themselves; option removed in round 4)
-		// div through LDS-DMA in the memory-order mapping where the sweep runs out of the cache (sb_body_lean, DD): 512^3 250 -> 238 us per iteration, the 66k-leaf
-		// plume 67.5 -> 65.2; at 256^3 and below the two extra barriers cost more than the accesses save (26.9 -> 27.7, 128^3 5.55 -> 5.86)
-		const bool dd = g->n_active > 40000 || options().sor_block_lean.load() == 3;  // ("sor_block_lean" = dma forces it: tests)
-		const int lean_word = options().sor_block_lean.load();  // 0 auto | 2 "1" | 3 "dma" | 4 "xy"
-		if (lean_word == 0 || lean_word == 4) {  // the XY form (the sweep threads are the fetch threads: k_rbgs_block_xy), the default at every size since round 5
-			if (src_is_zero)
-				hipLaunchKernelGGL(k_rbgs_block_xy<true>, dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega);
-			else
-				hipLaunchKernelGGL(k_rbgs_block_xy<false>, dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega);
-		} else if (dd && src_is_zero)
-			hipLaunchKernelGGL((k_rbgs_block<2, 2, true, true, NoMirror, true>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, sl);
-		else if (dd)
-			hipLaunchKernelGGL((k_rbgs_block<2, 2, false, true, NoMirror, true>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, sl);
-		else if (src_is_zero)
-			hipLaunchKernelGGL((k_rbgs_block<2, 2, true, true>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, sl);
+	if (lb == 1 && k == 2) SB_LAUNCH(2);
+	else if (lb == 1 && k == 4) SB_LAUNCH(4);
+	else if (lb == 1 && k == 1) {  // an odd iteration left over: the tile of two iterations, two colour sweeps
+		if (src_is_zero)
+			hipLaunchKernelGGL((k_rbgs_block<1, 2, true, 2>), dim3((unsigned)g->n_active), dim3(SbGeo<1, 2>::NT), 0, st, (const int*)g->d_blk, div, src, dst, bytes, dx2, omega);
 		else
-			hipLaunchKernelGGL((k_rbgs_block<2, 2, false, true>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, sl);
-	} else if (lb == 2 && k == 2) SB_LAUNCH(2, 2, sb_tab, n_sb);
-	else return fail(HNS_ERR_INVALID_ARGUMENT, "hns_rbgs_block_launch: unsupported block shape");
+			hipLaunchKernelGGL((k_rbgs_block<1, 2, false, 2>), dim3((unsigned)g->n_active), dim3(SbGeo<1, 2>::NT), 0, st, (const int*)g->d_blk, div, src, dst, bytes, dx2, omega);
+	}
+	else if (lb == 2 && (k == 2 || k == 1)) {
+#define XY_LAUNCH(ZERO_, NS_) hipLaunchKernelGGL((k_rbgs_block_xy<ZERO_, NoMirror, NS_>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, st, sb_tab, sb_tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, NoMirror{})
+		if (k == 2 && src_is_zero) XY_LAUNCH(true, 4);
+		else if (k == 2) XY_LAUNCH(false, 4);
+		else if (src_is_zero) XY_LAUNCH(true, 2);
+		else XY_LAUNCH(false, 2);
+#undef XY_LAUNCH
+	} else return fail(HNS_ERR_INVALID_ARGUMENT, "hns_rbgs_block_launch: unsupported block shape");
 #undef SB_LAUNCH
 	return HNS_OK;
 }
@@ -1174,14 +795,13 @@ int hns_rbgs_block_launch(hns_grid* g, int lb, int k, bool src_is_zero, const fl
 // is the grid's launch range swept two iterations per launch in 16^3 blocks by the XY form (the one form that can pack a rank's messages as it stores)?
 extern "C" __attribute__((visibility("hidden"))) bool hns_rbgs_block_packable(hns_grid* g) {
 	int k = 0;
-	const int lw = options().sor_block_lean.load();
-	return g && g->n_active && (lw == 0 || lw == 4) && hns_rbgs_block_shape(g, &k) == 2 && k == 2 && hns_rbgs_block_lean(g, 2, 2);
+	return g && g->n_active && hns_rbgs_block_shape(g, &k) == 2 && k == 2;
 }
 
 // The sweep of an exchanged pressure loop that packs its own messages (hns_flags.hpp: PackMirror), two iterations per launch over the grid's launch range (the rank's
 // boundary leaves, or -- round 6 -- all of its owned leaves); *done = false and nothing launched where that range is not swept in 16^3 blocks by the XY form.
 extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_block_pack_launch(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero,
-                                                                                 const hns::PackMirror* m, void* stream, bool* done) {
+                                                                                 const hns::PackMirror* m, void* stream, bool* done, int iterations) {
 	*done = false;
 	if (!hns_rbgs_block_packable(g)) return HNS_OK;
 	if (int rc = hns_grid_build_blocks(g)) return rc;  // (the records of THIS launch range under the current options: ADVICE r5 -- not whatever table a previous launch left)
@@ -1194,10 +814,13 @@ extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_block_pack_launch(
 	}
 	if (!tab || !n_sb) return HNS_OK;
 	const float dx2 = dx * dx;  // Kernel.cu:608
-	if (src_is_zero)
-		hipLaunchKernelGGL((k_rbgs_block_xy<true, PackMirror>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, *m);
-	else
-		hipLaunchKernelGGL((k_rbgs_block_xy<false, PackMirror>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, *m);
+#define XY_LAUNCH(ZERO_, NS_) hipLaunchKernelGGL((k_rbgs_block_xy<ZERO_, PackMirror, NS_>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, *m)
+	if (iterations != 1 && iterations != 2) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_rbgs_block_pack_launch: one or two iterations per launch");
+	if (iterations == 2 && src_is_zero) XY_LAUNCH(true, 4);
+	else if (iterations == 2) XY_LAUNCH(false, 4);
+	else if (src_is_zero) XY_LAUNCH(true, 2);
+	else XY_LAUNCH(false, 2);
+#undef XY_LAUNCH
 	*done = true;
 	return HNS_OK;
 }
@@ -1205,9 +828,9 @@ extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_block_pack_launch(
 // The chained sweep of a multi-GPU rank, two iterations per launch (hns_dist.hip; hns_flags.hpp): ONE launch over the rank's owned leaves
 // that waits for the peers where it reads their values and delivers its own boundary values into their ghost voxels. 16^3 blocks only.
 extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_block_mirror_launch(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero,
-                                                                                   const hns::PhaseMirror* m, void* stream) {
+                                                                                   const hns::PhaseMirror* m, void* stream, int iterations) {
 	int k = 0;
-	if (hns_rbgs_block_shape(g, &k) != 2 || !hns_rbgs_block_lean(g, 2, 2)) return fail(HNS_ERR_RUNTIME, "hns_rbgs_block_mirror_launch: this launch range is not swept in 16^3 blocks");
+	if (hns_rbgs_block_shape(g, &k) != 2 || k != 2) return fail(HNS_ERR_RUNTIME, "hns_rbgs_block_mirror_launch: this launch range is not swept in 16^3 blocks");
 	const unsigned bytes = (unsigned)((size_t)g->topo.n_leaves * 2048u);
 	const int* tab;
 	uint64_t n_sb;
@@ -1217,15 +840,13 @@ extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_block_mirror_launc
 	}
 	if (!tab || !n_sb) return fail(HNS_ERR_RUNTIME, "hns_rbgs_block_mirror_launch: no block records");
 	const float dx2 = dx * dx;  // Kernel.cu:608
-	const bool xy = options().sor_block_lean.load() == 0 || options().sor_block_lean.load() == 4;  // (auto | xy; "1" keeps the parity-sorted lean form)
-	if (xy && src_is_zero)
-		hipLaunchKernelGGL((k_rbgs_block_xy<true, PhaseMirror>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, *m);
-	else if (xy)
-		hipLaunchKernelGGL((k_rbgs_block_xy<false, PhaseMirror>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, *m);
-	else if (src_is_zero)
-		hipLaunchKernelGGL((k_rbgs_block<2, 2, true, true, PhaseMirror>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, 0, *m);
-	else
-		hipLaunchKernelGGL((k_rbgs_block<2, 2, false, true, PhaseMirror>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, 0, *m);
+#define XY_LAUNCH(ZERO_, NS_) hipLaunchKernelGGL((k_rbgs_block_xy<ZERO_, PhaseMirror, NS_>), dim3((unsigned)n_sb), dim3(SbGeo<2, 2>::NT), 0, (hipStream_t)stream, tab, tab + (size_t)n_sb * 64, div, src, dst, bytes, dx2, omega, *m)
+	if (iterations != 1 && iterations != 2) return fail(HNS_ERR_INVALID_ARGUMENT, "hns_rbgs_block_mirror_launch: one or two iterations per launch");
+	if (iterations == 2 && src_is_zero) XY_LAUNCH(true, 4);
+	else if (iterations == 2) XY_LAUNCH(false, 4);
+	else if (src_is_zero) XY_LAUNCH(true, 2);
+	else XY_LAUNCH(false, 2);
+#undef XY_LAUNCH
 	return HNS_OK;
 }
 

@@ -132,38 +132,25 @@ struct OptionDesc {
 	std::atomic<int> Options::*field;
 	const char* const* words;  // value words, index = stored value; nullptr: a non-negative integer
 };
-const char* const kWordsRbgs[] = {"auto", "color", "wave", "pair", "tile", "block", nullptr};
+const char* const kWordsRbgs[] = {"auto", "color", nullptr};
 const char* const kWordsAdvect[] = {"auto", "generic", nullptr};
 const char* const kWordsStencil[] = {"auto", "block", nullptr};
-const char* const kWordsSchedule[] = {"auto", "linear", "chunk", nullptr};
+const char* const kWordsSchedule[] = {"auto", "linear", nullptr};
 const char* const kWordsBool[] = {"0", "1", nullptr};
 const char* const kWordsMirror[] = {"0", "1", "guarded", nullptr};
-const char* const kWordsLean[] = {"auto", "0", "1", "dma", "xy", nullptr};
 const char* const kWordsDivergence[] = {"auto", "row", "coalesced", nullptr};
 const OptionDesc kOptions[] = {
     {"rbgs", &Options::rbgs, kWordsRbgs},
     {"advect", &Options::advect_generic, kWordsAdvect},
     {"stencil", &Options::stencil_block, kWordsStencil},
     {"schedule", &Options::schedule, kWordsSchedule},
-    {"alternate", &Options::alternate, kWordsBool},
-    {"rev", &Options::rev, kWordsBool},
     {"cook_cache", &Options::cook_cache, kWordsBool},
     {"cook_pipeline", &Options::cook_pipeline, kWordsBool},
+    {"divergence", &Options::divergence_form, kWordsDivergence},
+    {"fuse", &Options::fuse_pointwise, kWordsBool},
     {"sor_block_lb", &Options::sor_block_lb, nullptr},
-    {"sor_block_k", &Options::sor_block_k, nullptr},
-    {"sor_block_seg", &Options::sor_block_seg, nullptr},
-    {"sor_block_lean", &Options::sor_block_lean, kWordsLean},
-    {"sor_block_stagger", &Options::sor_block_stagger, nullptr},
-    {"schedule_segment", &Options::schedule_segment, nullptr},
     {"dist_wire_us", &Options::dist_wire_us, nullptr},
     {"dist_mirror", &Options::dist_mirror, kWordsMirror},
-    {"divergence", &Options::divergence_form, kWordsDivergence},
-    {"dist_spread", &Options::dist_spread, kWordsBool},
-    {"dist_block", &Options::dist_block, kWordsBool},
-    {"dist_pack", &Options::dist_pack, kWordsBool},
-    {"dist_chain", &Options::dist_chain, kWordsBool},
-    {"fuse", &Options::fuse_pointwise, kWordsBool},
-    {"dist_pipeline", &Options::dist_pipeline, kWordsBool},
     {"dist_unsplit", &Options::dist_unsplit, kWordsBool},
 };
 const Options kDefaults;

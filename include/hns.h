@@ -58,45 +58,31 @@ int hns_device_count(void); /* 0 when no HIP device is visible; never initialise
  * allocations; the device is idle when memory enters it) so that the next cook, typically on a slightly different
  * topology, does not pay hipMalloc/hipFree again; this returns it to the driver. */
 int hns_trim_memory(void);
-/* Alternative kernel forms and data-movement strategies, kept for A/B measurement and as cross-checks of the default ones
- * (all of them produce the same bits; tests/test_kernel_variants_gpu.py). Process-wide, read by every entry point when it
- * is called. value = NULL restores the default. Names and values:
- *   "rbgs"          auto | color (two launches per iteration) | wave (one wave per leaf) | pair (one wave per z-adjacent leaf
- *                   pair) | tile (y / z neighbouring pairs share a workgroup and their faces) | block (temporally blocked: several
- *                   iterations per launch on a block of leaves with a halo, hns_sorblock.hip). auto: by grid size
- *   "sor_block_lb"  0 = by size | 1 | 2: block edge of the temporally blocked form, in leaves
- *   "sor_block_k"   0 = by shape | 2 | 4: its iterations per launch (4: one-leaf blocks only)
- *   "sor_block_lean" auto | 0 | 1 | dma | xy: 16^3-voxel blocks with the rows' p kept in LDS and three workgroups per CU (1, dma, xy) or in registers and two (0).
- *                   xy (round 5, what auto takes at every size): the thread that sweeps a row fetches it -- rows owned in (x, y) order, a wave's lanes 32 bytes apart
- *                   in memory for p AND div, the parity of x+y a per-lane value. 1: waves sorted by that parity (a template parameter of the sweep code), p through a
- *                   separate fetch mapping; dma = 1 with div fetched in memory order by LDS-DMA and handed to the row owners through LDS (what 1 takes beyond 40k
- *                   leaves). 0, 1 and dma are cross-checks now.
- *   "sor_block_seg" N: its blocks per XCD segment of the launch order (0: one chunk per XCD; read when the block table is built)
- *   "sor_block_stagger" N: its launch-start stagger between the two workgroups of a CU, x 1,024 cycles (default 8; 0 = off)
+/* Alternative kernel forms and data-movement strategies, kept as cross-checks of the default ones and for A/B measurement (all of them produce the same bits:
+ * tests/test_kernel_variants_gpu.py). Process-wide, read by every entry point when it is called. value = NULL restores the default. Twelve names (round 6; the
+ * twenty-four of round 5 -- five more SOR forms among them -- are history: DESIGN_HISTORY.md, profiles/micro/exp/):
+ *   "rbgs"          auto | color. auto: temporally blocked red-black SOR (hns_sorblock.hip: two iterations per launch on 16^3-voxel blocks, two or four on one-leaf
+ *                   blocks for grids of up to 600 leaves). color: the reference's own decomposition, two launches per iteration in place -- the independent cross-check
+ *   "sor_block_lb"  0 = by size | 1 | 2: block edge of the temporally blocked form in leaves, whatever the size of the grid (how the tests reach both kernels on every leaf set)
  *   "advect"        auto | generic (64-bit addressed advection kernels)
  *   "stencil"       auto | block (512-thread divergence and gradient kernels)
- *   "schedule"      auto | linear | chunk (workgroup -> leaf order; takes effect when a grid's launch tables are next built)
- *   "schedule_segment" N leaves per XCD segment of the launch order under "schedule" = auto (0 = by grid size)
- *   "alternate"     1 | 0 (odd SOR sweeps walk the wave records backwards)
- *   "rev"           1 | 0 (divergence and advect_scalars walk the leaves backwards)
- *   "cook_cache"    1 | 0 (operator calls keep their device buffers with the grid)
- *   "cook_pipeline" 1 | 0 (hns_compute_sim overlaps its transfers with the substep)
+ *   "divergence"    auto | row | coalesced: the divergence kernel fetches its own leaf row by row, or in memory order with a hand-over through LDS (auto: the latter
+ *                   from 16,384 leaves)
+ *   "schedule"      auto | linear (workgroup -> leaf order: one chunk of the leaf list per XCD, 128-leaf segments beyond 40,000 leaves | plain leaf order; takes
+ *                   effect when a grid's launch tables are next built)
  *   "fuse"          1 | 0 (hns_sim_substep / hns_compute_sim without a collision field: divergence + combustion_oxygen + temperature_buoyancy as ONE launch that leaves
  *                   {fuel, waste, temperature, flame} as one 16-byte element per voxel, which advect_scalars then gathers its taps from; 0 = the reference's three
- *                   launches over five float arrays. Same bits)
- *   "dist_wire_us"  N: the loopback transport of hns_dist holds every exchange N microseconds (emulated wire time)
- *   "dist_chain"    1 | 0: with dist_mirror, every kernel of the substep of such a rank delivers its own halo (no exchanges at all
- *                   after the first substep); 0 = only the SOR sweeps do (read when the ranks connect; all ranks must agree)
- *   "divergence"    auto | row | coalesced: the divergence kernel fetches its own leaf row by row, or in memory order with a hand-over through
- *                   LDS (auto: the latter from 16,384 leaves)
- *   "dist_block"    1 | 0: a rank with sweeps_per_exchange >= 2 sweeps its boundary and interior launch ranges with the temporally
- *                   blocked SOR form, two iterations per launch, ghost leaves as tile sources (0 = one iteration per launch)
- *   "dist_pack"     1 | 0: that boundary sweep (exchanged pressure loop, sweeps_per_exchange = 2) writes the voxels its peers read straight into their messages: no pack launch per exchange
- *   "dist_spread"   1 | 0: hns_dist_create with sweeps_per_exchange = 1 deals the boundary leaves of the owned launch range out
- *                   to all XCDs first
- *   "dist_mirror"   1 | 0 | guarded: with sweeps_per_exchange = 1 over the ipc or local transport the SOR sweep writes its boundary rows
- *                   into the peers' ghost voxels itself (read when the ranks connect; all ranks must agree); guarded = one wave waits
- *                   for the peers in front of every sweep instead of the boundary waves inside it (ranks sharing one GPU) */
+ *                   launches over five float arrays)
+ *   "cook_cache"    1 | 0 (operator calls keep their device buffers with the grid)
+ *   "cook_pipeline" 1 | 0 (hns_compute_sim overlaps its transfers with the substep)
+ *   "dist_mirror"   1 | 0 | guarded: over the ipc or local transport a rank whose owned range is swept in 16^3 blocks, created with sweeps_per_exchange = 2, runs the
+ *                   CHAINED substep -- every kernel stores the voxels its peers read into their ghost voxels itself, no exchanges (read when the ranks connect; all
+ *                   ranks must agree). 0 = the exchanged substep, which is what RCCL ranks run. guarded = one wave waits for the peers in front of every chained launch
+ *                   instead of the boundary workgroups inside it (ranks sharing one GPU)
+ *   "dist_unsplit"  1 | 0: a rank of the exchanged substep with up to 16,384 owned leaves runs the sweeps of its pressure loop, its divergence and its gradient subtraction
+ *                   as ONE launch over all owned leaves with pack / transfer / unpack behind it on the compute stream; 0 = boundary leaves on a communication stream beside
+ *                   the interior launch at every size (what larger ranks always do)
+ *   "dist_wire_us"  N: the loopback transport of hns_dist holds every exchange N microseconds (emulated wire time) */
 int hns_set_option(const char* name, const char* value);
 const char* hns_get_option(const char* name); /* current value as a word; NULL for an unknown name */
 
@@ -150,13 +136,8 @@ int hns_grid_release_cache(hns_grid*);
  * so NanoVDB accessors return offset(ijk) = hns_grid_offsets(ijk). *size_out receives the byte size; pass buffer = NULL
  * to query it. `buffer` must be 32-byte aligned host memory. Works on HOST_ONLY grids. */
 int hns_grid_export_nanovdb(const hns_grid*, void* buffer, uint64_t capacity, uint64_t* size_out);
-/* Copies of the device-built launch tables (inspection / tests; any argument may be NULL): sched = n_active leaf ids in
- * workgroup order; wave_records = n_waves x 56 int32 {leaf0, nbr27[27], leaf1 or -1, nbr27[27]} read by the SOR kernel. */
-int hns_grid_launch_tables(const hns_grid*, int32_t* sched, int32_t* wave_records, uint64_t* n_waves, uint64_t* n_lone);
-/* The blocked SOR kernel's groups: n_groups x (tile_y * tile_z) wave-record indices (slot a * tile_z + c: record whose first
- * leaf has (y/8) mod tile_y = a, (z/16) mod tile_z = c, all in one aligned window) and the n_rest records outside complete
- * groups, swept by the one-wave kernel. Any argument may be NULL. */
-int hns_grid_tile_tables(const hns_grid*, int32_t* groups, int32_t* rest, uint64_t* n_groups, uint64_t* n_rest, int* tile_y, int* tile_z);
+/* Copy of the device-built launch order (inspection / tests): sched = n_active leaf ids in workgroup order. */
+int hns_grid_launch_tables(const hns_grid*, int32_t* sched);
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Either side of the path, without OpenVDB (host code; PARITY UNPINNED: OpenVDB is absent from the build image).   */
@@ -284,7 +265,7 @@ int hns_dev_divergence(hns_grid*, const float* vel3, float* div, float inv_dx, v
 int hns_dev_rbgs_color(hns_grid*, const float* div, float* p, float dx, float omega, int color, void* stream);
 /* `iterations` full (red, black) iterations, starting from p_a and ping-ponging p_a -> p_b -> p_a ... once per LAUNCH.
  * Bit-identical to 2*iterations calls of hns_dev_rbgs_color. How many iterations a launch holds depends on the form the
- * library picks for this grid (hns_grid_rbgs_plan: the temporally blocked form does 2 or 4 per launch, the others 1), so
+ * library picks for this grid (hns_grid_rbgs_plan: the temporally blocked form does 2 or 4 per launch, 1 for an odd one left over; "rbgs" = color: two launches per iteration), so
  * WHICH BUFFER HOLDS THE RESULT IS NOT A FUNCTION OF `iterations`: *result_in_b is 1 when it is p_b, 0 when it is p_a
  * (e.g. blocked form: iterations = 2 -> p_b, 4 -> p_b or p_a, 6 -> p_b or p_a). A caller that wants the result must pass
  * result_in_b and read it (NULL is accepted from callers that only time the solve). The other buffer holds an intermediate
@@ -342,7 +323,9 @@ typedef struct {
 	uint64_t messages_sent, exchanges; /* point-to-point messages / exchange rounds of the last substep              */
 	uint64_t halo_peers; /* peers this rank exchanges div / p / reach-1 halo voxels with (slab partition: the rank before and the rank behind it);
 	                        `peers` also counts ranks it only shares the element-0 mirror of the caller's leaf 0 with (its owner: every rank) */
-	uint64_t packed_exchanges; /* exchanges of the last substep whose messages the boundary sweep wrote itself (no pack launch; option "dist_pack") */
+	uint64_t packed_exchanges; /* exchanges of the last substep whose messages the sweep wrote itself as it stored (no pack launch) */
+	uint64_t chained;          /* 1 once connected if this rank runs the CHAINED substep (ipc / local transports, 16^3-block ranks, sweeps_per_exchange = 2: every kernel stores
+	                              its boundary values into the peers' ghost voxels itself, no exchanges); 0 = the exchanged substep */
 } hns_dist_stats;
 
 /* sweeps_per_exchange (1..4, 0 = default 4): the pressure loop refreshes the ghosts of p after every k-th fused sweep and

@@ -22,3 +22,7 @@ done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o "$here/libhns_$name.so" $objs -ldl
 rm -rf "$tmp"; echo "$here/libhns_$name.so"
+#     r06_removed_sor_forms_and_tables.patch: NOT an experiment but the record of what round 6 took out of the product (VERDICT r5 task 4): the one-iteration SOR kernels of rounds
+#       1-2 (one wave per leaf, per z-adjacent leaf pair, the 2 x 2 tile form, the mirroring pair form), the 16^3 rows-in-registers / parity-sorted "lean" / LDS-DMA forms of the blocked
+#       kernel, their launch-start stagger, and the wave-record / tile-group builders of hns_gridbuild.hip. A reverse diff against commit 2e52202: `patch -p1` over that commit's
+#       csrc/ restores them (hns_dist.hip, hns_internal.hpp, hns_topology.cpp of that commit are what call them).

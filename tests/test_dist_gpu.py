@@ -62,20 +62,19 @@ def scattered_leaves():
 
 
 @pytest.mark.parametrize("name,world,k", [("dense32", 2, 4), ("plume", 3, 2), ("scattered", 5, 1), ("plume", 8, 3), ("dense32", 4, 0), ("dense32", 2, 1),
-                                          ("plume", 8, 1), ("scattered", 3, -1), ("dense32", 4, 1), ("plume", 3, -2)])
+                                          ("plume", 8, 1), ("scattered", 3, -1), ("dense32", 4, 1)])
 def test_local_ranks_match_single_grid(name, world, k):
-    """k = 1: the chained substep -- every kernel one launch over the owned leaves that writes its boundary values into the
-    peers' ghost voxels itself; k = -1: the same plan with that switched off (option dist_mirror = 0: exchanged every sweep);
-    k = -2: only the SOR sweeps deliver their own halo (dist_chain = 0), the other kernels exchange."""
+    """Ranks of a few hundred leaves (one-leaf SOR blocks): the exchanged substep at every sweeps_per_exchange (1: a refresh of p behind every iteration); k = -1: the same with
+    option dist_mirror = 0 spelled out. (Rounds 2-5 chained such ranks at k = 1 through a mirroring one-iteration kernel; the chained substep is that of 16^3-block ranks now:
+    test_chained_ranks_two_iterations_per_launch.)"""
     import hnanosolver_amd as H
 
-    if k in (-1, -2):
-        opt = "dist_mirror" if k == -1 else "dist_chain"
-        H.set_option(opt, "0")
+    if k == -1:
+        H.set_option("dist_mirror", "0")
         try:
             return _local_ranks_match_single_grid(name, world, 1)
         finally:
-            H.set_option(opt, "1")
+            H.set_option("dist_mirror", None)
     return _local_ranks_match_single_grid(name, world, k)
 
 
@@ -99,25 +98,17 @@ def _local_ranks_match_single_grid(name, world, k, iters=7):
     assert all(sum(i["bytes_sent"].values()) > 0 for i in info if i["peers"])
 
 
-@pytest.mark.parametrize("name,world,k,block", [("plume", 3, 2, 0), ("plume", 5, 2, 1), ("scattered", 5, 2, 1), ("scattered", 3, 4, 1), ("dense32", 2, 2, 1), ("plume", 8, 3, 0)])
-def test_exchanged_ranks_with_and_without_blocked_range_sweeps(name, world, k, block):
+@pytest.mark.parametrize("name,world,k", [("plume", 5, 2), ("scattered", 5, 2), ("scattered", 3, 4), ("dense32", 2, 2)])
+def test_exchanged_ranks_with_blocked_range_sweeps(name, world, k):
     """Round 4: with sweeps_per_exchange >= 2 a rank's boundary and interior launch ranges take the last two iterations in front of
-    every exchange in ONE temporally blocked launch each (ghost leaves = tile sources; k = 2: no ghost leaf is ever swept). Option
-    dist_block = 0 is the round-3 loop (one iteration per launch on the ranges). Both must equal the single grid bit for bit."""
-    import hnanosolver_amd as H
-
-    H.set_option("dist_block", str(block))
-    try:
-        _local_ranks_match_single_grid(name, world, k)
-    finally:
-        H.set_option("dist_block", None)
+    every exchange in ONE temporally blocked launch each (ghost leaves = tile sources; k = 2: no ghost leaf is ever swept). Equal to the single grid bit for bit."""
+    _local_ranks_match_single_grid(name, world, k)
 
 
-@pytest.mark.parametrize("pack", [1, 0])
-def test_exchanged_blocked_boundary_sweep_packs_its_own_messages(pack):
+def test_exchanged_blocked_boundary_sweep_packs_its_own_messages():
     """Round 5: on the exchanged path (option dist_mirror = 0 over the local transport = what RCCL ranks run) with sweeps_per_exchange = 2 and a boundary
-    range of more than 600 leaves, the boundary sweep of the XY form writes the voxels its peers read straight into their messages (PackMirror) and the
-    pack launch is skipped; dist_pack = 0 keeps the pack launch. Either way the owned voxels equal the single grid bit for bit."""
+    range of more than 600 leaves, the boundary sweep of the 16^3 kernel writes the voxels its peers read straight into their messages (PackMirror) and the
+    pack launch is skipped. The owned voxels equal the single grid bit for bit."""
     import hnanosolver_amd as H
 
     R, world, iters = 208, 2, 6
@@ -125,37 +116,23 @@ def test_exchanged_blocked_boundary_sweep_packs_its_own_messages(pack):
     names = ["density"]
     _, want = single_grid(origins, R, names, iters, 1)
     H.set_option("dist_mirror", "0")
-    H.set_option("dist_pack", str(pack))
     try:
         ranks, b = run_local(origins, R, world, 2, names, iters, 1)
         check(ranks, b, want, names)
         info = [d.info() for d in ranks]
     finally:
         H.set_option("dist_mirror", None)
-        H.set_option("dist_pack", None)
     assert all(i["boundary_leaves"] > 600 for i in info), info
-    # three exchanges of p per substep (6 iterations, two per exchange), every one packed by the boundary sweep -- or none
-    assert all(i["packed_exchanges"] == (iters // 2 if pack else 0) for i in info), [(i["packed_exchanges"], i["exchanges"]) for i in info]
-
-
-def test_chained_blocked_sweep_does_not_depend_on_the_launch_order_option():
-    """dist_spread = 0 (boundary leaves / blocks not dealt out to all XCDs first) changes the launch order only: which blocks wait
-    for the peers and mirror their boundary leaves is a property of the plan."""
-    import hnanosolver_amd as H
-
-    H.set_option("dist_spread", "0")
-    try:
-        _local_ranks_match_single_grid("dense64", 3, 2, 6)
-    finally:
-        H.set_option("dist_spread", None)
+    # three exchanges of p per substep (6 iterations, two per exchange), every one packed by the boundary sweep
+    assert all(i["packed_exchanges"] == iters // 2 for i in info), [(i["packed_exchanges"], i["exchanges"]) for i in info]
 
 
 @pytest.mark.parametrize("name,world,iters", [("dense64", 2, 7), ("dense64", 5, 6), ("plume16", 3, 7), ("scattered_big", 4, 9), ("scattered_big", 2, 2)])
 def test_chained_ranks_two_iterations_per_launch(name, world, iters):
     """Round 4: sweeps_per_exchange = 2 over the local / ipc transport with more than 600 leaves per rank = the chained substep whose
     pressure loop is the temporally blocked kernel, two iterations per launch, boundary blocks waiting for the peers' previous launch
-    and writing the reach-4 region of p into the peers' ghost voxels themselves (k_rbgs_block<2, 2, ., true, PhaseMirror>); an odd
-    iteration left over goes through the one-iteration mirror sweep. Bit-identical to the single grid."""
+    and writing the reach-4 region of p into the peers' ghost voxels themselves (k_rbgs_block_xy<., PhaseMirror>); an odd
+    iteration left over is one more chained launch of the same kernel with two colour sweeps instead of four. Bit-identical to the single grid."""
     _local_ranks_match_single_grid(name, world, 2, iters)
 
 
@@ -164,8 +141,8 @@ def test_plume1024_in_8_ranges_matches_single_grid(k):
     """BASELINE.json configs[4]: the 1024^3-extent sparse plume (65,944 leaves) as the 8-GPU decomposition -- 8 contiguous
     leaf ranges, each with its ghost layer, boundary-first launch ranges and voxel-granular halo messages -- emulated on one
     device, 50 iterations, against the single-grid run of the same substep. k = 0: the exchanged pressure loop (refresh every
-    4th sweep); k = 1: the loop whose sweep kernel writes its boundary rows into the peers' ghost voxels itself; k = 2 (round 4):
-    the same with the temporally blocked kernel, two iterations per chained launch."""
+    4th sweep); k = 1: exchanged behind every iteration (one-iteration launches of the 16^3 kernel); k = 2 (round 4): the chained
+    substep with the temporally blocked kernel, two iterations per chained launch, no exchanges."""
     origins, R = fields.config_leaves("plume1024")
     names, iters = ["density"], 50
     _, want = single_grid(origins, R, names, iters, 1)
@@ -174,12 +151,16 @@ def test_plume1024_in_8_ranges_matches_single_grid(k):
     info = [d.info() for d in ranks]
     assert max(i["peers"] for i in info) <= 7 and min(i["boundary_leaves"] for i in info) > 0
     for i in info:
+        assert i["chained"] == (1 if k == 2 else 0)
         if k == 0:  # payload accounting: the pressure loop dominates; with k = 4 that is 12 refreshes of depth 8 plus the final depth-1 one
             assert i["exchanges"] == 1 + 1 + 1 + 13 + 1 + 1
             assert i["bytes_sent"]["p"] == 12 * 4 * i["region_voxels_sent"]["p"]
-        else:  # no exchange in the pressure loop: 50 sweeps each mirror the reach-2 region (k = 2: 25 blocked launches, the reach-4 region)
+        elif k == 1:  # 49 refreshes of depth 2 plus the final depth-1 one
+            assert i["exchanges"] == 1 + 1 + 1 + 50 + 1 + 1
+            assert i["bytes_sent"]["p"] == 49 * 4 * i["region_voxels_sent"]["p"]
+        else:  # no exchange in the pressure loop: 25 blocked launches each mirror the reach-4 region
             assert i["exchanges"] == 1  # the advection inputs of the first substep; every kernel after that delivers its own halo
-            assert i["bytes_sent"]["p"] == (50 // k) * 4 * i["region_voxels_sent"]["p"]
+            assert i["bytes_sent"]["p"] == 25 * 4 * i["region_voxels_sent"]["p"]
 
 
 def test_new_fields_between_substeps_and_many_substeps():
@@ -317,7 +298,7 @@ def _run_processes(world, case, k, iters, substeps, tmp_path, timeout=420):
                                                 # round 6, ranks of 2,048 / 1,365 leaves on the EXCHANGED path (dist_mirror = 0: what RCCL ranks run): the pressure loop as one launch over all owned
                                                 # leaves that packs its own messages, transfer and unpack behind it on the compute stream; divergence and gradient in line too; and the split form
                                                 ("128@dist_mirror=0", 2, 2, 9), ("128@dist_mirror=0", 2, 0, 10), ("128@dist_mirror=0", 3, 2, 7), ("128@dist_mirror=0@dist_unsplit=0", 2, 2, 9),
-                                                ("128@dist_mirror=0@dist_unsplit=0@dist_pipeline=0", 2, 0, 10)])
+                                                ("128@dist_mirror=0@dist_unsplit=0", 3, 0, 10)])
 def test_one_process_per_rank_over_mapped_peer_memory(case, world, k, iters, tmp_path):
     """The multi-process path for real: `world` PROCESSES (here sharing the one GPU), each a rank with its own streams, the
     halos put into the peer's memory through hipIpc mappings and the ranks meeting through device-side flags while their
@@ -336,7 +317,7 @@ def test_one_process_per_rank_over_mapped_peer_memory(case, world, k, iters, tmp
         assert np.array_equal(g["vel"], HD.take_leaves(want["vel"], ids)), f"rank {r} velocity"
         for n in names:
             assert np.array_equal(g[n], HD.take_leaves(want[n], ids)), f"rank {r} {n}"
-        assert int(g["messages"]) > 0 or k == 1  # (k = 1: after the first substep every kernel delivers its own halo, no messages)
+        assert int(g["messages"]) > 0
 
 
 @pytest.mark.parametrize("extra", [[], ["--config", "plume", "--partition"]])
@@ -364,11 +345,14 @@ def test_bench_py_as_two_processes_sharing_the_gpu(extra, tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["value"] > 0 and j["unit"] == "substeps/s"
     assert j["scaling"] == ("strong" if extra else "weak")
-    assert "verified bit for bit" in j["config"]["parallelism"], j["config"]["parallelism"]
+    if extra:  # ranks of ~2,000 leaves: the chained one-sided substep, checked against the exchanged one in place
+        assert "verified bit for bit" in j["config"]["parallelism"], j["config"]["parallelism"]
+    else:  # ranks of 256 leaves (one-leaf SOR blocks) run the exchanged substep over either transport: `auto` says so and stays on the reference transport
+        assert "one-sided transport not used" in j["config"]["parallelism"] and "600 leaves and fewer" in j["config"]["parallelism"], j["config"]["parallelism"]
     assert "bit-identical to the single-GPU run of the whole domain" in j["config"]["verified"], j["config"]["verified"]  # what was timed was checked against one GPU first
     assert "bit-equal to their owners' values" in j["config"]["ghosts"], j["config"]["ghosts"]  # and after the timed loop its ghost voxels were compared with their owners
-    # (the chained one-sided substep: k = 1, or -- ranks of more than 600 leaves -- k = 2 with the temporally blocked sweep)
-    assert j["config"]["halo"]["sweeps_per_exchange"] == (2 if extra else 1) and j["config"]["halo"]["bytes_sent"]["p"] > 0
+    # (the chained one-sided substep: k = 2 with the temporally blocked sweep; the exchanged one at the library's default, 4)
+    assert j["config"]["halo"]["sweeps_per_exchange"] == (2 if extra else 4) and j["config"]["halo"]["bytes_sent"]["p"] > 0
 
 
 def test_bench_py_launches_its_own_ranks():

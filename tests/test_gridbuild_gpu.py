@@ -37,24 +37,6 @@ def expected_sched(n):
     return (x * base + np.minimum(x, rem) + i).astype(np.int32)
 
 
-def expected_waves(nbr, n_active, sched):
-    """z-run parity rule: a leaf an even number of steps above the bottom of its z-run heads a wave and takes its +z
-    neighbour as partner; waves are listed in schedule order of their head."""
-    recs, lone = [], 0
-    for l in sched:
-        steps, m = 0, l
-        while 0 <= nbr[m, 12] < n_active:
-            m = nbr[m, 12]
-            steps += 1
-        if steps & 1:
-            continue
-        up = nbr[l, 14]
-        p = up if 0 <= up < n_active else -1
-        lone += p < 0
-        recs.append(np.concatenate([[l], nbr[l], [p], nbr[p] if p >= 0 else np.full(27, -1)]))
-    return np.array(recs, dtype=np.int32).reshape(-1, 56), lone
-
-
 @pytest.mark.parametrize("name", list(LEAF_SETS))
 def test_device_tables_match_host_builder(name):
     origins = LEAF_SETS[name]()
@@ -73,14 +55,9 @@ def test_device_tables_match_host_builder(name):
     assert np.array_equal(inside, np.arange(len(c), dtype=np.uint64)[::97] + 1)
     # launch order
     n = len(origins)
-    sched, recs, lone = dev.launch_tables()
-    assert np.array_equal(np.sort(sched), np.arange(n))
+    sched = dev.launch_order()
+    assert np.array_equal(np.sort(sched), np.arange(n))  # every leaf is worked on by exactly one workgroup
     assert np.array_equal(sched, expected_sched(n))
-    exp_recs, exp_lone = expected_waves(nbr_h, n, sched)
-    assert recs.shape == exp_recs.shape and np.array_equal(recs, exp_recs)
-    assert lone == exp_lone
-    members = np.concatenate([recs[:, 0], recs[recs[:, 28] >= 0, 28]])
-    assert np.array_equal(np.sort(members), np.arange(n))  # every leaf is swept by exactly one wave
     dev.reset()
     host.reset()
 
@@ -94,56 +71,32 @@ def expected_sched_segments(n, seg):
     return np.concatenate([head, body + expected_sched(n - body)]).astype(np.int32)
 
 
-@pytest.mark.parametrize("seg", [1, 16, 100])
-def test_segment_schedule(seg):
+def test_segment_schedule_of_large_grids_and_the_linear_option():
+    """beyond 40,000 leaves the eight XCDs walk through the leaf list together in segments of 128 leaves; option schedule = linear is plain leaf order"""
     import hnanosolver_amd as H
 
-    origins = fields.plume_leaves(32, 2.5, 0.22)
-    H.set_option("schedule_segment", seg)
-    try:
-        g = api.create_grid_from_leaves(origins, 0.1)
-    finally:
-        H.set_option("schedule_segment", None)
-    n = len(origins)
-    sched, recs, lone = g.launch_tables()
-    assert np.array_equal(np.sort(sched), np.arange(n))
-    assert np.array_equal(sched, expected_sched_segments(n, seg))
-    exp_recs, exp_lone = expected_waves(g.neighbor_table(), n, sched)
-    assert np.array_equal(recs, exp_recs) and lone == exp_lone
-    g.reset()
-
-
-@pytest.mark.parametrize("name", ["dense64", "plume", "scattered_dense", "single"])
-def test_tile_groups(name):
-    """Blocked SOR kernel: every wave record is in exactly one complete group or in the rest list; a group's members sit in
-    the slots their first leaf's coordinates dictate, inside one aligned window, at one x."""
-    origins = LEAF_SETS[name]()
+    origins = fields.dense_leaves(288)  # 46,656 leaves
     g = api.create_grid_from_leaves(origins, 0.1)
-    _, recs, _ = g.launch_tables()
-    groups, rest, (ty, tz) = g.tile_tables()
-    assert np.array_equal(np.sort(np.concatenate([groups.reshape(-1), rest])), np.arange(len(recs)))
-    o = origins[recs[:, 0]]
-    for grp in groups:
-        og = o[grp]
-        assert len(set(og[:, 0].tolist())) == 1
-        for s, oo in enumerate(og):
-            assert (oo[1] >> 3) % ty == s // tz and (oo[2] >> 4) % tz == s % tz
-        assert len({(oo[1] >> 3) // ty for oo in og}) == 1 and len({(oo[2] >> 4) // tz for oo in og}) == 1
-    if name == "dense64":
-        assert len(rest) == 0 and len(groups) * ty * tz == len(recs)
+    n = len(origins)
+    sched = g.launch_order()
+    assert np.array_equal(np.sort(sched), np.arange(n)) and np.array_equal(sched, expected_sched_segments(n, 128))
     g.reset()
+    H.set_option("schedule", "linear")
+    try:
+        g = api.create_grid_from_leaves(fields.plume_leaves(32, 2.5, 0.22), 0.1)
+        assert np.array_equal(g.launch_order(), np.arange(g.leaf_count()))
+        g.reset()
+    finally:
+        H.set_option("schedule", None)
 
 
 def test_active_prefix_rebuilds_launch_tables():
     origins = fields.plume_leaves(8, 1.0, 0.3)
     g = api.create_grid_from_leaves(origins, 0.1)
-    nbr = g.neighbor_table()
     for n_active in (len(origins) // 2, 1, len(origins)):
         g.set_active_leaves(n_active)
-        sched, recs, lone = g.launch_tables()
+        sched = g.launch_order()
         assert np.array_equal(sched, expected_sched(n_active))
-        exp_recs, exp_lone = expected_waves(nbr, n_active, sched)
-        assert np.array_equal(recs, exp_recs) and lone == exp_lone
     g.reset()
 
 
@@ -186,8 +139,7 @@ def test_create_index_grid_from_coordinates_256(capsys):
     assert h.leaf_count() == len(origins)
     host = api.create_grid_from_leaves(origins, 1.0 / R, _lib.HNS_GRID_HOST_ONLY)
     assert np.array_equal(h.neighbor_table(), host.neighbor_table())
-    sched, recs, lone = h.launch_tables()
-    assert lone == 0 and len(recs) == len(origins) // 2
+    assert np.array_equal(np.sort(h.launch_order()), np.arange(len(origins)))
     bad = c.copy()
     bad[512 * 20000 + 77, 2] += 1
     d.pCoords()[:] = bad

@@ -48,14 +48,14 @@ class FusedSorKernels(HipKernels):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["auto", "wave", "pair", "tile"])
+@pytest.mark.parametrize("form", [("rbgs", "auto"), ("sor_block_lb", "1"), ("sor_block_lb", "2"), ("rbgs", "color")])
 def test_fused_sor_forms_known_sweep(form):
-    """the closed-form two-iteration answer through the production (fused) SOR kernels"""
+    """the closed-form answer through hns_dev_rbgs_iterate, one iteration per call: the one-iteration launch of the 16^3 kernel, the two-launch form behind one-leaf blocks"""
     import hnanosolver_amd as H
 
     box = make_box("box24")
-    H.set_option("rbgs", form)
+    H.set_option(*form)
     try:
         kats.kat_rbgs_known_sweep(FusedSorKernels(box.leaves), box)
     finally:
-        H.set_option("rbgs", None)
+        H.set_option(form[0], None)

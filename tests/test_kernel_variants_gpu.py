@@ -46,19 +46,11 @@ def run_workload():
 VARIANTS = {
     "advect_64bit": {"advect": "generic"},
     "sor_two_launches_per_iteration": {"rbgs": "color"},  # the reference's own decomposition
-    "sor_wave_per_leaf": {"rbgs": "wave"},
-    "sor_wave_per_leaf_pair": {"rbgs": "pair"},  # the production form at scale; small grids default to one wave per leaf
-    "sor_blocked": {"rbgs": "tile"},  # wave records that are y / z neighbours share a workgroup and their faces
-    # temporally blocked (hns_sorblock.hip; small grids take it by default): K iterations per launch on blocks of 1 / 8 leaves
-    "sor_two_iterations_per_launch_leaf_blocks": {"rbgs": "block", "sor_block_lb": "1", "sor_block_k": "2"},
-    "sor_four_iterations_per_launch_leaf_blocks": {"rbgs": "block", "sor_block_lb": "1", "sor_block_k": "4"},
-    "sor_two_iterations_per_launch_16cube_blocks": {"rbgs": "block", "sor_block_lb": "2", "sor_block_k": "2", "sor_block_lean": "0"},
-    "sor_two_iterations_per_launch_16cube_blocks_rows_in_lds": {"rbgs": "block", "sor_block_lb": "2", "sor_block_k": "2", "sor_block_lean": "1"},
-    "sor_two_iterations_per_launch_16cube_blocks_div_by_lds_dma": {"rbgs": "block", "sor_block_lb": "2", "sor_block_k": "2", "sor_block_lean": "dma"},
-    "sor_two_iterations_per_launch_16cube_blocks_sweep_threads_fetch": {"rbgs": "block", "sor_block_lb": "2", "sor_block_k": "2", "sor_block_lean": "xy"},  # the default of 16^3 blocks since round 5
+    # temporally blocked (hns_sorblock.hip; rbgs = auto): the block edge forced either way on every grid -- one-leaf blocks (rows in registers; four iterations per launch up to
+    # 300 leaves, two beyond) and 16^3 blocks (rows in LDS, the sweep threads fetch their own rows)
+    "sor_leaf_blocks": {"sor_block_lb": "1"},
+    "sor_16cube_blocks": {"sor_block_lb": "2"},
     "schedule_linear": {"schedule": "linear"},
-    "sor_one_direction": {"alternate": "0", "rbgs": "pair"},
-    "all_kernels_forwards": {"rev": "0"},
     "divergence_block": {"stencil": "block"},
     "divergence_own_leaf_in_memory_order": {"divergence": "coalesced"},  # the default from 16,384 leaves (round 4)
     "cook_unpipelined_uncached": {"cook_pipeline": "0", "cook_cache": "0"},

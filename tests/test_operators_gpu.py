@@ -433,7 +433,7 @@ def test_c_abi_misuse_returns_codes_not_crashes():
     bad(L.hns_grid_set_active_leaves(h.ptr, 10 ** 9))
     bad(L.hns_grid_matches(None, None, 0, 0))
     bad(L.hns_grid_export_nanovdb(h.ptr, None, 0, None))
-    bad(L.hns_grid_launch_tables(None, None, None, None, None))
+    bad(L.hns_grid_launch_tables(None, None))
     bad(L.hns_grid_release_cache(None))
     # kernel-level API
     import torch
