@@ -13,7 +13,7 @@ N = 1: the workload is BASELINE.json's roofline configuration, the 256^3 dense-a
 N > 1: weak scaling -- every rank owns one such x-slab of a (256*N) x 256 x 256 domain (--partition: ONE --config domain,
 e.g. plume1024 = BASELINE.json's 1024^3-extent sparse grid, split across the ranks instead); ranks exchange the halo
 voxels of u / div / p / phi over RCCL where the single-GPU code has a kernel boundary that a stencil crosses, under the
-interior kernels (csrc/hns_dist.hip; hnanosolver_amd/dist.py is the host mirror). `value` = slab-substeps/s summed over ranks = N x (global substeps/s).
+interior kernels (csrc/hns_dist_*.hip; hnanosolver_amd/dist.py is the host mirror). `value` = slab-substeps/s summed over ranks = N x (global substeps/s).
 
 Rank 0 prints ONE JSON line. `roofline`: the SOR kernel (`kernel` names the form the library picked for this grid size).
 Algorithmic bytes are 12 B/voxel per red+black iteration (read p, read div, write p once each); a launch of the temporally
@@ -439,7 +439,7 @@ def main():
         local_rank = 0
         import hnanosolver_amd as H
 
-        H.set_option("dist_mirror", "guarded")  # processes sharing a GPU must not wait inside their sweeps (see hns_dist.hip)
+        H.set_option("dist_mirror", "guarded")  # processes sharing a GPU must not wait inside their sweeps (see hns_dist_*.hip)
         if args.transport == "rccl":
             args.transport = "ipc"
     torch.cuda.set_device(local_rank)

@@ -84,7 +84,7 @@ __host__ __device__ inline int sched_leaf(int b, int n, int seg) {
 
 // `pre` (a multiple of 8, 0 = none): the first `pre` leaves are dealt out first, an equal contiguous piece to every XCD, the rest
 // as above behind them -- a multi-GPU rank's boundary leaves (first in its leaf order) then run on all eight XCDs instead of
-// filling the head of XCD 0's chunk (hns_dist.hip: their waves poll and signal, and are slower than the others).
+// filling the head of XCD 0's chunk (hns_dist_*.hip: their waves poll and signal, and are slower than the others).
 __host__ __device__ inline int sched_leaf(int b, int n, int seg, int pre) {
 	if (pre <= 0) return sched_leaf(b, n, seg);
 	if (b < pre) return (b & 7) * (pre >> 3) + (b >> 3);

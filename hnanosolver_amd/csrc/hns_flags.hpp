@@ -1,5 +1,5 @@
 // hns_flags.hpp -- sequence-numbered flags between ranks (kernels of different processes / devices): system-scope release
-// stores and acquire loads on fine-grained device memory, bounded waits. Used by the one-sided halo transport (hns_dist.hip)
+// stores and acquire loads on fine-grained device memory, bounded waits. Used by the one-sided halo transport (hns_dist_*.hip)
 // and by the SOR sweep that writes its boundary rows into the peers' ghost voxels itself (hns_pressure.hip: k_rbgs_pair_mirror).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -58,7 +58,7 @@ __device__ __forceinline__ void store_through(float* p, chain_v4f v) { asm volat
 __device__ __forceinline__ void store_through(float* p, float4 v) { store_through(p, chain_v4f{v.x, v.y, v.z, v.w}); }
 __device__ __forceinline__ void store_through(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 
-// What a kernel of a "chained" multi-GPU rank needs besides its own arguments (by value; built by hns_dist.hip). Every kernel of
+// What a kernel of a "chained" multi-GPU rank needs besides its own arguments (by value; built by hns_dist_*.hip). Every kernel of
 // the substep is ONE launch over the owned leaves that delivers its own halo: a workgroup of a boundary leaf (local leaves
 // [0, n_boundary), first in the launch order) waits until every peer has completed its previous launch -- the peers' boundary
 // values of that launch are then in this rank's ghost voxels, and the peers no longer read what this launch is about to write
@@ -81,7 +81,7 @@ struct PhaseMirror {
 };
 struct NoMirror {};  // the same kernels on a single GPU: every chain_* call below compiles to nothing
 
-// The blocked boundary sweep of an EXCHANGED pressure loop (RCCL / loopback / local transports; hns_dist.hip: sor_block_exchanged) packs its own message: the voxels a peer reads of
+// The blocked boundary sweep of an EXCHANGED pressure loop (RCCL / loopback / local transports; hns_dist_substep.hip: sor_block_exchanged) packs its own message: the voxels a peer reads of
 // a boundary leaf go into that peer's send buffer in the message order (leaves in region order, rows x*8+y ascending, z ascending, travelling voxels only) as the block is stored --
 // plain stores, the send that follows reads them in stream order -- and the separate pack launch (7.5 us in a chain of four latency-bound launches per exchange) is gone.
 struct PackMirror {

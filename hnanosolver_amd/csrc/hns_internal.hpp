@@ -169,7 +169,7 @@ extern "C" __attribute__((visibility("hidden"))) int hns_advect_scalars_q4(hns_g
                                                                             float* const* out, int n, float dt, float inv_dx, void* stream);
 extern "C" __attribute__((visibility("hidden"))) bool hns_advect_q4_ok(const hns_grid* g);
 
-// implemented in hns_pointwise.hip: combustion_oxygen split into its divergence update (needs fuel, waste) and the rest (hns_dist.hip: the boundary leaves' divergence first)
+// implemented in hns_pointwise.hip: combustion_oxygen split into its divergence update (needs fuel, waste) and the rest (hns_dist_*.hip: the boundary leaves' divergence first)
 extern "C" __attribute__((visibility("hidden"))) int hns_combustion_div(const float* fuel, const float* waste, float* divergence, float expansion, uint64_t n,
                                                                         void* stream);
 extern "C" __attribute__((visibility("hidden"))) int hns_combustion_fields(const float* fuel, const float* waste, const float* temperature, const float* flame,

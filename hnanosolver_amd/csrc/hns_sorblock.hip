@@ -696,7 +696,7 @@ int hns_grid_build_blocks(hns_grid* g) {
 	int* total = leaders + n;
 	GridDev gd = g->dev();
 	const int first = (int)g->first_active, count = (int)g->n_active;
-	// (chain_boundary: the leading leaves of the range that are a multi-GPU rank's boundary leaves -- hns_dist.hip sets it on the range its
+	// (chain_boundary: the leading leaves of the range that are a multi-GPU rank's boundary leaves -- hns_dist_*.hip sets it on the range its
 	// chained sweeps run over; 0 everywhere else. sched_prefix != 0: deal the blocks they lead out to all XCDs first, option dist_spread)
 	const int n_boundary = g->chain_boundary ? first + (int)std::min<uint64_t>(g->chain_boundary, g->n_active) : 0;
 	hipStream_t st = nullptr;
@@ -732,7 +732,7 @@ int hns_rbgs_block_shape(hns_grid* g, int* k_max) {
 	*k_max = 0;
 	// fields addressable with 32-bit byte offsets. A launch range (a multi-GPU rank's boundary / interior / owned leaves) is swept like a
 	// whole grid: blocks that hold a leaf of the range, the other leaves of the grid as sources only (hns_grid_build_blocks). The CALLER
-	// vouches that p within 2K voxels of the range, and div within 2K - 1, are current in the leaves outside it (hns_dist.hip).
+	// vouches that p within 2K voxels of the range, and div within 2K - 1, are current in the leaves outside it (hns_dist_*.hip).
 	if (g->n_active == 0 || g->topo.n_leaves > 2000000) return 0;
 	int lb = options().sor_block_lb.load(), k = 0;
 	// by size (profiles/r03_sor_forms.txt): one-leaf blocks while the grid cannot fill the chip with 16^3 blocks, four iterations per
@@ -825,7 +825,7 @@ extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_block_pack_launch(
 	return HNS_OK;
 }
 
-// The chained sweep of a multi-GPU rank, two iterations per launch (hns_dist.hip; hns_flags.hpp): ONE launch over the rank's owned leaves
+// The chained sweep of a multi-GPU rank, two iterations per launch (hns_dist_*.hip; hns_flags.hpp): ONE launch over the rank's owned leaves
 // that waits for the peers where it reads their values and delivers its own boundary values into their ghost voxels. 16^3 blocks only.
 extern "C" __attribute__((visibility("hidden"))) int hns_rbgs_block_mirror_launch(hns_grid* g, const float* div, const float* src, float* dst, float dx, float omega, bool src_is_zero,
                                                                                    const hns::PhaseMirror* m, void* stream, int iterations) {

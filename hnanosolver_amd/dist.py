@@ -1,6 +1,6 @@
 """Leaf-partitioned multi-GPU core substep: host-side mirror of the ``hns_dist_*`` entry points of libhns.so.
 
-The reference is single-GPU; the decomposition is new design and lives in ``csrc/hns_dist.hip``: rank r
+The reference is single-GPU; the decomposition is new design and lives in ``csrc/hns_dist_*.hip``: rank r
 owns the r-th of `world` equal ranges of the global leaf list in slab order (``DistRank.owned_ids``; box domains: x-slabs = contiguous
 ranges of the NanoVDB-ordered list, as in rounds 1-4; the plume of BASELINE config 5: slabs along its own axis, two halo peers per rank), keeps
 one layer of ghost leaves in the local order ``[boundary | interior | ghosts]``, runs every kernel on its boundary leaves

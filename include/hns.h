@@ -302,7 +302,7 @@ int hns_dev_unpack_leaves(const float* packed, const int32_t* leaf_ids, uint64_t
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Leaf-partitioned multi-GPU core substep (new: the reference is single-GPU). One hns_dist per rank = per GPU.      */
 /* Rank r owns the r-th of `world` equal ranges of the global leaf list in slab order (hns_dist_partition_axis below), */
-/* keeps one layer of ghost leaves and refreshes exactly the ghost voxels the next kernel can read (hns_dist.hip). */
+/* keeps one layer of ghost leaves and refreshes exactly the ghost voxels the next kernel can read (hns_dist_*.hip). */
 /* Owned results are bit-identical to the single-domain hns_sim_core_substep -- as long as every tap of an advection   */
 /* back-trace that leaves the 27-leaf neighbourhood of its voxel's leaf (|u| dt / dx above ~8 voxels) still lands in   */
 /* a leaf this rank holds (owned or ghost: a rank holds ONE layer of ghost leaves). A far tap whose leaf is not here   */

@@ -43,7 +43,7 @@ def main():
     import hnanosolver_amd as H
 
     # every rank of this test sits on cuda:0: in-kernel waits of several processes can fill the device's wave slots and starve the
-    # process they wait for (hns_dist.hip: "guarded" puts ONE waiting wave in front of every chained launch instead)
+    # process they wait for (hns_dist_*.hip: "guarded" puts ONE waiting wave in front of every chained launch instead)
     H.set_option("dist_mirror", "guarded")
     case, *opts = case.split("@")  # "<case>@option=value@...": library options for this run
     for o in opts:

@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE: a CPU walk through the native multi-GPU plan.
 
-`ReferenceRank` executes the phases of hns_dist.hip's core substep (same order, same launch ranges [boundary | interior |
+`ReferenceRank` executes the phases of hns_dist_*.hip's core substep (same order, same launch ranges [boundary | interior |
 ghosts], same halo regions -- taken from the library's own plan, DistRank(plan_only=True)) with the ORACLE as the compute
 engine and torch.distributed (gloo) as the wire. It exists to prove, without a GPU, that the plan's regions and exchange
 points are sufficient: owned results must be bit-identical to the single-domain oracle run. The HIP path is tied to the
@@ -159,7 +159,7 @@ class ReferenceRank:
             self.phi, self.phi_next = self.phi_next, self.phi
             self.phi_in_flight = self.world > 1
 
-    # ---- the whole Compute_Sim substep (hns_dist.hip: Step::run_full; reference HNanoSolver.cu:150-356) ----
+    # ---- the whole Compute_Sim substep (hns_dist_substep.hip: Step::run_full; reference HNanoSolver.cu:150-356) ----
     def sim_substep(self, names, iterations, dt, params, has_collision):
         """`names`: the scalars in load order. Same phases, exchange types and launch ranges as hns_dist_sim_substep."""
         G, k = self.G, self.k

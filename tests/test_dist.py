@@ -273,7 +273,7 @@ def _sim_worker(rank, world, port, name, iters, k, coll, fs, out_dir):
 @pytest.mark.parametrize("name,world,k,coll,fs", [("plume", 2, 4, True, 1.0), ("dense", 3, 2, False, 0.5)])
 def test_partitioned_compute_sim_walk_is_bit_identical_to_single_domain(tmp_path, name, world, k, coll, fs):
     """The WHOLE Compute_Sim substep walked through the library's plan on CPU (oracle as engine, gloo as wire; the phases of
-    hns_dist.hip: Step::run_full): owned results of two chained substeps equal the oracle's own Compute driver on the single domain.
+    hns_dist_substep.hip: Step::run_full): owned results of two chained substeps equal the oracle's own Compute driver on the single domain.
     tests/test_dist_gpu.py ties the HIP path to the same answer."""
     import torch.multiprocessing as mp
 

@@ -1,4 +1,4 @@
-"""The native multi-GPU path (csrc/hns_dist.hip) on ONE device: every rank of a decomposition lives in this process and a
+"""The native multi-GPU path (csrc/hns_dist_*.hip) on ONE device: every rank of a decomposition lives in this process and a
 message is a device copy out of the peer's send buffer (hns_dist_connect_local) -- same plan, launch ranges, pack/unpack
 kernels, communication stream and events as the RCCL transport. Owned results must be bit-identical to the single-grid
 device run (which tests/test_fullsize_gpu.py ties to the oracle), including BASELINE.json configs[4]: the 1024^3-extent
