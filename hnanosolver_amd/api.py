@@ -266,7 +266,7 @@ def Compute_Sim(data: GridIndexedData, handle: IndexGridHandle, iteration: int, 
     those blocks are not uploaded again (hns_compute_sim_resident). checked=False (default): VOUCHED -- the caller knows what it changed; only a
     4,096-sample signature is compared, a sparse edit (an emitter added to a few leaves) is NOT detected, so a block the caller sourced
     into must not be named. checked=True: CHECKED -- a digest of every element (taken on the device when a block is handed back, on host threads when
-    it comes in again); any edit is noticed and that block uploaded. Sound; 14.8 ms per cook at 256^3 against 19.8 for the plain warm cook and 11.9
+    it comes in again); an edit is noticed and that block uploaded (a digest, not a comparison: missed with probability ~2^-64); 14.8 ms per cook at 256^3 against 19.8 for the plain warm cook and 11.9
     vouched (profiles/r05_final_cook256.json). Returns the number of uploads skipped."""
     if handle is None or handle.isEmpty():
         # argument checks come first in the reference (HNanoSolver.cu:12-23)

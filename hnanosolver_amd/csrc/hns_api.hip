@@ -89,7 +89,8 @@ struct hns_sim {
 	// Device-resident feedback across cooks (hns_compute_sim_resident): a signature of what the last hns_compute_sim on this state handed
 	// back for the velocity and for float field i -- those bytes are still in `vel` / cur[i]. 0 = nothing to vouch for (any upload clears it).
 	uint64_t sig_vel = 0, dig_vel = 0;  // (sig: sample signature; dig: full digest, 0 = not taken)
-	unsigned long long* d_dig = nullptr;  // 16 accumulators of the digest kernels (hns_digest.hpp)
+	unsigned long long* d_dig = nullptr;  // 16 accumulators of the digest kernels (hns_digest.hpp): a slice of the arena
+	unsigned long long* h_dig = nullptr;  // pinned host copy of them (read asynchronously on the cook's own stream)
 	std::vector<uint64_t> sig_cur, dig_cur;
 	void* arena = nullptr;  // every field above is a slice of this one allocation (see the arena pool below)
 	size_t arena_bytes = 0;
@@ -210,7 +211,7 @@ extern "C" void hns_sim_destroy(hns_sim* s) {
 	for (hipEvent_t e : s->xev)
 		if (e) (void)hipEventDestroy(e);
 	if (s->xfer) (void)hipStreamDestroy(s->xfer);
-	if (s->d_dig) (void)hipFree(s->d_dig);
+	if (s->h_dig) (void)hipHostFree(s->h_dig);
 	arena_put(Arena{s->arena, s->arena_bytes, s->device});
 	delete s;
 }
@@ -259,7 +260,7 @@ static hns_sim* sim_create(hns_grid* g, const char* const* float_names, int n_fl
 		const bool combust = s->find("fuel") >= 0 && s->find("waste") >= 0 && s->find("temperature") >= 0 && s->find("flame") >= 0;
 		const size_t units = 3 * 3 + 3 + 2 * s->names.size() + (combust ? 4 : 0);               // vel, adv, tmp | div, p_a, p_b | cur, nxt per field | q4
 		Arena a{nullptr, 0, -1};
-		rc = arena_get(unit * units, s->device, a);
+		rc = arena_get(unit * units + 256, s->device, a);  // (+ the 16 digest accumulators of hns_compute_sim_resident, CHECKED fields)
 		if (rc == HNS_OK) {
 			s->arena = a.p, s->arena_bytes = a.bytes;
 			char* q = (char*)a.p;
@@ -275,6 +276,7 @@ static hns_sim* sim_create(hns_grid* g, const char* const* float_names, int n_fl
 				s->nxt.push_back(take(1));
 			}
 			if (combust) s->q4 = take(4);
+			s->d_dig = (unsigned long long*)q;
 			s->p_result = s->p_a;
 			if (zero && hipMemsetAsync(a.p, 0, unit * units, (hipStream_t)stream) != hipSuccess) rc = fail(HNS_ERR_HIP, "hns_sim_create: clearing the field memory failed");
 		}
@@ -752,7 +754,7 @@ int make_sim(hns_grid* g, const FieldSplit& fs, SimGuard& guard, void* stream) {
 //    SOP_HNanoSolver.cpp:159-179, and must not flag a field it sourced into);
 //  * the FULL digest (hns_digest.hpp): every element, an order-independent sum over 16-byte pieces -- taken on the DEVICE when a field is handed back (beside the
 //    downloads) and on up to 8 HOST threads when the array comes in again (~5.5 ms for the 537 MB of a 256^3 cook, partly under the first kernels).
-//    resident[i] = 2 ("checked"): the skip is sound; 14.8 ms per cook at 256^3 against 19.8 plain and 11.9 vouched.
+//    resident[i] = 2 ("checked"): an edit goes unnoticed only if the 64-bit digests collide (probability ~2^-64 for an edit that is not crafted against the digest); 14.8 ms per cook at 256^3 against 19.8 plain and 11.9 vouched.
 // Neither is ever 0.
 static uint64_t host_signature(const float* a, size_t count) {
 	uint64_t h = 1469598103934665603ull ^ (uint64_t)count;
@@ -852,9 +854,10 @@ static int compute_sim_pipelined(hns_sim* s, FieldSplit& fs, int iterations, flo
 			if (k >= 0 && strcmp(f->name, "collision_sdf") && level_of(f) >= 2) bufs.push_back(s->cur[(size_t)k]), dig_slots.emplace_back(&s->dig_cur[(size_t)k], count);
 		}
 		if (bufs.empty()) return HNS_OK;
-		if (!s->d_dig) HNS_HIP(hipMalloc((void**)&s->d_dig, sizeof(unsigned long long) * 16));
+		if (!s->h_dig) HNS_HIP(hipHostMalloc((void**)&s->h_dig, sizeof(unsigned long long) * 16, hipHostMallocDefault));  // (host memory: no device synchronisation)
 		HNS_HIP(hipMemsetAsync(s->d_dig, 0, sizeof(unsigned long long) * 16, on));
 		for (size_t i = 0; i < bufs.size(); ++i) HNS_TRY(hns_field_digest(bufs[i], dig_slots[i].second, s->d_dig + i, on));
+		HNS_HIP(hipMemcpyAsync(s->h_dig, s->d_dig, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost, on));  // (on the cook's own stream, in front of its final synchronise: ADVICE r5)
 		return HNS_OK;
 	};
 	auto sign = [&]() -> int {  // (the downloads and the digest kernels have completed: what the host arrays hold now is what vel / cur[] hold)
@@ -868,9 +871,7 @@ static int compute_sim_pipelined(hns_sim* s, FieldSplit& fs, int iterations, flo
 			s->dig_cur[(size_t)k] = 0;
 		}
 		if (!dig_slots.empty()) {
-			unsigned long long sums[16];
-			HNS_HIP(hipMemcpy(sums, s->d_dig, sizeof(unsigned long long) * dig_slots.size(), hipMemcpyDeviceToHost));
-			for (size_t i = 0; i < dig_slots.size(); ++i) *dig_slots[i].first = hns_digest_finish(sums[i], dig_slots[i].second);
+			for (size_t i = 0; i < dig_slots.size(); ++i) *dig_slots[i].first = hns_digest_finish(s->h_dig[i], dig_slots[i].second);  // (the stream the copy ran on has been synchronised)
 		}
 		return HNS_OK;
 	};

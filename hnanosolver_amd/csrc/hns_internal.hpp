@@ -34,7 +34,7 @@ struct Options {
 	std::atomic<int> schedule{kScheduleAuto};  // "schedule": auto | linear (read when launch tables are built)
 	std::atomic<int> cook_cache{1};            // "cook_cache": operator calls keep their device buffers with the grid
 	std::atomic<int> cook_pipeline{1};         // "cook_pipeline": hns_compute_sim overlaps transfers with the substep
-	std::atomic<int> divergence_form{0};       // "divergence": 0 auto (by size) | 1 row | 2 coalesced (own leaf fetched in memory order, handed to the row owners through LDS)
+	std::atomic<int> divergence_form{0};       // "divergence": 0 auto (by size) | 1 row | 2 coalesced (own leaf fetched in memory order, handed to the row owners through LDS) | 3 zpair (coalesced, two z-adjacent leaves per workgroup)
 	std::atomic<int> fuse_pointwise{1};        // "fuse": hns_sim_substep / hns_compute_sim without a collision field run divergence + combustion + buoyancy as one launch and advect the four combustion fields out of one 16-byte-per-voxel array
 	std::atomic<int> sor_block_lb{0};          // "sor_block_lb": block edge of the temporally blocked SOR in leaves, 0 = by size | 1 | 2 (the tests' way to every kernel on every grid)
 	std::atomic<int> dist_wire_us{0};          // "dist_wire_us": loopback transport only, emulated time on the wire per exchange

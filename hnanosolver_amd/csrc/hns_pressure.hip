@@ -224,22 +224,48 @@ __device__ __forceinline__ void ld_row8(const float* f, size_t at, float (&v)[8]
 // the row owners through LDS (the wave's own 6 KB; one wave per workgroup, so only the wave's LDS order matters). Round 3 measured it
 // (64.1 -> 62.9 us at 256^3, 133 -> 123 on the 66k-leaf plume, but 11.8 -> 13.4 at 128^3: 12.6 KB of LDS per wave halve the waves in
 // flight where the grid is small) and dropped it; it is now switched by size instead.
-template <class M, bool COAL, class F>
+// ZP (round 6, VERDICT r5 task 5): TWO waves per workgroup on the z-adjacent leaves 2q and 2q + 1 of the launch range (leaf order is z-fastest: on a box every such pair
+// shares a z face); each hands the other the layer of u.z the other would gather -- 64 floats 96 bytes apart, every lane on a cache line of its own -- through LDS. The
+// pair is checked against the neighbour table: leaves that are not z neighbours gather as before.
+template <class M, bool COAL, class F, bool ZP = false>
 __device__ __forceinline__ void divergence_row_body(const GridDev& g, const float* __restrict__ u, float* __restrict__ div, const float inv_dx, const M& m, const F& fz) {
 	constexpr bool FUSE = !std::is_same<F, NoFuse>::value;
+	constexpr int NW = ZP ? 2 : 1;
 	// ux rows (x faces), uy rows (y faces), and the hand-over buffer of the coalesced form. FUSE: all three carved out of one array, which the out-going q4 / velocity rows
 	// are then staged in once the divergence has been read out of the tiles (576 float4: 64 rows x (8 + 1 pad))
-	__shared__ __attribute__((aligned(16))) RowTile TXs, TYs;
-	__shared__ __attribute__((aligned(16))) float4 s_owns[COAL ? 384 : 1];
-	__shared__ __attribute__((aligned(16))) float4 s_mem[FUSE ? (COAL ? 784 : 576) : 1];
-	RowTile& TX = FUSE ? *reinterpret_cast<RowTile*>(s_mem) : TXs;
-	RowTile& TY = FUSE ? *reinterpret_cast<RowTile*>(s_mem + 200) : TYs;
-	float4* const s_own = FUSE ? s_mem + 400 : s_owns;
-	const int l = threadIdx.x, x = l >> 3, y = l & 7;
-	const int* __restrict__ rec = g.blk + (size_t)launch_pos(g, blockIdx.x) * 28;
-	const int leaf = __builtin_amdgcn_readfirstlane(rec[0]);
+	__shared__ __attribute__((aligned(16))) RowTile TXs[NW], TYs[NW];
+	__shared__ __attribute__((aligned(16))) float4 s_owns[NW][COAL ? 384 : 1];
+	__shared__ __attribute__((aligned(16))) float4 s_mems[NW][FUSE ? (COAL ? 784 : 576) : 1];
+	__shared__ float s_z[NW][ZP ? 64 : 1];
+	const int wv = ZP ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
+	float4* const s_mem = s_mems[wv];
+	RowTile& TX = FUSE ? *reinterpret_cast<RowTile*>(s_mem) : TXs[wv];
+	RowTile& TY = FUSE ? *reinterpret_cast<RowTile*>(s_mem + 200) : TYs[wv];
+	float4* const s_own = FUSE ? s_mem + 400 : s_owns[wv];
+	const int l = threadIdx.x & 63, x = l >> 3, y = l & 7;
+	const int* __restrict__ rec;
+	int leaf;
+	bool live = true, z_shared = false;
+	if constexpr (ZP) {
+		// pair q of the range in the chunked order of hns_device.hpp (one chunk of the pair list per XCD), walked backwards like the one-leaf form
+		const int np = (g.n_active + 1) >> 1;
+		const unsigned rows = (unsigned)np >> 3, b = blockIdx.x;
+		const unsigned pos = (b >> 3) < rows ? (((rows - 1u - (b >> 3)) << 3) | (b & 7u)) : b;
+		const int q = sched_leaf((int)pos, np, g.sched_seg > 1 ? g.sched_seg / 2 : 0);
+		const int lf = g.first + 2 * q + wv;
+		live = lf < g.first + g.n_active;
+		leaf = live ? lf : g.first + 2 * q;  // (an odd range: the last pair's second wave shadows the first and stores nothing)
+		rec = g.nbr27 + (size_t)leaf * 27 - 1;  // (rec[1 + j] = neighbour j, as in the launch-order records)
+	} else {
+		rec = g.blk + (size_t)launch_pos(g, blockIdx.x) * 28;
+		leaf = __builtin_amdgcn_readfirstlane(rec[0]);
+	}
 	chain_begin(m, leaf);
 	const int n_zm = __builtin_amdgcn_readfirstlane(rec[1 + 12]), n_zp = __builtin_amdgcn_readfirstlane(rec[1 + 14]);
+	if constexpr (ZP) {
+		const int last = g.first + g.n_active - 1;
+		z_shared = wv == 0 ? (leaf + 1 <= last && n_zp == leaf + 1) : (live && n_zm == leaf - 1);
+	}
 	float r[24];
 	float c_fu[8], c_wa[8], c_te[8], c_fl[8];  // FUSE: the row's four combustion fields (32 contiguous bytes each)
 	if constexpr (FUSE) {
@@ -264,8 +290,9 @@ __device__ __forceinline__ void divergence_row_body(const GridDev& g, const floa
 	} else {
 		glb_row3(u, leaf, l, r);
 	}
-	const float uz_m = n_zm < 0 ? 0.0f : u[((size_t)n_zm * 512 + l * 8 + 7) * 3 + 2];
-	const float uz_p = n_zp < 0 ? 0.0f : u[((size_t)n_zp * 512 + l * 8) * 3 + 2];
+	float uz_m = (n_zm < 0 || (ZP && z_shared && wv == 1)) ? 0.0f : u[((size_t)n_zm * 512 + l * 8 + 7) * 3 + 2];
+	float uz_p = (n_zp < 0 || (ZP && z_shared && wv == 0)) ? 0.0f : u[((size_t)n_zp * 512 + l * 8) * 3 + 2];
+	if constexpr (ZP) s_z[wv][l] = wv == 0 ? r[23] : r[2];  // (u.z of the row's z = 7 / z = 0 voxel: what the partner wave would gather; read behind the workgroup barrier below)
 	int slot, src, RF;
 	face_duty(l, slot, src, RF);
 	float h[24];
@@ -318,6 +345,12 @@ __device__ __forceinline__ void divergence_row_body(const GridDev& g, const floa
 		rt_put(l < 16 ? TX : TY, RF, hv);
 	}
 	__syncthreads();
+	if constexpr (ZP) {
+		if (z_shared) {  // (wave-uniform)
+			if (wv == 0) uz_p = s_z[1][l];
+			else uz_m = s_z[0][l];
+		}
+	}
 	float xp[8], xm[8], yp[8], ym[8];
 	rt_get(TX, RT_ROW(x + 1, y), xp);
 	rt_get(TX, RT_ROW(x - 1, y), xm);
@@ -369,7 +402,7 @@ __device__ __forceinline__ void divergence_row_body(const GridDev& g, const floa
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
 			const int i = k * 64 + l;
-			q4[i] = s_mem[(i >> 3) * 9 + (i & 7)];
+			if (!ZP || live) q4[i] = s_mem[(i >> 3) * 9 + (i & 7)];
 		}
 		wave_sync();
 #pragma unroll
@@ -379,18 +412,28 @@ __device__ __forceinline__ void divergence_row_body(const GridDev& g, const floa
 #pragma unroll
 		for (int k = 0; k < 6; ++k) {
 			const int i = k * 64 + l, row = __mul24(i, 10923) >> 16;  // i / 6 for i < 384
-			uo[i] = s_mem[row * 7 + (i - row * 6)];
+			if (!ZP || live) uo[i] = s_mem[row * 7 + (i - row * 6)];
 		}
 	}
 	float4* q = reinterpret_cast<float4*>(div + (size_t)leaf * 512 + l * 8);
-	q[0] = make_float4(d[0], d[1], d[2], d[3]);
-	q[1] = make_float4(d[4], d[5], d[6], d[7]);
+	if (!ZP || live) {
+		q[0] = make_float4(d[0], d[1], d[2], d[3]);
+		q[1] = make_float4(d[4], d[5], d[6], d[7]);
+	}
 	chain_store_row(m, 0, leaf, l, make_float4(d[0], d[1], d[2], d[3]), make_float4(d[4], d[5], d[6], d[7]));
 	chain_end(m, leaf);
 }
 template <class M, bool COAL = false>
 __global__ __launch_bounds__(64) void k_divergence_row(const GridDev g, const float* __restrict__ u, float* __restrict__ div, const float inv_dx, const M m) {
 	divergence_row_body<M, COAL, NoFuse>(g, u, div, inv_dx, m, NoFuse{});
+}
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void k_divergence_combust_buoyancy_zpair(const GridDev g, const float* __restrict__ u, float* __restrict__ div, const float inv_dx,
+                                                                                                                      const CombustFuse fz) {
+	divergence_row_body<NoMirror, true, CombustFuse, true>(g, u, div, inv_dx, NoMirror{}, fz);
+}
+template <bool COAL>
+__global__ __launch_bounds__(128) void k_divergence_zpair(const GridDev g, const float* __restrict__ u, float* __restrict__ div, const float inv_dx) {
+	divergence_row_body<NoMirror, COAL, NoFuse, true>(g, u, div, inv_dx, NoMirror{}, NoFuse{});
 }
 // the fused launch of hns_sim_substep (CombustFuse above). Four waves per SIMD: left alone the scheduler hoists every load and takes 256 registers (one wave per SIMD)
 template <bool COAL>
@@ -419,7 +462,12 @@ int hns_dev_divergence(hns_grid* g, const float* vel3, float* div, float inv_dx,
 		gd.rev = 1;
 		// option "divergence" = auto | row | coalesced: by size (k_divergence_row's COAL form from 16k leaves; loses below, see the kernel)
 		const int form = options().divergence_form.load();
-		if (form == 2 || (form == 0 && g->n_active >= 16384))
+		// auto, from 16,384 leaves (round 6): z-adjacent leaves in pairs, the coalesced form (256^3 63 -> 58 us, 512^3 467 -> 431, 66k-leaf plume 118 -> 112;
+		// below that size the pairing buys nothing and the coalesced form loses to the row form: profiles/r06_divergence_zpair_ab.txt). A range whose boundary leaves
+		// are dealt out first (a chained multi-GPU rank) keeps one leaf per workgroup.
+		if ((form == 3 || (form == 0 && g->n_active >= 16384)) && g->sched_pre == 0)
+			hipLaunchKernelGGL(k_divergence_zpair<true>, dim3((unsigned)((g->n_active + 1) / 2)), dim3(128), 0, (hipStream_t)stream, gd, vel3, div, inv_dx);
+		else if (form == 2 || (form == 0 && g->n_active >= 16384))
 			hipLaunchKernelGGL((k_divergence_row<NoMirror, true>), dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, vel3, div, inv_dx, NoMirror{});
 		else
 			hipLaunchKernelGGL((k_divergence_row<NoMirror, false>), dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, vel3, div, inv_dx, NoMirror{});
@@ -440,7 +488,9 @@ int hns_divergence_combust_buoyancy(hns_grid* g, const float* vel3, float* div, 
 	gd.rev = 1;
 	const CombustFuse fz{fuel, waste, temperature, flame, reinterpret_cast<float4*>(q4), vel3_out, temp_gain, expansion, dt, ambient, strength};
 	const int form = options().divergence_form.load();
-	if (form == 2 || (form == 0 && g->n_active >= 16384))
+	if ((form == 3 || (form == 0 && g->n_active >= 16384)) && g->sched_pre == 0)
+		hipLaunchKernelGGL(k_divergence_combust_buoyancy_zpair, dim3((unsigned)((g->n_active + 1) / 2)), dim3(128), 0, (hipStream_t)stream, gd, vel3, div, inv_dx, fz);
+	else if (form == 2 || (form == 0 && g->n_active >= 16384))
 		hipLaunchKernelGGL(k_divergence_combust_buoyancy<true>, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, vel3, div, inv_dx, fz);
 	else
 		hipLaunchKernelGGL(k_divergence_combust_buoyancy<false>, dim3((unsigned)g->n_active), dim3(64), 0, (hipStream_t)stream, gd, vel3, div, inv_dx, fz);

@@ -676,8 +676,10 @@ int hns_grid_build_blocks(hns_grid* g) {
 	if (g->sb_built && g->sb_seg == seg && g->sb_first == g->first_active && g->sb_count == g->n_active) return HNS_OK;
 	if (g->d_sb_tab) {
 		//  a grid whose launch range or segment option changes every frame would park one table per change until it is destroyed: beyond
-		// four parked tables wait for the device -- a launch that was handed one of them has finished then -- and give them all back to the pool
-		if (g->sb_retired.size() >= 4) {
+		// 64 parked tables wait for the device -- a launch that was handed one of them has finished then -- and give them all back to the pool
+		// (that wait stalls every stream of the device from inside an asynchronous entry point, so it is the last resort of a pathological caller -- 64 rebuilds
+		// of one grid's records, each a megabyte at 256^3 -- not something a cook meets: a launch range changes when hns_dist builds its four ranges, once each)
+		if (g->sb_retired.size() >= 64) {
 			HNS_HIP(hipDeviceSynchronize());
 			hns_grid_retire_blocks(g);
 		}

@@ -138,7 +138,7 @@ const char* const kWordsStencil[] = {"auto", "block", nullptr};
 const char* const kWordsSchedule[] = {"auto", "linear", nullptr};
 const char* const kWordsBool[] = {"0", "1", nullptr};
 const char* const kWordsMirror[] = {"0", "1", "guarded", nullptr};
-const char* const kWordsDivergence[] = {"auto", "row", "coalesced", nullptr};
+const char* const kWordsDivergence[] = {"auto", "row", "coalesced", "zpair", nullptr};
 const OptionDesc kOptions[] = {
     {"rbgs", &Options::rbgs, kWordsRbgs},
     {"advect", &Options::advect_generic, kWordsAdvect},

@@ -66,8 +66,8 @@ int hns_trim_memory(void);
  *   "sor_block_lb"  0 = by size | 1 | 2: block edge of the temporally blocked form in leaves, whatever the size of the grid (how the tests reach both kernels on every leaf set)
  *   "advect"        auto | generic (64-bit addressed advection kernels)
  *   "stencil"       auto | block (512-thread divergence and gradient kernels)
- *   "divergence"    auto | row | coalesced: the divergence kernel fetches its own leaf row by row, or in memory order with a hand-over through LDS (auto: the latter
- *                   from 16,384 leaves)
+ *   "divergence"    auto | row | coalesced | zpair: the divergence kernel fetches its own leaf row by row, or in memory order with a hand-over through LDS, or that with
+ *                   two z-adjacent leaves per workgroup handing each other their common z face (auto: the last from 16,384 leaves, the first below)
  *   "schedule"      auto | linear (workgroup -> leaf order: one chunk of the leaf list per XCD, 128-leaf segments beyond 40,000 leaves | plain leaf order; takes
  *                   effect when a grid's launch tables are next built)
  *   "fuse"          1 | 0 (hns_sim_substep / hns_compute_sim without a collision field: divergence + combustion_oxygen + temperature_buoyancy as ONE launch that leaves
@@ -191,7 +191,8 @@ int hns_compute_sim(hns_grid*, hns_field* fields, int n_fields, int iterations, 
  *                    sourced into must NOT be flagged). The library only trips on gross mistakes: a signature of the array (its size and
  *                    4,096 evenly spread elements) must match the one taken when it was handed back. A sparse edit that misses the samples
  *                    is NOT detected and that field would silently stay stale on the device.
- *   resident[i] = 2  CHECKED. A 64-bit digest of EVERY element must match as well: any edit is noticed and the field uploaded. The digest is
+ *   resident[i] = 2  CHECKED. A 64-bit digest of EVERY element must match as well: an edit is noticed and the field uploaded, except with probability ~2^-64 (a
+ *                    digest, not a comparison: two different arrays can collide). The digest is
  *                    taken on the DEVICE when the field is handed back (of the buffer the array is downloaded from: the same bits, one pass at
  *                    memory speed beside the downloads) by a call that asked for it, and on the HOST, on up to 8 threads, when the array comes
  *                    in again (hns_digest.hpp: an order-independent sum over 16-byte pieces). Measured at 256^3: 14.8 ms per cook against 19.8

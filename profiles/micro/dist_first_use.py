@@ -16,10 +16,9 @@ t0 = time.perf_counter(); sim = D.Sim(grid, ["density"]); sim.upload({"vel": f["
 t0 = time.perf_counter(); sim.core_substep(7, 1.0 / 24, 1.0 / R, D.current_stream()); torch.cuda.synchronize(); lap("single substep", t0)
 t0 = time.perf_counter(); ranks = [HD.DistRank(origins, 2, r, 1.0 / R, n_scalars=1) for r in range(2)]; lap("DistRank x2", t0)
 t0 = time.perf_counter(); HD.DistRank.connect_local(ranks); lap("connect_local", t0)
-b = HD.partition_bounds(len(origins), 2)
 t0 = time.perf_counter()
 for r, d in enumerate(ranks):
-    sl = slice(b[r] * 512, b[r + 1] * 512); d.upload(f["vel"][sl], [f["density"][sl]])
+    d.upload(d.owned_voxels(f["vel"]), [d.owned_voxels(f["density"])])
 lap("upload", t0)
 st = int(torch.cuda.current_stream().cuda_stream)
 t0 = time.perf_counter(); HD.DistRank.local_core_substep(ranks, 7, 1.0 / 24, st); lap("enqueue substep", t0)

@@ -26,9 +26,7 @@ except Exception as e:  # noqa: BLE001
     print(f"rank {rank}: connect_rccl failed: {e}", flush=True)
     dist.destroy_process_group()
     sys.exit(3)
-b = HD.partition_bounds(len(origins), world)
-sl = slice(b[rank] * 512, b[rank + 1] * 512)
-d.upload(f["vel"][sl], [f["density"][sl]])
+d.upload(d.owned_voxels(f["vel"]), [d.owned_voxels(f["density"])])  # (the library's own ownership rule: slabs along the cheapest axis, not ranges of the leaf list)
 st = int(torch.cuda.current_stream().cuda_stream)
 for _ in range(2):
     d.core_substep(7, 1.0 / 24.0, st)
@@ -41,7 +39,7 @@ sim.upload(want)
 for _ in range(2):
     sim.core_substep(7, 1.0 / 24.0, 1.0 / R, D.current_stream())
 sim.download(want)
-ok = np.array_equal(got["vel"], want["vel"][sl]) and np.array_equal(got["scalars"][0], want["density"][sl])
+ok = np.array_equal(got["vel"], d.owned_voxels(want["vel"])) and np.array_equal(got["scalars"][0], d.owned_voxels(want["density"]))
 print(f"rank {rank}: RCCL transport bit-identical to the single grid: {ok}; info {d.info()['bytes_sent']}", flush=True)
 dist.barrier()
 dist.destroy_process_group()

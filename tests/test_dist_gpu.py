@@ -400,6 +400,14 @@ def test_bench_py_default_line_carries_the_strong_scaling_record():
     assert "bit-identical to the single-GPU run of the whole domain" in s["config"]["verified"], s["config"]["verified"]
     assert "bit-equal to their owners' values" in s["config"]["ghosts"], s["config"]["ghosts"]
     assert s["config"]["halo"]["halo_peers"] == 1 and "slabs of leaves along axis y" in s["config"]["parallelism"]
+    # round 6: and the same domain again over the one-sided transport where it connects and reproduces the reference transport bit for bit (ranks of ~33,000 leaves: the
+    # chained substep) -- a record of its own under its own watchdog, so that a hang on a machine this path has never seen cannot cost the line
+    o = j["strong_scaling_one_sided"]
+    assert "error" not in o, o
+    assert o["n_gpus"] == 2 and o["scaling"] == "strong" and o["value"] > 0 and o["config"]["leaves"] == 65944
+    assert "verified bit for bit" in o["config"]["parallelism"], o["config"]["parallelism"]
+    assert "bit-identical to the single-GPU run of the whole domain" in o["config"]["verified"], o["config"]["verified"]
+    assert o["config"]["halo"]["sweeps_per_exchange"] == 2 and o["config"]["halo"]["exchanges"] == 0
 
 
 def test_unconnected_ranks_refuse_to_step():

@@ -53,6 +53,8 @@ VARIANTS = {
     "schedule_linear": {"schedule": "linear"},
     "divergence_block": {"stencil": "block"},
     "divergence_own_leaf_in_memory_order": {"divergence": "coalesced"},  # the default from 16,384 leaves (round 4)
+    "divergence_z_pairs": {"divergence": "zpair"},  # round 6, the default from 16,384 leaves: two z-adjacent leaves per workgroup hand each other their common z face through LDS
+    "divergence_row_form": {"divergence": "row"},
     "cook_unpipelined_uncached": {"cook_pipeline": "0", "cook_cache": "0"},
     # round 6: the default substep without a collision field runs divergence + combustion + buoyancy as ONE launch and advects {fuel, waste, temperature, flame} out of one
     # 16-byte-per-voxel array; this is the reference's own decomposition (three launches, five float arrays)
