@@ -508,7 +508,8 @@ struct Step {
 	// (boundary kernel -> pack -> transfer -> unpack, each a latency-bound launch, plus two cross-stream event edges) is longer than the interior kernel it was meant to hide
 	// under. Large ranks (a 256^3 slab: 32,768 leaves) keep the boundary / interior split on two streams. A rank decides for itself: the messages are the same either way.
 	bool in_line_rank() const {
-		return !d->single_stream && (d->comm || d->loopback || d->ipc) && options().dist_unsplit.load() != 0 && d->nB + d->nI <= 16384;
+		const int u = options().dist_unsplit.load();  // 0 never | 1 by size | 2 always
+		return !d->single_stream && (d->comm || d->loopback || d->ipc) && u != 0 && (u == 2 || d->nB + d->nI <= 16384);
 	}
 
 	bool split_blocked() const {

@@ -138,6 +138,7 @@ const char* const kWordsStencil[] = {"auto", "block", nullptr};
 const char* const kWordsSchedule[] = {"auto", "linear", nullptr};
 const char* const kWordsBool[] = {"0", "1", nullptr};
 const char* const kWordsMirror[] = {"0", "1", "guarded", nullptr};
+const char* const kWordsUnsplit[] = {"0", "1", "always", nullptr};
 const char* const kWordsDivergence[] = {"auto", "row", "coalesced", "zpair", nullptr};
 const OptionDesc kOptions[] = {
     {"rbgs", &Options::rbgs, kWordsRbgs},
@@ -151,7 +152,7 @@ const OptionDesc kOptions[] = {
     {"sor_block_lb", &Options::sor_block_lb, nullptr},
     {"dist_wire_us", &Options::dist_wire_us, nullptr},
     {"dist_mirror", &Options::dist_mirror, kWordsMirror},
-    {"dist_unsplit", &Options::dist_unsplit, kWordsBool},
+    {"dist_unsplit", &Options::dist_unsplit, kWordsUnsplit},
 };
 const Options kDefaults;
 }  // namespace
