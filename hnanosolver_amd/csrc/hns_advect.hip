@@ -121,8 +121,9 @@ __device__ __forceinline__ Taps make_taps(const GridDev& g, const int* s_nbr, co
 		}
 	} else {
 		int any = 0;
+		far_cell_taps(g, i, j, k, T.t);
 #pragma unroll
-		for (int c = 0; c < 8; ++c) any |= (T.t[c] = tap_index(g, s_nbr, org, i + (c >> 2), j + ((c >> 1) & 1), k + (c & 1)));  // unrolled: see make_taps_b
+		for (int c = 0; c < 8; ++c) any |= T.t[c];
 		// a multi-GPU rank: a tap beyond the 27-leaf neighbourhood whose leaf is not HERE may exist on another rank (hns_dist reports
 		// it); one that resolves to a local leaf -- owned or ghost, both hold current values -- is answered as the single domain answers it
 		if (any < 0 && g.far_flag) *g.far_flag = 1;
@@ -157,12 +158,12 @@ __device__ __forceinline__ TapsB make_taps_b(const GridDev& g, const int* s_nbr,
 			T.o[c] = *reinterpret_cast<const unsigned*>(tab + (XY[dij] | Z[dk])) + lxy[dij] + lz[dk];
 		}
 	} else {
-		int any = 0;
+		int any = 0, ft[8];
+		far_cell_taps(g, i, j, k, ft);  // (round 6: one hash walk per distinct leaf under the cell instead of one per corner)
 #pragma unroll
-		for (int c = 0; c < 8; ++c) {  // unrolled: a rolled loop would index T.o dynamically and push the whole array into LDS
-			const int t = tap_index(g, s_nbr, org, i + (c >> 2), j + ((c >> 1) & 1), k + (c & 1));
-			any |= t;
-			T.o[c] = t < 0 ? kOutside : (unsigned)t << 2;
+		for (int c = 0; c < 8; ++c) {
+			any |= ft[c];
+			T.o[c] = ft[c] < 0 ? kOutside : (unsigned)ft[c] << 2;
 		}
 		if (any < 0 && g.far_flag) *g.far_flag = 1;  // a multi-GPU rank: a far tap whose leaf is not here may exist on another rank (see make_taps)
 	}
@@ -577,8 +578,9 @@ __device__ __forceinline__ void interp_from_taps(const Taps& T, int oob, int (&i
 // Q4: besides the P.n float fields, the four fields of P.q4. A corner tap of those four is ONE 16-byte gather instead of four 4-byte (z-paired: 8-byte) ones: the
 // kernel is bound by L1 accesses per gather instruction (profiles/r05_advect_notes.txt 2), and a quad of lanes costs an access whatever its width -- sixteen
 // gathers for the four fields' two samples instead of thirty-two. Per field the arithmetic is the same chain of fused multiply-adds in the same order.
+// (at least four waves per SIMD = two workgroups per CU: the Q4 form sits at the 128-register line, and one register over it is ONE workgroup per CU -- 585 -> 838 us at 256^3, measured)
 template <bool Q4>
-__global__ __launch_bounds__(512) void k_advect_scalars_n(const GridDev g, const float* __restrict__ u, const ScalarPtrs P, const float scaled_dt) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k_advect_scalars_n(const GridDev g, const float* __restrict__ u, const ScalarPtrs P, const float scaled_dt) {
 	__shared__ int s_nbr[27];
 	__shared__ int s_base[27];
 	__shared__ unsigned s_b4[27];

@@ -44,6 +44,33 @@ __device__ __forceinline__ int tap_index(const GridDev& g, const int* s_nbr, con
 	return leaf < 0 ? -1 : leaf * 512 + (((i & 7) << 6) | ((j & 7) << 3) | (k & 7));
 }
 
+// The eight corners of a trilinear cell whose lower corner (i, j, k) lies beyond the 27-leaf neighbourhood (a back-trace of more than a leaf: |u| dt / dx > 8). The cell
+// spans two leaves along an axis only where the lower corner sits on the last voxel of its leaf: in two cells out of three all eight corners share ONE leaf, so the origin hash is
+// asked once per distinct leaf (1, 2, 4 or 8 dependent probe chains) instead of once per corner. Same leaf ids, same indices as eight calls of tap_index. t[di*4 + dj*2 + dk].
+__device__ __forceinline__ void far_cell_taps(const GridDev& g, int i, int j, int k, int (&t)[8]) {
+	const int i0 = i & ~7, j0 = j & ~7, k0 = k & ~7;
+	const bool cx = (i & 7) == 7, cy = (j & 7) == 7, cz = (k & 7) == 7;
+	int L[8];
+	L[0] = d_find_leaf(g, i0, j0, k0);
+	L[1] = cz ? d_find_leaf(g, i0, j0, k0 + 8) : L[0];
+	L[2] = cy ? d_find_leaf(g, i0, j0 + 8, k0) : L[0];
+	L[3] = cy ? (cz ? d_find_leaf(g, i0, j0 + 8, k0 + 8) : L[2]) : L[1];
+	if (cx) {
+		L[4] = d_find_leaf(g, i0 + 8, j0, k0);
+		L[5] = cz ? d_find_leaf(g, i0 + 8, j0, k0 + 8) : L[4];
+		L[6] = cy ? d_find_leaf(g, i0 + 8, j0 + 8, k0) : L[4];
+		L[7] = cy ? (cz ? d_find_leaf(g, i0 + 8, j0 + 8, k0 + 8) : L[6]) : L[5];
+	} else {
+		L[4] = L[0], L[5] = L[1], L[6] = L[2], L[7] = L[3];
+	}
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		const int di = c >> 2, dj = (c >> 1) & 1, dk = c & 1;
+		const int leaf = L[c];  // (corner c lies in the leaf of the same index: where an axis does not cross, L[] repeats the lower leaf)
+		t[c] = leaf < 0 ? -1 : leaf * 512 + ((((i + di) & 7) << 6) | (((j + dj) & 7) << 3) | ((k + dk) & 7));
+	}
+}
+
 // IndexSampler<float,0> (Stencils.hpp:81-89): value, or 0 outside the domain
 __device__ __forceinline__ float ld0(const float* __restrict__ f, int idx) { return idx < 0 ? 0.0f : f[idx]; }
 
