@@ -48,8 +48,9 @@ BYTES_PER_VOXEL_ITER = 12  # RB-SOR per iteration reads p, reads d
 BYTES_PER_VOXEL_SUBSTEP = 688  # advect_vector 24 + divergence 16 + 50*12 + gradient 28 + advect_scalars(S=1) 20
 # SURVEY.md 8d, algorithmic bytes per voxel of each stage of the core substep (pressure: per iteration)
 STAGE_BYTES = {"advect_vector": 24, "divergence": 16, "pressure": BYTES_PER_VOXEL_ITER, "gradient": 28, "advect_scalars": 20}
-STAGE_KERNEL = {"advect_vector": "k_advect_vector_n", "divergence": "k_divergence_row", "pressure": "k_rbgs_pair", "gradient": "k_subtract_gradient_s",
-                "advect_scalars": "k_advect_scalars_n"}
+# (the divergence kernel is picked by size: z-paired workgroups from 16,384 leaves, one leaf per workgroup below; the pressure kernel's name comes from hns_grid_rbgs_plan)
+STAGE_KERNEL = {"advect_vector": ("k_advect_vector_n",), "divergence": ("k_divergence_zpair", "k_divergence_row"), "pressure": (), "gradient": ("k_subtract_gradient_s",),
+                "advect_scalars": ("k_advect_scalars_n",)}
 
 
 def kernel_source_sha16():
@@ -546,7 +547,10 @@ def main():
                 per = ms / n_sub / n_l  # ms per kernel launch
                 alg = STAGE_BYTES[st] * n_vox_rank * (args.iterations / n_l if st == "pressure" else 1)
                 gbs = alg / (per * 1e-3) / 1e9 if per > 0 else None
-                kname = STAGE_KERNEL[st] if st != "pressure" else sor_form.split(":")[0]
+                if st == "pressure":
+                    kname = sor_form.split(":")[0]
+                else:  # (whichever of the stage's kernels the committed PMC profile of this configuration saw; else the first)
+                    kname = next((k for k in STAGE_KERNEL[st] if pmc_of(k) is not None), STAGE_KERNEL[st][0] if n_vox_rank >= 16384 * 512 or len(STAGE_KERNEL[st]) == 1 else STAGE_KERNEL[st][-1])
                 moved = pmc_of(kname)
                 ent = {"stage": st, "ms_per_launch": per, "launches_per_substep": n_l, "algorithmic_bytes_per_launch": alg, "achieved": gbs,
                        "frac": gbs / HBM_PEAK_GBS if gbs else None,
