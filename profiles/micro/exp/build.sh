@@ -15,7 +15,7 @@ tmp=$(mktemp -d); cp "$src"/*.hip "$src"/*.hpp "$src"/*.cpp "$tmp"/
 cd "$tmp"
 objs=""
 for f in hns_topology.cpp hns_nanovdb.cpp hns_leafio.cpp hns_gridbuild.hip hns_advect.hip hns_pressure.hip hns_sorblock.hip hns_pointwise.hip hns_api.hip hns_dist_plan.hip hns_dist_transport.hip hns_dist_substep.hip; do
-  extra=""; [ "$f" = hns_sorblock.hip ] && extra="-fno-slp-vectorize"
+  extra=""; [ "$f" = hns_sorblock.hip ] && extra="${HNS_SORBLOCK_FLAGS--fno-slp-vectorize}"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -I"$src/../../include" $extra "$@" -x hip -c $f -o $f.o &
   objs="$objs $f.o"
 done
