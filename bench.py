@@ -292,7 +292,7 @@ def timed_steps(step, steps, warmup, world, on_cpu, before_timed=None):
 def ghost_note_of(runner):
     """after a timed region: do the ghost voxels the timed transport wrote hold their owners' bits? (collective; any failure is reported, not raised)"""
     try:
-        n_pairs, bad = runner.rank_obj.ghost_check(None)
+        n_pairs, bad = runner.rank_obj.ghost_check(None, stream=runner.stream)
         return (f"after the timed substeps the velocity and p ghost voxels of all {n_pairs} (owner, holder, field) pairs are bit-equal to their owners' values"
                 if not bad else f"GHOST VOXELS DIFFER FROM THEIR OWNERS' VALUES after the timed substeps in {len(bad)} of {n_pairs} pairs, first {bad[0]}")
     except Exception as e:  # noqa: BLE001
@@ -331,7 +331,7 @@ def strong_scaling_record(args, world, rank, dt, transport=None):
                 runner.verify_against_single_gpu()
             except Exception as e:  # noqa: BLE001
                 runner.verified_note = f"check against the single-GPU run did not complete: {type(e).__name__}: {e}"[:300]
-                runner.rank_obj.upload(*runner._fields)
+                runner.rank_obj.upload(*runner._fields, stream=runner.stream)
         elapsed = timed_steps(runner.step, args.steps, args.warmup, world, args.share_one_gpu)
         info = runner.info()
         rec["config"].update({
@@ -502,7 +502,7 @@ def main():
                 runner.verify_against_single_gpu()
             except Exception as e:  # noqa: BLE001 -- the check must not cost the measurement; it says that it did not run
                 runner.verified_note = f"check against the single-GPU run did not complete: {type(e).__name__}: {e}"[:300]
-                runner.rank_obj.upload(*runner._fields)
+                runner.rank_obj.upload(*runner._fields, stream=runner.stream)
 
         def timing_on():
             runner.timing_on(args.steps)

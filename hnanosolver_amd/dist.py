@@ -354,7 +354,10 @@ class SlabBench:
         slab_origins = np.ascontiguousarray(slab_origins, dtype=np.int32)
         glob = slab_origins if partition else slab_domain(slab_origins, R, world)
         self.iterations, self.dt, self.vs = iterations, dt, 1.0 / R  # same voxel size (and omega) as the single-GPU workload
-        self.stream = int(torch.cuda.current_stream().cuda_stream)
+        # a stream of the run's own, not the legacy null stream: since round 6 small ranks issue their RCCL groups on the stream they step on (in-line exchanges), and RCCL on
+        # the null stream -- with its implicit synchronisation against every blocking stream of the process -- is a combination nobody else exercises
+        self._torch_stream = torch.cuda.Stream() if world > 1 else None
+        self.stream = int((self._torch_stream or torch.cuda.current_stream()).cuda_stream)
         self.transport_note = "no peers" if world == 1 else transport
 
         def make(k):
@@ -376,7 +379,7 @@ class SlabBench:
             self.rank_obj = make(sweeps_per_exchange or (self._one_sided_k(len(glob), world) if transport == "ipc" else 0))
             if world > 1 and connect:
                 self.rank_obj.connect_ipc() if transport == "ipc" else self.rank_obj.connect_rccl()
-        self.rank_obj.upload(*self._fields)
+        self.rank_obj.upload(*self._fields, stream=self.stream)
         self._glob, self._R, self._partition, self._world = glob, R, partition, world
         self.verified_note = "single GPU" if world == 1 else "not checked"
 
@@ -402,11 +405,11 @@ class SlabBench:
         d = self.rank_obj
         why = ""
         try:  # (whatever goes wrong on one rank -- the partitioned substeps included -- every rank reaches the collective below)
-            d.upload(*self._fields)
+            d.upload(*self._fields, stream=self.stream)
             for _ in range(substeps):
                 d.core_substep(self.iterations, self.dt, self.stream)
             d.synchronize(self.stream)
-            got = d.download()
+            got = d.download(stream=self.stream)
             if self._partition:
                 f = fields.synthetic_fields(self._glob, self._R)
                 vel, den = f["vel"], f["density"]
@@ -417,10 +420,10 @@ class SlabBench:
             grid = api.create_grid_from_leaves(self._glob, self.vs)
             sim = D.Sim(grid, ["density"])
             arrays = {"vel": np.ascontiguousarray(vel), "density": np.ascontiguousarray(den)}
-            sim.upload(arrays)
+            sim.upload(arrays, self.stream)
             for _ in range(substeps):
                 sim.core_substep(self.iterations, self.dt, self.vs, self.stream)
-            sim.download(arrays)
+            sim.download(arrays, self.stream)
             same = np.array_equal(got["vel"], d.owned_voxels(arrays["vel"])) and np.array_equal(got["scalars"][0], d.owned_voxels(arrays["density"]))
             sim.close()
         except Exception as e:  # noqa: BLE001
@@ -435,7 +438,7 @@ class SlabBench:
         else:
             self.verified_note = (f"owned velocity and density after {substeps} substeps bit-identical to the single-GPU run of the whole domain on every rank" if ok else
                                   "MISMATCH against the single-GPU run of the whole domain: THIS RUN'S PHYSICS IS WRONG, its throughput means nothing")
-        d.upload(*self._fields)
+        d.upload(*self._fields, stream=self.stream)
         return ok
 
     def _verified_one_sided(self, make, sweeps_per_exchange, reference_transport):
@@ -453,11 +456,11 @@ class SlabBench:
             return bool(int(t.item()))
 
         def two_substeps(d):  # (three, at the full iteration count: ~150 sweeps over every boundary leaf)
-            d.upload(*self._fields)
+            d.upload(*self._fields, stream=self.stream)
             for _ in range(3):
                 d.core_substep(self.iterations, self.dt, self.stream)
             d.synchronize(self.stream)
-            return d.download(pressure=True)
+            return d.download(pressure=True, stream=self.stream)
 
         ref = make(sweeps_per_exchange)
         ref.connect_rccl() if reference_transport == "rccl" else ref.connect_ipc()
