@@ -837,7 +837,7 @@ int hns_dev_advect_scalars(hns_grid* g, const float* vel3, const float* const* i
 		{
 			GridDev gd = g->dev();
 			// backwards: the gradient kernel has just written the velocity front to back; starting on its cached tail also
-			// leaves the head cached for the next substep's advect_vector (256^3: -1 % here, -4 % there). Option "rev" = 0: forwards.
+			// leaves the head cached for the next substep's advect_vector (256^3: -1 % here, -4 % there).
 			gd.rev = 1;
 			hipLaunchKernelGGL(k_advect_scalars_n<false>, grid, block, 0, (hipStream_t)stream, gd, vel3, P, scaled_dt);
 		}

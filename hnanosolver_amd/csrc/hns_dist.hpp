@@ -208,7 +208,7 @@ struct hns_dist {
 	bool ipc = false;
 	size_t unit_bytes = 0;  // bytes per scalar field over the local leaves (fields sit at multiples of it in the arena)
 	// "mirror" pressure loop (sweeps_per_exchange = 1 over the ipc or local transport): the sweep kernel itself writes its
-	// boundary rows into the peers' ghost voxels (hns_pressure.hip: k_rbgs_pair_mirror)
+	// boundary values into the peers' ghost voxels (hns_sorblock.hip: k_rbgs_block_xy<., PhaseMirror>)
 	bool mirror = false;
 	void* mir_tables = nullptr;
 	hns::PhaseMirror mir;            // everything but the region tables, the output arrays and the launch number

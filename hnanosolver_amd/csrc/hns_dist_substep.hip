@@ -601,7 +601,7 @@ struct Step {
 			return HNS_OK;
 		}
 		HNS_TRY(post(d, xt, Fields{{dst, 1}}, st, [=](hipStream_t s) -> int {
-			// two iterations in one blocked launch: the boundary sweep writes the peers' messages as it stores (PackMirror; option "dist_pack")
+			// two iterations in one blocked launch: the boundary sweep writes the peers' messages as it stores (PackMirror)
 			if (tail == 2 && D->pack_ok[xt]) {
 				PackMirror m = D->pack_type[xt];
 				for (size_t pi = 0; pi < D->peers.size(); ++pi) m.msg[pi] = D->peers[pi].sbuf[D->pending.parity];

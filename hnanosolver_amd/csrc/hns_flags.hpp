@@ -1,6 +1,6 @@
 // hns_flags.hpp -- sequence-numbered flags between ranks (kernels of different processes / devices): system-scope release
 // stores and acquire loads on fine-grained device memory, bounded waits. Used by the one-sided halo transport (hns_dist_*.hip)
-// and by the SOR sweep that writes its boundary rows into the peers' ghost voxels itself (hns_pressure.hip: k_rbgs_pair_mirror).
+// and by the kernels of a chained rank, which write their boundary values into the peers' ghost voxels themselves (PhaseMirror below).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>

@@ -3,8 +3,8 @@
 // The reference rebuilds its NanoGrid<ValueOnIndex> on the GPU every cook (create_index_grid, reference
 // src/Cuda/HNanoSolver.cu:375-384 -> externals/nanovdb/tools/cuda/PointsToGrid.cuh:511-1064: ~25 launches and 8 CUB
 // sorts/scans over all N voxel coordinates). Here only the leaf origins (one coordinate in 512) cross PCIe; the origin
-// hash, the 27-neighbour table and the launch-ordered wave records the kernels read are built by five small kernels
-// over the leaves. Integer work only; tests/test_gridbuild_gpu.py checks every table against the host builder of
+// hash, the 27-neighbour table and the launch-ordered {leaf, nbr27} records the kernels read are built by three small kernels
+// over the leaves (the block records of the SOR kernel: hns_sorblock.hip, on first use). Integer work only; tests/test_gridbuild_gpu.py checks every table against the host builder of
 // hns_topology.cpp.
 #include <cstdlib>
 #include <cstring>

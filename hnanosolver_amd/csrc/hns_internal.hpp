@@ -79,7 +79,7 @@ struct GridDev {
 	int n_active;
 	int first;  // first active leaf: kernels update leaves [first, first + n_active)
 	int oob;  // element read by advect_scalars for out-of-domain taps (0 on an unpartitioned grid)
-	int rev;  // 1: walk the launch order backwards (rows of eight workgroups reversed, see k_rbgs_pair)
+	int rev;  // 1: walk the launch order backwards (rows of eight workgroups reversed: a kernel starts on the cached tail of what its predecessor wrote)
 	int* far_flag;  // null, or (the local grid of a multi-GPU rank) a word the advection kernels raise when a tap leaves the 27-leaf neighbourhood of its
 	                // leaf: the rank holds one layer of ghost leaves, further away it cannot tell "outside the domain" from "on another rank"
 };

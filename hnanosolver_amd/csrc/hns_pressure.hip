@@ -458,7 +458,7 @@ int hns_dev_divergence(hns_grid* g, const float* vel3, float* div, float inv_dx,
 	{
 		GridDev gd = g->dev();
 		// backwards: advect_vector has just written the velocity front to back, so its tail is what the Infinity Cache holds
-		// (256^3: 74 -> 66 us). Option "rev" = 0 walks every kernel forwards.
+		// (256^3: 74 -> 66 us).
 		gd.rev = 1;
 		// option "divergence" = auto | row | coalesced: by size (k_divergence_row's COAL form from 16k leaves; loses below, see the kernel)
 		const int form = options().divergence_form.load();

@@ -699,7 +699,7 @@ int hns_grid_build_blocks(hns_grid* g) {
 	GridDev gd = g->dev();
 	const int first = (int)g->first_active, count = (int)g->n_active;
 	// (chain_boundary: the leading leaves of the range that are a multi-GPU rank's boundary leaves -- hns_dist_*.hip sets it on the range its
-	// chained sweeps run over; 0 everywhere else. sched_prefix != 0: deal the blocks they lead out to all XCDs first, option dist_spread)
+	// chained sweeps run over; 0 everywhere else. sched_prefix != 0: deal the blocks they lead out to all XCDs first)
 	const int n_boundary = g->chain_boundary ? first + (int)std::min<uint64_t>(g->chain_boundary, g->n_active) : 0;
 	hipStream_t st = nullptr;
 	HNS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
