@@ -12,10 +12,10 @@ constexpr int LN = 32;  // leaves per axis: 256^3 voxels
 struct f3 { float x, y, z; };
 __device__ __forceinline__ int leaf_of(int lx, int ly, int lz) { return (((lx + LN) % LN) * LN + ((ly + LN) % LN)) * LN + ((lz + LN) % LN); }
 
-template <int LDS>  // 0: global, 1: 12-byte packed tile, 2: 16-byte padded tile (64 KB)
+template <int LDS>  // 0: global, 1: 12-byte packed tile, 2: 16-byte padded tile (64 KB), 3: three component planes (48 KB), z index XOR-swizzled by y so that a wave's 8 x 8 (y, z) window hits every bank twice
 __global__ __launch_bounds__(512) void k(const float* __restrict__ u, float* __restrict__ out, const int* __restrict__ shifts) {
 	__shared__ int s_base[27];
-	__shared__ __attribute__((aligned(16))) float s_tile[LDS == 1 ? 16 * 16 * 16 * 3 : (LDS == 2 ? 16 * 16 * 16 * 4 : 4)];
+	__shared__ __attribute__((aligned(16))) float s_tile[(LDS == 1 || LDS == 3) ? 16 * 16 * 16 * 3 : (LDS == 2 ? 16 * 16 * 16 * 4 : 4)];
 	const int leaf = blockIdx.x, n = threadIdx.x;
 	const int lx = leaf / (LN * LN), ly = (leaf / LN) % LN, lz = leaf % LN;
 	if (n < 27) s_base[n] = leaf_of(lx + n / 9 - 1, ly + (n / 3) % 3 - 1, lz + n % 3 - 1) * 512;
@@ -28,6 +28,25 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ u, float* __r
 			const int cx = tx < 4 ? 0 : (tx < 12 ? 1 : 2), cy = ty < 4 ? 0 : (ty < 12 ? 1 : 2), cz = tz < 4 ? 0 : (tz < 12 ? 1 : 2);
 			const float* t = u + (size_t)(s_base[cx * 9 + cy * 3 + cz] + ((((tx + 4) & 7) << 6) | (((ty + 4) & 7) << 3) | ((tz + 4) & 7))) * 3;
 			*reinterpret_cast<float4*>(&s_tile[v * 4]) = make_float4(t[0], t[1], t[2], 0.0f);
+		}
+	}
+	if (LDS == 3) {
+		__syncthreads();
+#pragma unroll
+		for (int kk = 0; kk < 6; ++kk) {
+			const int p = n + 512 * kk, row = p / 12, part = p - row * 12;
+			const int tx = row >> 4, ty = row & 15;
+			const int cx = tx < 4 ? 0 : (tx < 12 ? 1 : 2), cy = ty < 4 ? 0 : (ty < 12 ? 1 : 2), cz = part < 3 ? 0 : (part < 9 ? 1 : 2);
+			const int vx = (tx + 4) & 7, vy = (ty + 4) & 7;
+			const int zoff = cz == 0 ? 12 + part * 4 : (cz == 1 ? (part - 3) * 4 : (part - 9) * 4);
+			const float4 v = *reinterpret_cast<const float4*>(u + (size_t)(s_base[cx * 9 + cy * 3 + cz] + ((vx << 6) | (vy << 3))) * 3 + zoff);
+			const float e[4] = {v.x, v.y, v.z, v.w};
+			const int swz = ((ty >> 1) & 1) << 3;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int f = part * 4 + q, vz = f / 3, c = f - vz * 3;
+				s_tile[c * 4096 + row * 16 + (vz ^ swz)] = e[q];
+			}
 		}
 	}
 	if (LDS == 1) {
@@ -58,6 +77,10 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ u, float* __r
 			if (LDS == 2) {
 				const float4 t = *reinterpret_cast<const float4*>(&s_tile[((((i + 4) & 15) * 16 + ((j + 4) & 15)) * 16 + ((kq + 4) & 15)) * 4]);
 				v.x = t.x, v.y = t.y, v.z = t.z;
+			} else if (LDS == 3) {
+				const int Y = (j + 4) & 15;
+				const float* t = &s_tile[((((i + 4) & 15) * 16 + Y) * 16) + (((kq + 4) & 15) ^ (((Y >> 1) & 1) << 3))];
+				v.x = t[0], v.y = t[4096], v.z = t[8192];
 			} else if (LDS == 1) {
 				const float* t = &s_tile[(((i + 4) & 15) * 16 + ((j + 4) & 15)) * 48 + ((kq + 4) & 15) * 3];
 				v.x = t[0], v.y = t[1], v.z = t[2];
@@ -86,18 +109,19 @@ int main() {
 	hipEvent_t e0, e1;
 	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
 	for (int rep = 0; rep < 3; ++rep)
-		for (int v = 0; v < 3; ++v) {
+		for (int v = 0; v < 4; ++v) {
 			float best = 1e9f;
 			for (int t = 0; t < 5; ++t) {
 				(void)hipEventRecord(e0);
-				if (v == 2) hipLaunchKernelGGL(k<2>, dim3(LN * LN * LN), dim3(512), 0, 0, u, out, sh);
+				if (v == 3) hipLaunchKernelGGL(k<3>, dim3(LN * LN * LN), dim3(512), 0, 0, u, out, sh);
+				else if (v == 2) hipLaunchKernelGGL(k<2>, dim3(LN * LN * LN), dim3(512), 0, 0, u, out, sh);
 				else if (v) hipLaunchKernelGGL(k<1>, dim3(LN * LN * LN), dim3(512), 0, 0, u, out, sh);
 				else hipLaunchKernelGGL(k<0>, dim3(LN * LN * LN), dim3(512), 0, 0, u, out, sh);
 				(void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
 				float ms; (void)hipEventElapsedTime(&ms, e0, e1);
 				best = ms < best ? ms : best;
 			}
-			printf("%s: %7.1f us for 256^3 (16 gathers of 12 bytes per voxel + own store)\n", v == 2 ? "L4 taps out of a 16^3 LDS tile of 16-byte voxels (64 KB)" : (v ? "L  taps out of a 16^3 LDS tile (48 KB staged per leaf) " : "G  taps out of global memory (L1)                       "), 1e3 * best);
+			printf("%s: %7.1f us for 256^3 (16 gathers of 12 bytes per voxel + own store)\n", v == 3 ? "S  taps out of three swizzled component planes in LDS (48 KB)" : v == 2 ? "L4 taps out of a 16^3 LDS tile of 16-byte voxels (64 KB)" : (v ? "L  taps out of a 16^3 LDS tile (48 KB staged per leaf) " : "G  taps out of global memory (L1)                       "), 1e3 * best);
 		}
 	return 0;
 }
