@@ -84,6 +84,11 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ u, float* __r
 			} else if (LDS == 1) {
 				const float* t = &s_tile[(((i + 4) & 15) * 16 + ((j + 4) & 15)) * 48 + ((kq + 4) & 15) * 3];
 				v.x = t[0], v.y = t[1], v.z = t[2];
+			} else if (LDS == 4) {  // planar velocity in global memory: three 4-byte gathers per tap
+				const int slot = ((i + 8) >> 3) * 9 + ((j + 8) >> 3) * 3 + ((kq + 8) >> 3);
+				const float* t = u + (size_t)(s_base[slot] + (((i & 7) << 6) | ((j & 7) << 3) | (kq & 7)));
+				constexpr size_t plane = (size_t)LN * LN * LN * 512;
+				v.x = t[0], v.y = t[plane], v.z = t[2 * plane];
 			} else {
 				const int slot = ((i + 8) >> 3) * 9 + ((j + 8) >> 3) * 3 + ((kq + 8) >> 3);
 				const float* t = u + (size_t)(s_base[slot] + (((i & 7) << 6) | ((j & 7) << 3) | (kq & 7))) * 3;
@@ -109,11 +114,12 @@ int main() {
 	hipEvent_t e0, e1;
 	(void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
 	for (int rep = 0; rep < 3; ++rep)
-		for (int v = 0; v < 4; ++v) {
+		for (int v = 0; v < 5; ++v) {
 			float best = 1e9f;
 			for (int t = 0; t < 5; ++t) {
 				(void)hipEventRecord(e0);
-				if (v == 3) hipLaunchKernelGGL(k<3>, dim3(LN * LN * LN), dim3(512), 0, 0, u, out, sh);
+				if (v == 4) hipLaunchKernelGGL(k<4>, dim3(LN * LN * LN), dim3(512), 0, 0, u, out, sh);
+				else if (v == 3) hipLaunchKernelGGL(k<3>, dim3(LN * LN * LN), dim3(512), 0, 0, u, out, sh);
 				else if (v == 2) hipLaunchKernelGGL(k<2>, dim3(LN * LN * LN), dim3(512), 0, 0, u, out, sh);
 				else if (v) hipLaunchKernelGGL(k<1>, dim3(LN * LN * LN), dim3(512), 0, 0, u, out, sh);
 				else hipLaunchKernelGGL(k<0>, dim3(LN * LN * LN), dim3(512), 0, 0, u, out, sh);
@@ -121,7 +127,7 @@ int main() {
 				float ms; (void)hipEventElapsedTime(&ms, e0, e1);
 				best = ms < best ? ms : best;
 			}
-			printf("%s: %7.1f us for 256^3 (16 gathers of 12 bytes per voxel + own store)\n", v == 3 ? "S  taps out of three swizzled component planes in LDS (48 KB)" : v == 2 ? "L4 taps out of a 16^3 LDS tile of 16-byte voxels (64 KB)" : (v ? "L  taps out of a 16^3 LDS tile (48 KB staged per leaf) " : "G  taps out of global memory (L1)                       "), 1e3 * best);
+			printf("%s: %7.1f us for 256^3 (16 gathers of 12 bytes per voxel + own store)\n", v == 4 ? "P  taps out of global memory, planar velocity (3 x 4-byte gathers) " : v == 3 ? "S  taps out of three swizzled component planes in LDS (48 KB)" : v == 2 ? "L4 taps out of a 16^3 LDS tile of 16-byte voxels (64 KB)" : (v ? "L  taps out of a 16^3 LDS tile (48 KB staged per leaf) " : "G  taps out of global memory (L1)                       "), 1e3 * best);
 		}
 	return 0;
 }
