@@ -5,7 +5,7 @@
 //     slot = 9*dx + 3*dy + dz (leaf offset of the tap relative to the workgroup's leaf, each in {0,1,2})
 //     index = s_base[slot] + local offset          (s_base = the 27 neighbour leaves' base indices, staged in LDS)
 // computed once per axis for the two planes of a trilinear stencil and combined for its 8 corners, branch-free. Taps
-// farther than one leaf away (|u| dt/dx > 8) take a generic path through the origin hash; it is wave-divergent but rare.
+// farther than one leaf away (|u| dt/dx > 8) take a generic path -- the neighbour's own neighbour table up to two leaves away, the origin hash beyond; wave-divergent but rare.
 // The arithmetic (Floor, lerp order z->y->x, fused Vec3f lerps, unfused float lerps, weight-product form of
 // advect_scalars, clamp set and order) is the reference's, so results stay bit-identical to the oracle.
 #include <cstdlib>
@@ -121,7 +121,7 @@ __device__ __forceinline__ Taps make_taps(const GridDev& g, const int* s_nbr, co
 		}
 	} else {
 		int any = 0;
-		far_cell_taps(g, i, j, k, T.t);
+		far_cell_taps(g, s_nbr, org, i, j, k, T.t);
 #pragma unroll
 		for (int c = 0; c < 8; ++c) any |= T.t[c];
 		// a multi-GPU rank: a tap beyond the 27-leaf neighbourhood whose leaf is not HERE may exist on another rank (hns_dist reports
@@ -159,7 +159,7 @@ __device__ __forceinline__ TapsB make_taps_b(const GridDev& g, const int* s_nbr,
 		}
 	} else {
 		int any = 0, ft[8];
-		far_cell_taps(g, i, j, k, ft);  // (round 6: one hash walk per distinct leaf under the cell instead of one per corner)
+		far_cell_taps(g, s_nbr, org, i, j, k, ft);  // (round 6: through the neighbour tables up to two leaves away, the hash beyond)
 #pragma unroll
 		for (int c = 0; c < 8; ++c) {
 			any |= ft[c];

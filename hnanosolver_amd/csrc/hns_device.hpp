@@ -44,24 +44,43 @@ __device__ __forceinline__ int tap_index(const GridDev& g, const int* s_nbr, con
 	return leaf < 0 ? -1 : leaf * 512 + (((i & 7) << 6) | ((j & 7) << 3) | (k & 7));
 }
 
-// The eight corners of a trilinear cell whose lower corner (i, j, k) lies beyond the 27-leaf neighbourhood (a back-trace of more than a leaf: |u| dt / dx > 8). The cell
-// spans two leaves along an axis only where the lower corner sits on the last voxel of its leaf: in two cells out of three all eight corners share ONE leaf, so the origin hash is
-// asked once per distinct leaf (1, 2, 4 or 8 dependent probe chains) instead of once per corner. Same leaf ids, same indices as eight calls of tap_index. t[di*4 + dj*2 + dk].
-__device__ __forceinline__ void far_cell_taps(const GridDev& g, int i, int j, int k, int (&t)[8]) {
+// The eight corners of a trilinear cell whose lower corner (i, j, k) lies beyond the 27-leaf neighbourhood of the workgroup's leaf (origin `org`, neighbours `s_nbr` in LDS): a
+// back-trace of more than a leaf, |u| dt / dx > 8. Same leaf ids, same indices as eight calls of tap_index; t[di*4 + dj*2 + dk].
+// Round 6: up to two leaves away (|u| dt / dx < 16: where a fast plume's back-traces land) the leaf comes out of the neighbour tables in TWO HOPS -- the workgroup's own neighbour
+// towards it (LDS), then that neighbour's row of nbr27 (one 4-byte load) -- instead of a walk through the origin hash (hash slot, then the candidate's origin, then the next
+// slot: dependent loads, one walk after the other for the 1, 2, 4 or 8 leaves under the cell). The eight table loads are independent and issued together: one round trip. nbr27 rows
+// are built from the same hash, so the answer is the hash's; the hash is still asked where the intermediate leaf is absent or the cell lies farther out.
+__device__ __forceinline__ void far_cell_taps(const GridDev& g, const int* s_nbr, const int4 org, int i, int j, int k, int (&t)[8]) {
 	const int i0 = i & ~7, j0 = j & ~7, k0 = k & ~7;
-	const bool cx = (i & 7) == 7, cy = (j & 7) == 7, cz = (k & 7) == 7;
+	// leaf offsets, relative to the workgroup's leaf, of the leaf under the lower corner and (where the cell crosses a leaf face: lower corner on the last voxel) the one above it
+	const int ax[2] = {(i0 - org.x) >> 3, ((i0 - org.x) >> 3) + ((i & 7) == 7)}, ay[2] = {(j0 - org.y) >> 3, ((j0 - org.y) >> 3) + ((j & 7) == 7)},
+	          az[2] = {(k0 - org.z) >> 3, ((k0 - org.z) >> 3) + ((k & 7) == 7)};
 	int L[8];
-	L[0] = d_find_leaf(g, i0, j0, k0);
-	L[1] = cz ? d_find_leaf(g, i0, j0, k0 + 8) : L[0];
-	L[2] = cy ? d_find_leaf(g, i0, j0 + 8, k0) : L[0];
-	L[3] = cy ? (cz ? d_find_leaf(g, i0, j0 + 8, k0 + 8) : L[2]) : L[1];
-	if (cx) {
-		L[4] = d_find_leaf(g, i0 + 8, j0, k0);
-		L[5] = cz ? d_find_leaf(g, i0 + 8, j0, k0 + 8) : L[4];
-		L[6] = cy ? d_find_leaf(g, i0 + 8, j0 + 8, k0) : L[4];
-		L[7] = cy ? (cz ? d_find_leaf(g, i0 + 8, j0 + 8, k0 + 8) : L[6]) : L[5];
-	} else {
-		L[4] = L[0], L[5] = L[1], L[6] = L[2], L[7] = L[3];
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		const int a = ax[c >> 2], b = ay[(c >> 1) & 1], d = az[c & 1];
+		const int a1 = max(-1, min(1, a)), b1 = max(-1, min(1, b)), d1 = max(-1, min(1, d));
+		const bool two = max(max(abs(a), abs(b)), abs(d)) <= 2;
+		const int n1 = two ? s_nbr[(a1 + 1) * 9 + (b1 + 1) * 3 + (d1 + 1)] : -1;
+		L[c] = n1 >= 0 ? g.nbr27[n1 * 27 + (a - a1 + 1) * 9 + (b - b1 + 1) * 3 + (d - d1 + 1)] : -2;  // (-2: not in the tables' reach)
+	}
+	bool hash = false;
+#pragma unroll
+	for (int c = 0; c < 8; ++c) hash |= L[c] == -2;
+	if (hash) {  // one walk per DISTINCT leaf under the cell: in two cells out of three all eight corners share one leaf
+		const bool cx = (i & 7) == 7, cy = (j & 7) == 7, cz = (k & 7) == 7;
+		L[0] = d_find_leaf(g, i0, j0, k0);
+		L[1] = cz ? d_find_leaf(g, i0, j0, k0 + 8) : L[0];
+		L[2] = cy ? d_find_leaf(g, i0, j0 + 8, k0) : L[0];
+		L[3] = cy ? (cz ? d_find_leaf(g, i0, j0 + 8, k0 + 8) : L[2]) : L[1];
+		if (cx) {
+			L[4] = d_find_leaf(g, i0 + 8, j0, k0);
+			L[5] = cz ? d_find_leaf(g, i0 + 8, j0, k0 + 8) : L[4];
+			L[6] = cy ? d_find_leaf(g, i0 + 8, j0 + 8, k0) : L[4];
+			L[7] = cy ? (cz ? d_find_leaf(g, i0 + 8, j0 + 8, k0 + 8) : L[6]) : L[5];
+		} else {
+			L[4] = L[0], L[5] = L[1], L[6] = L[2], L[7] = L[3];
+		}
 	}
 #pragma unroll
 	for (int c = 0; c < 8; ++c) {
