@@ -302,6 +302,49 @@ __device__ __forceinline__ unsigned halo_off(const unsigned* s_b4, int h) {
 	return s_b4[slot] + ((unsigned)local << 2);
 }
 
+// ---- the leaf and ONE voxel around it as a 10 x 10 x 10 box in LDS (round 6) ------------------------------------------------------------------
+// BFECC's second sample is taken at back + u(back) * s, which is the voxel's own position up to s * (u(back) - u(own)): a fraction of a voxel wherever the
+// velocity is smooth. Its eight taps then lie among the voxel and its 26 neighbours -- values the workgroup holds anyway once the tile the clamp needs
+// (own leaf + six face layers, 896 voxels) is completed by the twelve edges and eight corners (104 more). Where the sample lands inside the box the kernel reads
+// the second sample's taps from LDS: 8 of the kernel's 17 gathers (26 L1 tag lookups per wave each, the unit that bounds it: profiles/floors.py) are gone
+// for 12 % more staging. Outside (a steep velocity gradient) the taps are gathered as before. Same values, same arithmetic: bit-identical.
+// Box cell of voxel (x, y, z) relative to the leaf origin, each in [-1, 8]: ((x + 1) * 10 + y + 1) * 10 + z + 1; three component planes of kBox floats.
+constexpr int kBox = 1000, kBoxShell = kBox - 512;
+// shell cell h in [0, 488): the two full x-slabs (2 x 100), the y = -1 / 8 rows of the inner x (2 x 80), the z = -1 / 8 ends of the inner rows (2 x 64):
+// slot of its leaf in the 27-table, voxel inside that leaf, box cell
+__device__ __forceinline__ void box_shell_entry(int h, int& slot, int& local, int& cell) {
+	int bx, by, bz;
+	if (h < 200) {
+		const int side = h >= 100, r = h - 100 * side;
+		bx = 9 * side, by = r / 10, bz = r - 10 * by;
+	} else if (h < 360) {
+		const int q = h - 200, side = q >= 80, r = q - 80 * side;
+		bx = 1 + r / 10, by = 9 * side, bz = r - 10 * (bx - 1);
+	} else {
+		const int q = h - 360, side = q >> 6, r = q & 63;
+		bx = 1 + (r >> 3), by = 1 + (r & 7), bz = 9 * side;
+	}
+	slot = ((bx + 7) >> 3) * 9 + ((by + 7) >> 3) * 3 + ((bz + 7) >> 3);
+	local = (((bx + 7) & 7) << 6) | (((by + 7) & 7) << 3) | ((bz + 7) & 7);
+	cell = (bx * 10 + by) * 10 + bz;
+}
+__device__ __forceinline__ V3 box_v3(const float* s_box, int a) {
+	V3 r;
+	r.xy = v2f32{s_box[a], s_box[a + kBox]};
+	r.z = s_box[a + 2 * kBox];
+	return r;
+}
+// TrilinearSampler over the box: a = cell of the lower corner
+__device__ __forceinline__ f3 tri_v_box(const float* s_box, int a, float fx, float fy, float fz) {
+	V3 c[8];
+#pragma unroll
+	for (int q = 0; q < 8; ++q) c[q] = box_v3(s_box, a + (q >> 2) * 100 + ((q >> 1) & 1) * 10 + (q & 1));
+	const V3 z0 = lerp_v3(c[0], c[1], fz), z1 = lerp_v3(c[2], c[3], fz), z2 = lerp_v3(c[4], c[5], fz), z3 = lerp_v3(c[6], c[7], fz);
+	const V3 y0 = lerp_v3(z0, z1, fy), y1 = lerp_v3(z2, z3, fy);
+	const V3 r = lerp_v3(y0, y1, fx);
+	return f3{r.xy.x, r.xy.y, r.z};
+}
+
 // 32-bit addressed form (no collision field): same loads and arithmetic as the generic kernel below
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_advect_vector_n(const GridDev g, const float* __restrict__ u, float* __restrict__ out, const float scaled_dt) {
 	__shared__ int s_nbr[27];
@@ -319,18 +362,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4, s_b4p, leaf);
 	const float px = (float)(L.org.x + (n >> 6)), py = (float)(L.org.y + ((n >> 3) & 7)), pz = (float)(L.org.z + (n & 7));
 
-	__shared__ float s_tile[kTile * 3];
-	s_tile[3 * n] = vo.x, s_tile[3 * n + 1] = vo.y, s_tile[3 * n + 2] = vo.z;
-	if (n < 384) {
-		const f3 h = ldv(ru, halo_off(s_b4, n));
-		s_tile[3 * (512 + n)] = h.x, s_tile[3 * (512 + n) + 1] = h.y, s_tile[3 * (512 + n) + 2] = h.z;
+	__shared__ float s_box[3 * kBox];
+	const int ob = (((n >> 6) + 1) * 10 + ((n >> 3) & 7) + 1) * 10 + (n & 7) + 1;
+	s_box[ob] = vo.x, s_box[ob + kBox] = vo.y, s_box[ob + 2 * kBox] = vo.z;
+	if (n < kBoxShell) {
+		int slot, local, cell;
+		box_shell_entry(n, slot, local, cell);
+		const f3 h = ldv(ru, s_b4[slot] + ((unsigned)local << 2));
+		s_box[cell] = h.x, s_box[cell + kBox] = h.y, s_box[cell + 2 * kBox] = h.z;
 	}
 	float sx = px - scaled_dt * vo.x, sy = py - scaled_dt * vo.y, sz = pz - scaled_dt * vo.z;  // backPos (Kernel.cu:374)
 	f3 vf = {0.0f, 0.0f, 0.0f}, vb = {0.0f, 0.0f, 0.0f};
 #pragma unroll 1
 	for (int pass = 0; pass < 2; ++pass) {
-		const TapsB T = make_taps_b(g, s_nbr, s_b4p, L.org, sx, sy, sz);
-		const f3 v = tri_v_b(ru, T);
+		if (pass) __syncthreads();  // box complete (the first sample's gathers had the memory system to themselves)
+		const int i = __float2int_rd(sx), j = __float2int_rd(sy), k = __float2int_rd(sz);
+		const unsigned rx = (unsigned)(i - (L.org.x - 1)), ry = (unsigned)(j - (L.org.y - 1)), rz = (unsigned)(k - (L.org.z - 1));  // cell and cell + 1 inside the box <=> each in [0, 8]
+		f3 v;
+		if (pass && __all(max(rx, max(ry, rz)) <= 8u)) {  // (per WAVE here: with a lane outside, all of them gather -- measured 2.4 % faster through the plume's transient than a per-lane split; advect_scalars splits per lane)
+			v = tri_v_box(s_box, (int)((rx * 10u + ry) * 10u + rz), sx - (float)i, sy - (float)j, sz - (float)k);
+		} else {
+			const TapsB T = make_taps_b(g, s_nbr, s_b4p, L.org, sx, sy, sz);
+			v = tri_v_b(ru, T);
+		}
 		if (pass == 0) {
 			vf = v;
 			sx = sx + scaled_dt * v.x, sy = sy + scaled_dt * v.y, sz = sz + scaled_dt * v.z;  // Kernel.cu:387
@@ -339,18 +393,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 		}
 	}
 	f3 vc = {vf.x + 0.5f * (vo.x - vb.x), vf.y + 0.5f * (vo.y - vb.y), vf.z + 0.5f * (vo.z - vb.z)};
-	__syncthreads();  // tile complete (the gathers above had the memory system to themselves)
-	const int e[6] = {tile_nbr<0, -1>(n), tile_nbr<0, 1>(n), tile_nbr<1, -1>(n), tile_nbr<1, 1>(n), tile_nbr<2, -1>(n), tile_nbr<2, 1>(n)};
+	const int e[6] = {ob - 100, ob + 100, ob - 10, ob + 10, ob - 1, ob + 1};
 	f3 mn = vo, mx = vo;
 #pragma unroll
 	for (int d = 0; d < 6; ++d) {
-		const f3 nv = {s_tile[3 * e[d]], s_tile[3 * e[d] + 1], s_tile[3 * e[d] + 2]};
-		mn.x = fminf(mn.x, nv.x);
-		mx.x = fmaxf(mx.x, nv.x);
-		mn.y = fminf(mn.y, nv.y);
-		mx.y = fmaxf(mx.y, nv.y);
-		mn.z = fminf(mn.z, nv.z);
-		mx.z = fmaxf(mx.z, nv.z);
+		const V3 t = box_v3(s_box, e[d]);
+		mn.x = fminf(mn.x, t.xy.x);
+		mx.x = fmaxf(mx.x, t.xy.x);
+		mn.y = fminf(mn.y, t.xy.y);
+		mx.y = fmaxf(mx.y, t.xy.y);
+		mn.z = fminf(mn.z, t.z);
+		mx.z = fmaxf(mx.z, t.z);
 	}
 	mn.x = fminf(mn.x, vf.x);
 	mx.x = fmaxf(mx.x, vf.x);
@@ -615,26 +668,48 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
 		vf.y = vf.y + bw[q] * v.y;
 		vf.z = vf.z + bw[q] * v.z;
 	}
+	// The second sample point is the voxel's own position up to s * (u(back) - u(own)): where it lands inside the leaf's 10^3 box (k_advect_vector_n, which see)
+	// the fields' forward taps are read from the LDS box that the clamp needs anyway, not gathered
+	const float qx = bx + scaled_dt * vf.x, qy = by + scaled_dt * vf.y, qz = bz + scaled_dt * vf.z;
+	const int qi = __float2int_rd(qx), qj = __float2int_rd(qy), qk = __float2int_rd(qz);
+	const unsigned rx = (unsigned)(qi - (L.org.x - 1)), ry = (unsigned)(qj - (L.org.y - 1)), rz = (unsigned)(qk - (L.org.z - 1));
+	const bool boxed = max(rx, max(ry, rz)) <= 8u;  // (per lane)
+	const int fa = boxed ? (int)((rx * 10u + ry) * 10u + rz) : 0;  // box cell of the forward cell's lower corner
 	{
-		const TapsB T = make_taps_b(g, s_nbr, s_b4p, L.org, bx + scaled_dt * vf.x, by + scaled_dt * vf.y, bz + scaled_dt * vf.z);
-		const float tx = T.fx, ty = T.fy, tz = T.fz, itx = 1.0f - tx, ity = 1.0f - ty, itz = 1.0f - tz;
+		float tx, ty, tz;
+		if (boxed) {
+			tx = qx - (float)qi, ty = qy - (float)qj, tz = qz - (float)qk;  // (make_taps_b's fractions)
+#pragma unroll
+			for (int q = 0; q < 8; ++q) fo[q] = 0u;
+		} else {
+			const TapsB T = make_taps_b(g, s_nbr, s_b4p, L.org, qx, qy, qz);
+			tx = T.fx, ty = T.fy, tz = T.fz;
+#pragma unroll
+			for (int q = 0; q < 8; ++q) fo[q] = T.o[perm[q]] >= kOutside ? oob4 : T.o[perm[q]];
+		}
+		const float itx = 1.0f - tx, ity = 1.0f - ty, itz = 1.0f - tz;
 		const float w00 = itx * ity, w10 = tx * ity, w01 = itx * ty, w11 = tx * ty;
 		fw[0] = w00 * itz, fw[1] = w10 * itz, fw[2] = w01 * itz, fw[3] = w11 * itz, fw[4] = w00 * tz, fw[5] = w10 * tz, fw[6] = w01 * tz, fw[7] = w11 * tz;
-#pragma unroll
-		for (int q = 0; q < 8; ++q) fo[q] = T.o[perm[q]] >= kOutside ? oob4 : T.o[perm[q]];
 	}
-	// clamp neighbours through LDS (see k_advect_vector_n): per field one own value per thread and one halo value per thread
-	// of the first six waves; two tiles alternate so that one barrier per field suffices
-	__shared__ float s_tile[2][kTile];
-	const int e[6] = {tile_nbr<0, -1>(n), tile_nbr<0, 1>(n), tile_nbr<1, -1>(n), tile_nbr<1, 1>(n), tile_nbr<2, -1>(n), tile_nbr<2, 1>(n)};
-	unsigned ho = n < 384 ? halo_off(s_b4, n) : 0u;
+	// the leaf and one voxel around it through LDS (see k_advect_vector_n): per field one own value per thread and one shell value per thread of the first 488; two boxes
+	// alternate so that one barrier per field suffices. Corner q of the interpolation order (x fastest: perm) sits at box offset (q & 1) * 100 + ((q >> 1) & 1) * 10 + (q >> 2).
+	__shared__ float s_box[2][kBox];
+	const int ob = (((n >> 6) + 1) * 10 + ((n >> 3) & 7) + 1) * 10 + (n & 7) + 1;
+	const int e[6] = {ob - 100, ob + 100, ob - 10, ob + 10, ob - 1, ob + 1};
+	unsigned ho = 0u;
+	int hcell = 0;
+	if (n < kBoxShell) {
+		int slot, local;
+		box_shell_entry(n, slot, local, hcell);
+		ho = s_b4[slot] + ((unsigned)local << 2);
+	}
 	ho = ho >= kOutside ? oob4 : ho;  // out-of-domain neighbours read element g.oob here (Kernel.cu:225)
 	if constexpr (Q4) {
-		__shared__ v4f32 s_tile4[kTile];
+		__shared__ v4f32 s_box4[kBox];
 		const v4i rq = field_rsrc(P.q4, bytes1 * 4u);  // element = 16 bytes: byte offset = 4 x the float-field byte offset
 		const v4f32 phiOrig = hns_buffer_load_v4f32(rq, (int)(own << 2), 0, 0);
-		s_tile4[n] = phiOrig;
-		if (n < 384) s_tile4[512 + n] = hns_buffer_load_v4f32(rq, (int)(ho << 2), 0, 0);
+		s_box4[ob] = phiOrig;
+		if (n < kBoxShell) s_box4[hcell] = hns_buffer_load_v4f32(rq, (int)(ho << 2), 0, 0);
 		v4f32 phiF = {0.0f, 0.0f, 0.0f, 0.0f}, phiB = {0.0f, 0.0f, 0.0f, 0.0f};
 		{
 			v4f32 c[8];
@@ -643,20 +718,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
 #pragma unroll
 			for (int q = 0; q < 8; ++q) phiF = __builtin_elementwise_fma(c[q], v4f32{bw[q], bw[q], bw[q], bw[q]}, phiF);
 		}
-		{
+		if (!boxed) {
 			v4f32 c[8];
 #pragma unroll
 			for (int q = 0; q < 8; ++q) c[q] = hns_buffer_load_v4f32(rq, (int)(fo[q] << 2), 0, 0);
 #pragma unroll
 			for (int q = 0; q < 8; ++q) phiB = __builtin_elementwise_fma(c[q], v4f32{fw[q], fw[q], fw[q], fw[q]}, phiB);
 		}
+		__syncthreads();
+		if (boxed) {
+#pragma unroll
+			for (int q = 0; q < 8; ++q) phiB = __builtin_elementwise_fma(s_box4[fa + (q & 1) * 100 + ((q >> 1) & 1) * 10 + (q >> 2)], v4f32{fw[q], fw[q], fw[q], fw[q]}, phiB);
+		}
 		const v4f32 error = phiOrig - phiB;
 		const v4f32 phiCorr = __builtin_elementwise_fma(v4f32{0.5f, 0.5f, 0.5f, 0.5f}, error, phiF);
-		__syncthreads();
 		v4f32 mn = phiOrig, mx = phiOrig;
 #pragma unroll
 		for (int d = 0; d < 6; ++d) {
-			const v4f32 v = s_tile4[e[d]];
+			const v4f32 v = s_box4[e[d]];
 			mn = __builtin_elementwise_min(mn, v);
 			mx = __builtin_elementwise_max(mx, v);
 		}
@@ -667,29 +746,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
 	}
 	for (int s = 0; s < P.n; ++s) {
 		const v4i rf = field_rsrc(P.in[s], bytes1);
-		float* tile = s_tile[s & 1];
+		float* box = s_box[s & 1];
 		const float phiOrig = lds1(rf, own);
-		tile[n] = phiOrig;
-		if (n < 384) tile[512 + n] = lds1(rf, ho);
+		box[ob] = phiOrig;
+		if (n < kBoxShell) box[hcell] = lds1(rf, ho);
 		float vb[8], vf8[8];  // corner q and q+4 of the interpolation order differ only in z
 #pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			ld_zpair(rf, bo[q], bo[q + 4], vb[q], vb[q + 4]);
-			ld_zpair(rf, fo[q], fo[q + 4], vf8[q], vf8[q + 4]);
+		for (int q = 0; q < 4; ++q) ld_zpair(rf, bo[q], bo[q + 4], vb[q], vb[q + 4]);
+		if (!boxed) {
+#pragma unroll
+			for (int q = 0; q < 4; ++q) ld_zpair(rf, fo[q], fo[q + 4], vf8[q], vf8[q + 4]);
 		}
 		float phiF = 0.0f, phiB = 0.0f;
 #pragma unroll
-		for (int q = 0; q < 8; ++q) {
-			phiF = __fmaf_rn(vb[q], bw[q], phiF);
-			phiB = __fmaf_rn(vf8[q], fw[q], phiB);
+		for (int q = 0; q < 8; ++q) phiF = __fmaf_rn(vb[q], bw[q], phiF);
+		__syncthreads();
+		if (boxed) {
+#pragma unroll
+			for (int q = 0; q < 8; ++q) vf8[q] = box[fa + (q & 1) * 100 + ((q >> 1) & 1) * 10 + (q >> 2)];
 		}
+#pragma unroll
+		for (int q = 0; q < 8; ++q) phiB = __fmaf_rn(vf8[q], fw[q], phiB);
 		const float error = phiOrig - phiB;
 		const float phiCorr = __fmaf_rn(0.5f, error, phiF);
-		__syncthreads();
 		float mn = phiOrig, mx = phiOrig;
 #pragma unroll
 		for (int d = 0; d < 6; ++d) {
-			const float v = tile[e[d]];
+			const float v = box[e[d]];
 			mn = fminf(mn, v);
 			mx = fmaxf(mx, v);
 		}
