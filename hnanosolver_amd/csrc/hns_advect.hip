@@ -373,13 +373,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 	}
 	float sx = px - scaled_dt * vo.x, sy = py - scaled_dt * vo.y, sz = pz - scaled_dt * vo.z;  // backPos (Kernel.cu:374)
 	f3 vf = {0.0f, 0.0f, 0.0f}, vb = {0.0f, 0.0f, 0.0f};
+	__syncthreads();  // box complete
 #pragma unroll 1
 	for (int pass = 0; pass < 2; ++pass) {
-		if (pass) __syncthreads();  // box complete (the first sample's gathers had the memory system to themselves)
 		const int i = __float2int_rd(sx), j = __float2int_rd(sy), k = __float2int_rd(sz);
 		const unsigned rx = (unsigned)(i - (L.org.x - 1)), ry = (unsigned)(j - (L.org.y - 1)), rz = (unsigned)(k - (L.org.z - 1));  // cell and cell + 1 inside the box <=> each in [0, 8]
 		f3 v;
-		if (pass && __all(max(rx, max(ry, rz)) <= 8u)) {  // (per WAVE here: with a lane outside, all of them gather -- measured 2.4 % faster through the plume's transient than a per-lane split; advect_scalars splits per lane)
+		// (either sample: the FIRST one too lands in the box where the flow moves less than a voxel per step -- then the wave gathers nothing at all. Per WAVE here: with a lane
+		// outside, all of them gather -- measured 2.4 % faster through the plume's transient than a per-lane split; advect_scalars splits per lane)
+		if (__all(max(rx, max(ry, rz)) <= 8u)) {
 			v = tri_v_box(s_box, (int)((rx * 10u + ry) * 10u + rz), sx - (float)i, sy - (float)j, sz - (float)k);
 		} else {
 			const TapsB T = make_taps_b(g, s_nbr, s_b4p, L.org, sx, sy, sz);
@@ -633,7 +635,7 @@ __device__ __forceinline__ void interp_from_taps(const Taps& T, int oob, int (&i
 // gathers for the four fields' two samples instead of thirty-two. Per field the arithmetic is the same chain of fused multiply-adds in the same order.
 // (at least four waves per SIMD = two workgroups per CU: the Q4 form sits at the 128-register line, and one register over it is ONE workgroup per CU -- 585 -> 838 us at 256^3, measured)
 template <bool Q4>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k_advect_scalars_n(const GridDev g, const float* __restrict__ u, const ScalarPtrs P, const float scaled_dt) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Q4 ? 6 : 4))) void k_advect_scalars_n(const GridDev g, const float* __restrict__ u, const ScalarPtrs P, const float scaled_dt) {
 	__shared__ int s_nbr[27];
 	__shared__ int s_base[27];
 	__shared__ unsigned s_b4[27];
@@ -648,25 +650,74 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
 	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4, s_b4p, leaf);
 	const float px = (float)(L.org.x + (n >> 6)), py = (float)(L.org.y + ((n >> 3) & 7)), pz = (float)(L.org.z + (n & 7));
 
+	// the leaf and one voxel around it through LDS (see k_advect_vector_n): the velocity once, then per field; shell cell of this thread (the first 488) and where its value lies
+	const int ob = (((n >> 6) + 1) * 10 + ((n >> 3) & 7) + 1) * 10 + (n & 7) + 1;
+	const int e[6] = {ob - 100, ob + 100, ob - 10, ob + 10, ob - 1, ob + 1};
+	unsigned ho = 0u;
+	int hcell = 0;
+	if (n < kBoxShell) {
+		int slot, local;
+		box_shell_entry(n, slot, local, hcell);
+		ho = s_b4[slot] + ((unsigned)local << 2);
+	}
+	ho = ho >= kOutside ? oob4 : ho;  // out-of-domain neighbours read element g.oob here (Kernel.cu:225)
+	// FIRST: the first sample's taps out of the boxes too (below). Measured (profiles/r06_advect_box_ab.txt): it pays in the q4 form, which then fits 80 registers = six waves per SIMD,
+	// and costs the float-only form a fifth (one more 12-byte gather per thread for the velocity shell, and a barrier in front of its first gathers)
+	constexpr bool FIRST = Q4;
+	__shared__ float s_ubox[FIRST ? 3 * kBox : 1];
+	if constexpr (FIRST) {
+		s_ubox[ob] = vc.x, s_ubox[ob + kBox] = vc.y, s_ubox[ob + 2 * kBox] = vc.z;
+		if (n < kBoxShell) {
+			const f3 h = ldv(ru, ho);
+			s_ubox[hcell] = h.x, s_ubox[hcell + kBox] = h.y, s_ubox[hcell + 2 * kBox] = h.z;
+		}
+	}
+
 	const float bx = px - scaled_dt * vc.x, by = py - scaled_dt * vc.y, bz = pz - scaled_dt * vc.z;
 	unsigned bo[8], fo[8];
 	float bw[8], fw[8];
 	const int perm[8] = {0, 4, 2, 6, 1, 5, 3, 7};  // setupInterpolation's order 000,100,010,110,001,... of (x,y,z) (Kernel.cu:163-196)
+	// Where the flow moves less than a voxel per step the FIRST sample point, too, lies among the voxel's 26 neighbours: its taps (velocity here, the fields' below) come out of
+	// the boxes, per lane. Corner q of the interpolation order (x fastest: perm) sits at box offset (q & 1) * 100 + ((q >> 1) & 1) * 10 + (q >> 2).
+	const int bi = __float2int_rd(bx), bj = __float2int_rd(by), bk = __float2int_rd(bz);
+	const unsigned sx_ = (unsigned)(bi - (L.org.x - 1)), sy_ = (unsigned)(bj - (L.org.y - 1)), sz_ = (unsigned)(bk - (L.org.z - 1));
+	const bool bboxed = FIRST && max(sx_, max(sy_, sz_)) <= 8u;
+	const int ba = bboxed ? (int)((sx_ * 10u + sy_) * 10u + sz_) : 0;  // box cell of the back cell's lower corner
 	{
-		const TapsB T = make_taps_b(g, s_nbr, s_b4p, L.org, bx, by, bz);
-		const float tx = T.fx, ty = T.fy, tz = T.fz, itx = 1.0f - tx, ity = 1.0f - ty, itz = 1.0f - tz;
+		float tx, ty, tz;
+		if (bboxed) {
+			tx = bx - (float)bi, ty = by - (float)bj, tz = bz - (float)bk;  // (make_taps_b's fractions)
+#pragma unroll
+			for (int q = 0; q < 8; ++q) bo[q] = 0u;
+		} else {
+			const TapsB T = make_taps_b(g, s_nbr, s_b4p, L.org, bx, by, bz);
+			tx = T.fx, ty = T.fy, tz = T.fz;
+#pragma unroll
+			for (int q = 0; q < 8; ++q) bo[q] = T.o[perm[q]] >= kOutside ? oob4 : T.o[perm[q]];
+		}
+		const float itx = 1.0f - tx, ity = 1.0f - ty, itz = 1.0f - tz;
 		const float w00 = itx * ity, w10 = tx * ity, w01 = itx * ty, w11 = tx * ty;
 		bw[0] = w00 * itz, bw[1] = w10 * itz, bw[2] = w01 * itz, bw[3] = w11 * itz, bw[4] = w00 * tz, bw[5] = w10 * tz, bw[6] = w01 * tz, bw[7] = w11 * tz;
+	}
+	f3 vt[8];
+	if (!bboxed) {
 #pragma unroll
-		for (int q = 0; q < 8; ++q) bo[q] = T.o[perm[q]] >= kOutside ? oob4 : T.o[perm[q]];
+		for (int q = 0; q < 8; ++q) vt[q] = ldv(ru, bo[q]);
+	}
+	if constexpr (FIRST) __syncthreads();  // velocity box complete
+	if (bboxed) {
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			const int a = ba + (q & 1) * 100 + ((q >> 1) & 1) * 10 + (q >> 2);
+			vt[q] = f3{s_ubox[a], s_ubox[a + kBox], s_ubox[a + 2 * kBox]};
+		}
 	}
 	f3 vf = {0.0f, 0.0f, 0.0f};
 #pragma unroll
 	for (int q = 0; q < 8; ++q) {  // velF = velF + v * w (Kernel.cu:201-206), unfused
-		const f3 v = ldv(ru, bo[q]);
-		vf.x = vf.x + bw[q] * v.x;
-		vf.y = vf.y + bw[q] * v.y;
-		vf.z = vf.z + bw[q] * v.z;
+		vf.x = vf.x + bw[q] * vt[q].x;
+		vf.y = vf.y + bw[q] * vt[q].y;
+		vf.z = vf.z + bw[q] * vt[q].z;
 	}
 	// The second sample point is the voxel's own position up to s * (u(back) - u(own)): where it lands inside the leaf's 10^3 box (k_advect_vector_n, which see)
 	// the fields' forward taps are read from the LDS box that the clamp needs anyway, not gathered
@@ -691,19 +742,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
 		const float w00 = itx * ity, w10 = tx * ity, w01 = itx * ty, w11 = tx * ty;
 		fw[0] = w00 * itz, fw[1] = w10 * itz, fw[2] = w01 * itz, fw[3] = w11 * itz, fw[4] = w00 * tz, fw[5] = w10 * tz, fw[6] = w01 * tz, fw[7] = w11 * tz;
 	}
-	// the leaf and one voxel around it through LDS (see k_advect_vector_n): per field one own value per thread and one shell value per thread of the first 488; two boxes
-	// alternate so that one barrier per field suffices. Corner q of the interpolation order (x fastest: perm) sits at box offset (q & 1) * 100 + ((q >> 1) & 1) * 10 + (q >> 2).
+	// per field one own value per thread and one shell value per thread of the first 488; two boxes alternate so that one barrier per field suffices
 	__shared__ float s_box[2][kBox];
-	const int ob = (((n >> 6) + 1) * 10 + ((n >> 3) & 7) + 1) * 10 + (n & 7) + 1;
-	const int e[6] = {ob - 100, ob + 100, ob - 10, ob + 10, ob - 1, ob + 1};
-	unsigned ho = 0u;
-	int hcell = 0;
-	if (n < kBoxShell) {
-		int slot, local;
-		box_shell_entry(n, slot, local, hcell);
-		ho = s_b4[slot] + ((unsigned)local << 2);
-	}
-	ho = ho >= kOutside ? oob4 : ho;  // out-of-domain neighbours read element g.oob here (Kernel.cu:225)
 	if constexpr (Q4) {
 		__shared__ v4f32 s_box4[kBox];
 		const v4i rq = field_rsrc(P.q4, bytes1 * 4u);  // element = 16 bytes: byte offset = 4 x the float-field byte offset
@@ -711,7 +751,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
 		s_box4[ob] = phiOrig;
 		if (n < kBoxShell) s_box4[hcell] = hns_buffer_load_v4f32(rq, (int)(ho << 2), 0, 0);
 		v4f32 phiF = {0.0f, 0.0f, 0.0f, 0.0f}, phiB = {0.0f, 0.0f, 0.0f, 0.0f};
-		{
+		if (!bboxed) {
 			v4f32 c[8];
 #pragma unroll
 			for (int q = 0; q < 8; ++q) c[q] = hns_buffer_load_v4f32(rq, (int)(bo[q] << 2), 0, 0);
@@ -726,6 +766,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
 			for (int q = 0; q < 8; ++q) phiB = __builtin_elementwise_fma(c[q], v4f32{fw[q], fw[q], fw[q], fw[q]}, phiB);
 		}
 		__syncthreads();
+		if (bboxed) {
+#pragma unroll
+			for (int q = 0; q < 8; ++q) phiF = __builtin_elementwise_fma(s_box4[ba + (q & 1) * 100 + ((q >> 1) & 1) * 10 + (q >> 2)], v4f32{bw[q], bw[q], bw[q], bw[q]}, phiF);
+		}
 		if (boxed) {
 #pragma unroll
 			for (int q = 0; q < 8; ++q) phiB = __builtin_elementwise_fma(s_box4[fa + (q & 1) * 100 + ((q >> 1) & 1) * 10 + (q >> 2)], v4f32{fw[q], fw[q], fw[q], fw[q]}, phiB);
@@ -751,16 +795,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
 		box[ob] = phiOrig;
 		if (n < kBoxShell) box[hcell] = lds1(rf, ho);
 		float vb[8], vf8[8];  // corner q and q+4 of the interpolation order differ only in z
+		if (!bboxed) {
 #pragma unroll
-		for (int q = 0; q < 4; ++q) ld_zpair(rf, bo[q], bo[q + 4], vb[q], vb[q + 4]);
+			for (int q = 0; q < 4; ++q) ld_zpair(rf, bo[q], bo[q + 4], vb[q], vb[q + 4]);
+		}
 		if (!boxed) {
 #pragma unroll
 			for (int q = 0; q < 4; ++q) ld_zpair(rf, fo[q], fo[q + 4], vf8[q], vf8[q + 4]);
 		}
 		float phiF = 0.0f, phiB = 0.0f;
+		__syncthreads();
+		if (bboxed) {
+#pragma unroll
+			for (int q = 0; q < 8; ++q) vb[q] = box[ba + (q & 1) * 100 + ((q >> 1) & 1) * 10 + (q >> 2)];
+		}
 #pragma unroll
 		for (int q = 0; q < 8; ++q) phiF = __fmaf_rn(vb[q], bw[q], phiF);
-		__syncthreads();
 		if (boxed) {
 #pragma unroll
 			for (int q = 0; q < 8; ++q) vf8[q] = box[fa + (q & 1) * 100 + ((q >> 1) & 1) * 10 + (q >> 2)];
