@@ -310,8 +310,12 @@ __device__ __forceinline__ unsigned halo_off(const unsigned* s_b4, int h) {
 // for 12 % more staging. Outside (a steep velocity gradient) the taps are gathered as before. Same values, same arithmetic: bit-identical.
 // Box cell of voxel (x, y, z) relative to the leaf origin, each in [-1, 8]: ((x + 1) * 10 + y + 1) * 10 + z + 1; three component planes of kBox floats.
 constexpr int kBox = 1000, kBoxShell = kBox - 512;
+// k_advect_vector_n pads its rows from 10 to 24 floats (kVY; a plane = kVP floats): a wave's taps are an 8 (y) x 8 (z) window of one x-slice, and with rows 24 apart the four rows of
+// a 32-lane group fall on banks c, c + 24, c + 16, c + 8 (+ 0..7): every bank once. With rows 10 apart six lanes of every group collide (46 % of the kernel's LDS cycles were conflicts).
+constexpr int kVY = 24, kVX = 10 * kVY, kVP = 10 * kVX;
 // shell cell h in [0, 488): the two full x-slabs (2 x 100), the y = -1 / 8 rows of the inner x (2 x 80), the z = -1 / 8 ends of the inner rows (2 x 64):
 // slot of its leaf in the 27-table, voxel inside that leaf, box cell
+template <int XS = 100, int YS = 10>  // strides of the box the cell number is for
 __device__ __forceinline__ void box_shell_entry(int h, int& slot, int& local, int& cell) {
 	int bx, by, bz;
 	if (h < 200) {
@@ -326,19 +330,19 @@ __device__ __forceinline__ void box_shell_entry(int h, int& slot, int& local, in
 	}
 	slot = ((bx + 7) >> 3) * 9 + ((by + 7) >> 3) * 3 + ((bz + 7) >> 3);
 	local = (((bx + 7) & 7) << 6) | (((by + 7) & 7) << 3) | ((bz + 7) & 7);
-	cell = (bx * 10 + by) * 10 + bz;
+	cell = bx * XS + by * YS + bz;
 }
 __device__ __forceinline__ V3 box_v3(const float* s_box, int a) {
 	V3 r;
-	r.xy = v2f32{s_box[a], s_box[a + kBox]};
-	r.z = s_box[a + 2 * kBox];
+	r.xy = v2f32{s_box[a], s_box[a + kVP]};
+	r.z = s_box[a + 2 * kVP];
 	return r;
 }
 // TrilinearSampler over the box: a = cell of the lower corner
 __device__ __forceinline__ f3 tri_v_box(const float* s_box, int a, float fx, float fy, float fz) {
 	V3 c[8];
 #pragma unroll
-	for (int q = 0; q < 8; ++q) c[q] = box_v3(s_box, a + (q >> 2) * 100 + ((q >> 1) & 1) * 10 + (q & 1));
+	for (int q = 0; q < 8; ++q) c[q] = box_v3(s_box, a + (q >> 2) * kVX + ((q >> 1) & 1) * kVY + (q & 1));
 	const V3 z0 = lerp_v3(c[0], c[1], fz), z1 = lerp_v3(c[2], c[3], fz), z2 = lerp_v3(c[4], c[5], fz), z3 = lerp_v3(c[6], c[7], fz);
 	const V3 y0 = lerp_v3(z0, z1, fy), y1 = lerp_v3(z2, z3, fy);
 	const V3 r = lerp_v3(y0, y1, fx);
@@ -362,14 +366,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 	const LeafCtx L = stage_leaf_base(g, s_nbr, s_base, blockIdx.x, s_b4, s_b4p, leaf);
 	const float px = (float)(L.org.x + (n >> 6)), py = (float)(L.org.y + ((n >> 3) & 7)), pz = (float)(L.org.z + (n & 7));
 
-	__shared__ float s_box[3 * kBox];
-	const int ob = (((n >> 6) + 1) * 10 + ((n >> 3) & 7) + 1) * 10 + (n & 7) + 1;
-	s_box[ob] = vo.x, s_box[ob + kBox] = vo.y, s_box[ob + 2 * kBox] = vo.z;
+	__shared__ float s_box[3 * kVP];
+	const int ob = ((n >> 6) + 1) * kVX + (((n >> 3) & 7) + 1) * kVY + (n & 7) + 1;
+	s_box[ob] = vo.x, s_box[ob + kVP] = vo.y, s_box[ob + 2 * kVP] = vo.z;
 	if (n < kBoxShell) {
 		int slot, local, cell;
-		box_shell_entry(n, slot, local, cell);
+		box_shell_entry<kVX, kVY>(n, slot, local, cell);
 		const f3 h = ldv(ru, s_b4[slot] + ((unsigned)local << 2));
-		s_box[cell] = h.x, s_box[cell + kBox] = h.y, s_box[cell + 2 * kBox] = h.z;
+		s_box[cell] = h.x, s_box[cell + kVP] = h.y, s_box[cell + 2 * kVP] = h.z;
 	}
 	float sx = px - scaled_dt * vo.x, sy = py - scaled_dt * vo.y, sz = pz - scaled_dt * vo.z;  // backPos (Kernel.cu:374)
 	f3 vf = {0.0f, 0.0f, 0.0f}, vb = {0.0f, 0.0f, 0.0f};
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 		// (either sample: the FIRST one too lands in the box where the flow moves less than a voxel per step -- then the wave gathers nothing at all. Per WAVE here: with a lane
 		// outside, all of them gather -- measured 2.4 % faster through the plume's transient than a per-lane split; advect_scalars splits per lane)
 		if (__all(max(rx, max(ry, rz)) <= 8u)) {
-			v = tri_v_box(s_box, (int)((rx * 10u + ry) * 10u + rz), sx - (float)i, sy - (float)j, sz - (float)k);
+			v = tri_v_box(s_box, (int)(rx * (unsigned)kVX + ry * (unsigned)kVY + rz), sx - (float)i, sy - (float)j, sz - (float)k);
 		} else {
 			const TapsB T = make_taps_b(g, s_nbr, s_b4p, L.org, sx, sy, sz);
 			v = tri_v_b(ru, T);
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 		}
 	}
 	f3 vc = {vf.x + 0.5f * (vo.x - vb.x), vf.y + 0.5f * (vo.y - vb.y), vf.z + 0.5f * (vo.z - vb.z)};
-	const int e[6] = {ob - 100, ob + 100, ob - 10, ob + 10, ob - 1, ob + 1};
+	const int e[6] = {ob - kVX, ob + kVX, ob - kVY, ob + kVY, ob - 1, ob + 1};
 	f3 mn = vo, mx = vo;
 #pragma unroll
 	for (int d = 0; d < 6; ++d) {
